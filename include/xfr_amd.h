@@ -1,0 +1,193 @@
+/*
+ * xfr_amd.h -- C ABI of the MI355X-native excitation-backprop (EBP) saliency engine.
+ *
+ * Drop-in boundary for the hot path of stresearch/xfr:
+ *     python/xfr/models/whitebox.py:482-558   Whitebox.ebp / contrastive_ebp / truncated_contrastive_ebp
+ *     python/xfr/models/whitebox.py:742-785   Whitebox.encode / embeddings
+ * The reference has NO native layer (it is PyTorch hooks + autograd); this library replaces the three
+ * hooked forwards and the autograd sweep of whitebox.py:490-498 with a static layer program executed by
+ * hand-written HIP kernels for gfx950.  Each entry point below cites the reference code it stands in for.
+ *
+ * Conventions
+ *   - plain C types only; all device pointers are raw HIP device pointers (float32, contiguous);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); no entry point synchronises
+ *     the stream unless documented;
+ *   - every function returns an xfr_status; on failure xfr_last_error() holds a thread-local message;
+ *   - one engine per (process, device); calls on one engine must be serialised by the caller
+ *     (the reference is equally non-re-entrant: whitebox.py:291-296 mutable hook state);
+ *   - the engine never mutates caller buffers other than the documented outputs (the reference leaves
+ *     W+ installed in the caller's modules after ebp(): whitebox.py:371-377).
+ */
+#ifndef XFR_AMD_H
+#define XFR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XFR_AMD_ABI_VERSION 1
+
+typedef enum {
+    XFR_OK = 0,
+    XFR_INVALID_ARG = 1,        /* -> ValueError / AssertionError in the Python mirror            */
+    XFR_UNSUPPORTED_LAYER = 2,  /* -> ValueError (whitebox.py:403 Sigmoid/ELU/Tanh, unknown kinds) */
+    XFR_OOM = 3,
+    XFR_HIP_ERROR = 4,
+    XFR_STATE_ERROR = 5         /* e.g. weights not loaded */
+} xfr_status;
+
+/* Layer program op kinds.  "Hooked" kinds are leaf nn.Module calls of the reference (they receive the
+ * pre-forward/forward hooks of whitebox.py:306-437); G_* kinds are functional glue between modules
+ * (torch.add, torch.max, F.normalize) that the reference's hooks never see. */
+typedef enum {
+    XFR_OP_CONV = 1,        /* nn.Conv2d                      resnet.py:116-122,177; lightcnn.py:53        */
+    XFR_OP_BATCHNORM = 2,   /* nn.BatchNorm2d (eval)          resnet.py:118,179                             */
+    XFR_OP_RELU = 3,        /* nn.ReLU(inplace=True)          resnet.py:124                                 */
+    XFR_OP_MAXPOOL = 4,     /* nn.MaxPool2d                   resnet.py:181; resnet50_128.py:16 (ceil_mode)  */
+    XFR_OP_AVGPOOL = 5,     /* nn.AvgPool2d                   resnet.py:186,211; lightcnn.py:237            */
+    XFR_OP_ADD = 6,         /* Add module (2 inputs)          resnet.py:104-108; lightcnn.py:33-37          */
+    XFR_OP_CONCAT = 7,      /* ConcatChannels (zero pad)      resnet.py:152-157                             */
+    XFR_OP_MULTIPLY = 8,    /* Multiply(n)                    resnet.py:160-165                             */
+    XFR_OP_LINEAR = 9,      /* nn.Linear (on flattened CHW)   resnet.py:187-189; lightcnn.py:228-229        */
+    XFR_OP_SPLIT = 10,      /* Split module (identity view)   lightcnn.py:39-45                             */
+    XFR_OP_G_ADD = 11,      /* functional a+b                 resnet50_128.py:187; lightcnn.py:252          */
+    XFR_OP_G_MAXHALVES = 12,/* torch.max(split[0], split[1])  lightcnn.py:62                                */
+    XFR_OP_G_NORMALIZE = 13 /* F.normalize(p=2, dim=1)        resnet.py:250                                 */
+} xfr_op_kind;
+
+/* One record of the static layer program (call order == the reference's forward call order).
+ * Tensor id 0 is the network input; every op defines exactly one new tensor id `out`
+ * (ids must be 1,2,3,... in op order).  All tensors are logically N x C x H x W. */
+typedef struct {
+    int32_t kind;        /* xfr_op_kind */
+    int32_t in0;         /* first input tensor id  */
+    int32_t in1;         /* second input tensor id (ADD, G_ADD) or -1 */
+    int32_t out;         /* output tensor id */
+    int32_t cout;        /* CONV/LINEAR: output channels; CONCAT: number of zero copies appended (resnet.py:157) */
+    int32_t kh, kw;      /* CONV/MAXPOOL/AVGPOOL kernel; LINEAR: must equal the input H, W */
+    int32_t stride;
+    int32_t pad;
+    int32_t ceil_mode;   /* MAXPOOL */
+    int32_t inplace;     /* RELU: 1 = nn.ReLU(inplace=True) (hook lands on the output tensor) */
+    float   fparam;      /* MULTIPLY: n;  BATCHNORM: eps */
+    int32_t w_weight;    /* index into the weight table, or -1 */
+    int32_t w_bias;      /* index into the weight table, or -1 */
+    int32_t w_mean;      /* BATCHNORM running_mean */
+    int32_t w_var;       /* BATCHNORM running_var  */
+} xfr_op_desc;
+
+/* A host-memory view of one parameter tensor (float32, contiguous, PyTorch layout:
+ * Conv [Cout][Cin][kh][kw], Linear [out][in], BatchNorm vectors [C]). */
+typedef struct {
+    const float* data;
+    int64_t      numel;
+} xfr_tensor_view;
+
+/* ebp_subtree_mode of whitebox.py:262-263,396-430 */
+typedef enum {
+    XFR_MODE_AFFINEONLY = 0,
+    XFR_MODE_AFFINEONLY_WITH_PRIOR = 1,
+    XFR_MODE_NORELU = 2,
+    XFR_MODE_ALL = 3
+} xfr_subtree_mode;
+
+typedef struct xfr_engine xfr_engine;
+
+/* Version of this ABI (XFR_AMD_ABI_VERSION of the library that was loaded). */
+int32_t xfr_abi_version(void);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* xfr_last_error(void);
+
+/* Build an engine for one backbone on HIP device `device`.
+ * Stands in for: Whitebox.__init__ (whitebox.py:261-304: hook installation over every leaf module) plus the
+ * backbone constructors (resnet.py:168-198, resnet50_128.py:6-170, lightcnn.py:216-247).
+ * `ops`/`n_ops`: the layer program; `n_weights`: size of the weight table the ops index into;
+ * (in_c,in_h,in_w): input image shape; `max_batch`: largest N accepted by the run calls.
+ * Workspace for activations (A), positive activations (X) and two gradient streams is allocated here. */
+xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_weights,
+                             int32_t in_c, int32_t in_h, int32_t in_w,
+                             int32_t max_batch, int32_t device, xfr_engine** out);
+
+xfr_status xfr_engine_destroy(xfr_engine* e);
+
+/* Upload and pack the parameters (W, W+ = relu(W), transposed/flipped W+ for the backward-data GEMMs,
+ * folded eval-mode BatchNorm scale/shift for gamma and relu(gamma)).
+ * Stands in for: load_state_dict (resnet.py:277-279) and for the per-forward weight save / relu / restore
+ * dance of whitebox.py:309-324,333-346,371-377, which becomes a one-off pack. */
+xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* weights, int32_t n_weights);
+
+/* Device address and size of the packed parameter arena, so that a multi-GPU launcher can broadcast it
+ * (rank 0 loads, the others receive: replaces the per-job torch.load of
+ * eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:74).  After writing into the arena of an
+ * engine that never called xfr_engine_load_weights, call xfr_engine_mark_weights_loaded. */
+xfr_status xfr_engine_weight_arena(xfr_engine* e, void** dev_ptr, size_t* bytes);
+xfr_status xfr_engine_mark_weights_loaded(xfr_engine* e);
+
+/* Whitebox(..., with_bias, eps, ebp_subtree_mode) -- whitebox.py:262-304. */
+xfr_status xfr_engine_set_mode(xfr_engine* e, int32_t subtree_mode, float eps, int32_t with_bias);
+
+/* Number of tensors / shape of a tensor of the program (C,H,W), for wrappers and tests. */
+xfr_status xfr_engine_tensor_shape(xfr_engine* e, int32_t tensor_id, int32_t* c, int32_t* h, int32_t* w);
+
+/* Forward only.  Stands in for WhiteboxNetwork.encode / classify (whitebox.py:58-64,98-103,126-133,222-230).
+ * x_dev: N x in_c x in_h x in_w (NCHW).  The true values of tensor `tensor_id` are written to out_dev as
+ * N x C x H x W (NCHW).  */
+xfr_status xfr_forward(xfr_engine* e, const float* x_dev, int32_t n, int32_t tensor_id,
+                       float* out_dev, void* stream);
+
+/* Excitation backprop.  Stands in for Whitebox.ebp(x, Pn, mwp=True) (whitebox.py:482-504): the 'activation',
+ * 'positive_activation' and 'ebp' forwards (:490-497) and Xn.backward(Pn) with the _backward_ebp tensor hooks
+ * (:381-430, :498).
+ *   x_dev        N x in_c x in_h x in_w
+ *   n_streams    S = 1 (ebp) or 2 (the mate and non-mate sweeps of contrastive_ebp :514,:520 share one forward)
+ *   seed_tensor  tensor id at which the gradient seed is injected: the classify() output when the classifier is
+ *                hooked (seed = Pn), or the encode() tensor when the classifier is the un-hooked triplet layer
+ *                of set_triplet_classifier (whitebox.py:93-96; seed = Pn @ W_cls, computed by the caller)
+ *   seed_dev     S x N x D  (D = C*H*W of seed_tensor)
+ * Outputs (either may be NULL):
+ *   mwp_dev      S x N x C1 x H1 x W1 : P[-2], the MWP at the first conv's output (whitebox.py:499 before pooling)
+ *   pooled_dev   S x N x H1 x W1      : sum over channels of P[-2]          (whitebox.py:499)
+ */
+xfr_status xfr_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32_t n_streams,
+                   int32_t seed_tensor, const float* seed_dev,
+                   float* mwp_dev, float* pooled_dev, void* stream);
+
+/* Contrastive / truncated contrastive EBP for a batch of independent probes.
+ * Stands in for Whitebox.contrastive_ebp (whitebox.py:506-527) when percentile < 0 and
+ * Whitebox.truncated_contrastive_ebp (whitebox.py:529-558) when 0 <= percentile <= 100, applied per sample,
+ * followed by _mwp_to_saliency (ebp_ver 6 branch, whitebox.py:456-459: gaussian sigma=2 'nearest', clamp, /sum).
+ *   seed_dev  2 x N x D : stream 0 = mate (k_poschannel), stream 1 = non-mate (k_negchannel)
+ *   sal_dev   N x H1 x W1 saliency maps (each sums to 1) */
+xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n,
+                           int32_t seed_tensor, const float* seed_dev, float percentile,
+                           float* sal_dev, void* stream);
+
+/* _mwp_to_saliency (whitebox.py:448-460, ebp_ver 6) on N pooled maps: in N x H x W -> out N x H x W. */
+xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w,
+                               float* sal_dev, void* stream);
+
+/* Debug / parity: after an xfr_ebp call made while tracing is enabled, the per-firing trace
+ * sum(P[i]) (what the golden fixtures store for every entry of Whitebox.P, whitebox.py:394).
+ * xfr_engine_set_trace(e, 1) makes xfr_ebp record it (slower).  `sums` receives n_firings x S x N doubles
+ * in the reference's firing order; `kinds` (may be NULL) receives the xfr_op_kind of the hooked module. */
+xfr_status xfr_engine_set_trace(xfr_engine* e, int32_t enable);
+xfr_status xfr_engine_trace_size(xfr_engine* e, int32_t* n_firings);
+xfr_status xfr_engine_get_trace(xfr_engine* e, double* sums, int32_t* kinds, int32_t capacity);
+
+/* Bytes of device memory held by the engine (weights + workspace). */
+xfr_status xfr_engine_memory(xfr_engine* e, size_t* weight_bytes, size_t* workspace_bytes);
+
+/* Duration in ms of the conv/linear GEMM launches of the most recent run call (sum of HIP-event timings on the
+ * run's stream) and their count and algorithmic FLOPs; enabled by xfr_engine_set_profile(e, 1).  Used by
+ * bench.py for the live roofline figure. */
+xfr_status xfr_engine_set_profile(xfr_engine* e, int32_t enable);
+xfr_status xfr_engine_get_profile(xfr_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFR_AMD_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of libxfr_amd.so (C ABI: include/xfr_amd.h).  Fails loudly; there is no fallback path."""
+import ctypes
+import os
+
+from .program import OpDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libxfr_amd.so')
+
+XFR_OK, XFR_INVALID_ARG, XFR_UNSUPPORTED_LAYER, XFR_OOM, XFR_HIP_ERROR, XFR_STATE_ERROR = range(6)
+ABI_VERSION = 1
+
+
+class TensorView(ctypes.Structure):
+    _fields_ = [('data', ctypes.c_void_p), ('numel', ctypes.c_int64)]
+
+
+class XfrError(RuntimeError):
+    def __init__(self, status, msg):
+        RuntimeError.__init__(self, msg)
+        self.status = status
+
+
+# every symbol include/xfr_amd.h declares: (name, restype, argtypes)
+_P = ctypes.c_void_p
+_I = ctypes.c_int32
+_F = ctypes.c_float
+SYMBOLS = [
+    ('xfr_abi_version', _I, []),
+    ('xfr_last_error', ctypes.c_char_p, []),
+    ('xfr_engine_create', _I, [ctypes.POINTER(OpDesc), _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_P)]),
+    ('xfr_engine_destroy', _I, [_P]),
+    ('xfr_engine_load_weights', _I, [_P, ctypes.POINTER(TensorView), _I]),
+    ('xfr_engine_weight_arena', _I, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_size_t)]),
+    ('xfr_engine_mark_weights_loaded', _I, [_P]),
+    ('xfr_engine_set_mode', _I, [_P, _I, _F, _I]),
+    ('xfr_engine_tensor_shape', _I, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    ('xfr_forward', _I, [_P, _P, _I, _I, _P, _P]),
+    ('xfr_ebp', _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    ('xfr_contrastive', _I, [_P, _P, _I, _I, _P, _F, _P, _P]),
+    ('xfr_mwp_to_saliency', _I, [_P, _P, _I, _I, _I, _P, _P]),
+    ('xfr_engine_set_trace', _I, [_P, _I]),
+    ('xfr_engine_trace_size', _I, [_P, ctypes.POINTER(_I)]),
+    ('xfr_engine_get_trace', _I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), _I]),
+    ('xfr_engine_memory', _I, [_P, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    ('xfr_engine_set_profile', _I, [_P, _I]),
+    ('xfr_engine_get_profile', _I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                    ctypes.POINTER(ctypes.c_double)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library.  Raises if it has not been built: the product has no other compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('xfr_amd: %s is missing -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          'or `make -C xfr_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)      # AttributeError if the ABI symbol is absent
+        fn.restype = restype
+        fn.argtypes = argtypes
+    v = lib.xfr_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError('xfr_amd: ABI version mismatch (library %d, binding %d)' % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status == XFR_OK:
+        return
+    msg = load().xfr_last_error().decode('utf-8', 'replace')
+    if status == XFR_INVALID_ARG:
+        raise ValueError(msg)
+    if status == XFR_UNSUPPORTED_LAYER:
+        raise ValueError(msg)
+    if status == XFR_OOM:
+        raise MemoryError(msg)
+    raise XfrError(status, msg)

@@ -1,0 +1,107 @@
+// common.h -- shared declarations of the xfr_amd HIP engine (gfx950 only).
+//
+// Tensor layout in HBM: every activation / gradient tensor is stored CNHW, i.e. [C][NB][H][W] with NB the
+// number of images in flight (N for forward tensors, S*N for the S gradient streams).  With the batch folded
+// inside the channel, a 1x1 stride-1 convolution over the whole batch is ONE plain row-major GEMM
+// Out[Cout][NB*H*W] = W[Cout][Cin] * In[Cin][NB*H*W], tiles may straddle image boundaries, and the spatial
+// index -- the contiguous one -- is the MFMA "B" lane index, so both the im2col gather and the epilogue
+// stores are coalesced along it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define XFR_MAX_EW_STEPS 10
+
+// ---- implicit-GEMM convolution -------------------------------------------------------------------------------
+struct ConvParams {
+    const float* in;    // [Cin][NB][H][W]
+    const float* w;     // packed [K][ldw], K = Cin*kh*kw ordered (ci, kh, kw); column = output channel
+    const float* w_pos; // second weight matrix of a dual launch (relu(W)), same packing
+    const float* bias;  // [CoutTot] or nullptr
+    const float* bias_pos;
+    float* out0;        // output of half 0 (w, bias)
+    float* out1;        // output of half 1 (w_pos, bias_pos) when nhalves == 2
+    int Cin, H, W, NB;
+    int kh, kw, stride, pad;
+    int OH, OW;
+    int K, M;           // M = NB*OH*OW
+    int CoutTot, nhalves, ldw;   // CoutTot = output channels per half
+    int relu_in;        // clamp the gathered input at 0 (A = relu(input))
+    int accumulate;     // out += result
+    int out_H, out_W, out_stride;  // out_stride > 1: scatter the (OH,OW) grid into an (out_H,out_W) tensor
+};
+
+void launch_conv_gemm(const ConvParams& p, hipStream_t s);
+
+// ---- fused elementwise backward chain ------------------------------------------------------------------------
+enum { EW_HOOK = 0, EW_MASK = 1, EW_SCALE_C = 2, EW_SCALE = 3 };
+enum { HOOK_DIV = 0, HOOK_RELU = 1, HOOK_PASS = 2 };
+
+struct EwStep {
+    int type;
+    int action;        // HOOK_*
+    const float* p0;   // HOOK: a source (relu applied on load);  MASK: tensor whose sign gates;  SCALE_C: per-channel vector
+    const float* p1;   // HOOK: x source (relu applied on load), nullptr => x = a
+    float* pstore;     // HOOK: if non-null, p is stored here (same indexing as the gradient)
+    double* trace;     // HOOK: if non-null, sum(p) per (stream,sample) is accumulated at trace[sb]
+    float f;           // SCALE: factor
+};
+
+struct EwChain {
+    int n;
+    EwStep s[XFR_MAX_EW_STEPS];
+};
+
+// g = src[idx]; run chain; dst[idx] = (accumulate ? dst[idx] : 0) + g.   Tensors are [C][SB][HW] for the gradient
+// and [C][B][HW] for the forward-side sources (sample b = sb % B).
+void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain& chain,
+                     int C, int SB, int B, int HW, float eps, hipStream_t s);
+
+// ---- simple forward / backward kernels -----------------------------------------------------------------------
+void launch_nchw_to_cnhw(const float* in, float* out, int N, int C, int HW, hipStream_t s);
+void launch_cnhw_to_nchw(const float* in, float* out, int N, int C, int HW, hipStream_t s);
+// out = maybe_relu( maybe_relu_in(in) * alpha[c] + beta[c] )
+void launch_affine_c(const float* in, float* out, const float* alpha, const float* beta, int C, long per_c,
+                     int relu_in, int relu_out, hipStream_t s);
+void launch_relu(const float* in, float* out, long n, hipStream_t s);
+void launch_scale(const float* in, float* out, long n, float f, int relu_in, hipStream_t s);
+// out = maybe_relu_out( maybe_relu_in(a) + maybe_relu_in(b) )
+void launch_add2(const float* a, const float* b, float* out, long n, int relu_a, int relu_b, int relu_out, hipStream_t s);
+// dst (+)= src
+void launch_copy_acc(const float* src, float* dst, long n, int accumulate, hipStream_t s);
+void launch_maxpool_fwd(const float* in, float* out, uint8_t* idx, int CN, int H, int W, int OH, int OW,
+                        int k, int stride, int pad, hipStream_t s);
+// gin (+)= scatter of gout through the stored argmax; gradient batch SB vs forward batch B
+void launch_maxpool_bwd(const float* gout, const uint8_t* idx, float* gin, int accumulate, int C, int SB, int B,
+                        int H, int W, int OH, int OW, int k, int stride, int pad, hipStream_t s);
+void launch_avgpool_fwd(const float* in, float* out, int CN, int H, int W, int OH, int OW, int k, int stride,
+                        int relu_in, hipStream_t s);
+void launch_avgpool_bwd(const float* gout, float* gin, int accumulate, int CN, int H, int W, int OH, int OW,
+                        int k, int stride, hipStream_t s);
+// out[c] = max(in[c], in[c+Co]) ; optional relu on load
+void launch_maxhalves_fwd(const float* in, float* out, int Co, long per_c, int relu_in, hipStream_t s);
+// gin[2Co] from gout[Co] using the TRUE forward input tin (ties split evenly, like at::maximum backward)
+void launch_maxhalves_bwd(const float* gout, const float* tin, float* gin, int accumulate, int Co, int SB, int B,
+                          int HW, hipStream_t s);
+// per-sample L2 normalise over channels: tensor [C][NB] (HW == 1)
+void launch_normalize_fwd(const float* in, float* out, float* norms, int C, int NB, int relu_in, hipStream_t s);
+void launch_normalize_bwd(const float* gout, const float* tin, const float* norms, float* gin, int accumulate,
+                          int C, int SB, int B, hipStream_t s);
+// seed [S][N][D] (D = C*HW, NCHW order inside a sample) -> gradient tensor [C][S*N][HW]
+void launch_seed_to_cnhw(const float* seed, float* g, int SB, int C, int HW, hipStream_t s);
+void launch_fill(float* p, long n, float v, hipStream_t s);
+
+// ---- saliency post-processing --------------------------------------------------------------------------------
+// pooled[sb][hw] = sum_c P[c][sb][hw]
+void launch_channel_pool(const float* P, float* pooled, int C, int SB, int HW, hipStream_t s);
+// sums[sb] = sum over (c,hw) of P[c][sb][hw]  (double accumulation)
+void launch_sample_sums(const float* P, double* sums, int C, int SB, int HW, hipStream_t s);
+// contrast[n][hw] = sum_c relu(keep * (P[c][n][hw]/sum_n - P[c][N+n][hw]/sum_{N+n})), keep = P/sum >= thr[n] (thr may be null)
+void launch_contrast(const float* P, const double* sums, const float* thr, float* out, int C, int N, int HW, hipStream_t s);
+// per-sample truncation threshold of whitebox.py:550-553 on m = P[:, n, :]/sum_n: smallest value v such that the
+// ascending cumulative sum reaches percentile% of the total at v.
+void launch_truncation_threshold(const float* P, const double* sums, float percentile, float* thr, void* scratch,
+                                 int C, int N, int HW, hipStream_t s);
+size_t truncation_scratch_bytes(int N);
+// gaussian(sigma=2, nearest, truncate 4) -> clamp -> /max(sum,eps)    in/out [N][H][W]; tmp same size
+void launch_saliency_blur(const float* in, float* tmp, float* out, int N, int H, int W, float eps, hipStream_t s);

@@ -1,0 +1,587 @@
+// elementwise.hip -- HBM-bound kernels of the EBP engine (gfx950): the fused hook chain of the MWP sweep,
+// eval-mode BatchNorm / ReLU / Add / pools / MaxFeatureMap forward and VJPs, layout conversion.
+//
+// All tensors are CNHW (common.h).  These kernels do no data reuse, so the rules that matter are coalescing
+// (consecutive lanes walk the contiguous H*W*NB run of one channel, float4 where alignment allows), enough
+// workgroups to cover 256 CUs several times over (grid-stride loops, 256-thread blocks = 4 wave64), and fusing
+// every elementwise step that touches the same gradient into ONE pass (EwChain) so that each gradient element is
+// read and written once between two GEMMs.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+inline int grid_for(long n, int per_thread = 1)
+{
+    long b = (n + (long)NT * per_thread - 1) / ((long)NT * per_thread);
+    if (b < 1) b = 1;
+    if (b > 256L * 32) b = 256L * 32;   // 32 workgroups per CU, grid-stride beyond
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The tensor hooks of whitebox.py:381-430 (+ ReLU / BatchNorm / Multiply VJPs), fused.
+//   zh = relu(z); p = a*zh;                                            (:388-389)
+//   DIV : z <- p / (x + eps)     RELU: z <- zh     PASS: z unchanged    (:396-430)
+// `a` and `x` are clamped at 0 on load (A = relu(input) :359, X = relu(input) :327).
+// The division is a true IEEE fp32 divide and ReLU zeros are exact: the eps = 1e-16 corner (x == 0 < a) is
+// where the reference's values jump by 1e16, and it must jump identically here.
+// ---------------------------------------------------------------------------------------------------------
+// Scalar kernel (any HW), with optional P store and trace.
+template <bool TRACE>
+__global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                     int accumulate, const EwChain ch, int C, int SB, int B, int HW,
+                                                     float eps)
+{
+    const long per_c = (long)SB * HW;
+    const long total = (long)C * per_c;
+    for (long base = (long)blockIdx.x * NT; base < total; base += (long)gridDim.x * NT) {
+        const long idx = base + threadIdx.x;
+        const bool ok = idx < total;
+        int c = 0, sb = 0;
+        long aidx = 0;
+        float g = 0.f;
+        if (ok) {
+            c = (int)(idx / per_c);
+            const long r = idx - (long)c * per_c;
+            sb = (int)(r / HW);
+            const int hw = (int)(r - (long)sb * HW);
+            const int b = sb % B;
+            aidx = ((long)c * B + b) * HW + hw;
+            g = src[idx];
+        }
+#pragma unroll 1
+        for (int i = 0; i < ch.n; ++i) {
+            const EwStep& st = ch.s[i];
+            if (st.type == EW_HOOK) {
+                float p = 0.f;
+                if (ok) {
+                    const float a = fmaxf(st.p0[aidx], 0.f);
+                    const float zh = fmaxf(g, 0.f);
+                    p = a * zh;
+                    if (st.pstore) st.pstore[idx] = p;
+                    if (st.action == HOOK_DIV) {
+                        const float x = st.p1 ? fmaxf(st.p1[aidx], 0.f) : a;
+                        g = __fdiv_rn(p, x + eps);
+                    } else if (st.action == HOOK_RELU) {
+                        g = zh;
+                    }
+                }
+                if (TRACE && st.trace) {
+                    // per-(stream,sample) sum of p; a block may straddle samples when HW < NT, so reduce per lane
+                    // run only when the whole wave shares sb, else fall back to per-lane atomics.
+                    const int sb0 = __shfl(sb, 0);
+                    const bool uniform = __all(!ok || sb == sb0);
+                    if (uniform) {
+                        double v = ok ? (double)p : 0.0;
+                        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+                        if ((threadIdx.x & 63) == 0 && __any(ok)) atomicAdd(&st.trace[sb0], v);
+                    } else if (ok) {
+                        atomicAdd(&st.trace[sb], (double)p);
+                    }
+                }
+            } else if (ok) {
+                if (st.type == EW_MASK) g = (st.p0[aidx] > 0.f) ? g : 0.f;
+                else if (st.type == EW_SCALE_C) g = g * st.p0[c];
+                else g = g * st.f;
+            }
+        }
+        if (ok) {
+            if (accumulate) g += dst[idx];
+            dst[idx] = g;
+        }
+    }
+}
+
+// float4 kernel: HW % 4 == 0, no trace.
+__global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                        int accumulate, const EwChain ch, int C, int SB, int B, int HW4,
+                                                        float eps)
+{
+    const long per_c = (long)SB * HW4;
+    const long total = (long)C * per_c;
+    for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
+        const int c = (int)(idx / per_c);
+        const long r = idx - (long)c * per_c;
+        const int sb = (int)(r / HW4);
+        const int hw = (int)(r - (long)sb * HW4);
+        const int b = sb % B;
+        const long aidx = ((long)c * B + b) * HW4 + hw;
+        float4 gv = src[idx];
+        float g[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll 1
+        for (int i = 0; i < ch.n; ++i) {
+            const EwStep& st = ch.s[i];
+            if (st.type == EW_HOOK) {
+                const float4 av = reinterpret_cast<const float4*>(st.p0)[aidx];
+                const float a[4] = {fmaxf(av.x, 0.f), fmaxf(av.y, 0.f), fmaxf(av.z, 0.f), fmaxf(av.w, 0.f)};
+                float p[4], zh[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { zh[q] = fmaxf(g[q], 0.f); p[q] = a[q] * zh[q]; }
+                if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(p[0], p[1], p[2], p[3]);
+                if (st.action == HOOK_DIV) {
+                    float x[4];
+                    if (st.p1) {
+                        const float4 xv = reinterpret_cast<const float4*>(st.p1)[aidx];
+                        x[0] = fmaxf(xv.x, 0.f); x[1] = fmaxf(xv.y, 0.f); x[2] = fmaxf(xv.z, 0.f); x[3] = fmaxf(xv.w, 0.f);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] = a[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = __fdiv_rn(p[q], x[q] + eps);
+                } else if (st.action == HOOK_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = zh[q];
+                }
+            } else if (st.type == EW_MASK) {
+                const float4 tv = reinterpret_cast<const float4*>(st.p0)[aidx];
+                g[0] = tv.x > 0.f ? g[0] : 0.f; g[1] = tv.y > 0.f ? g[1] : 0.f;
+                g[2] = tv.z > 0.f ? g[2] : 0.f; g[3] = tv.w > 0.f ? g[3] : 0.f;
+            } else if (st.type == EW_SCALE_C) {
+                const float sc = st.p0[c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] *= sc;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] *= st.f;
+            }
+        }
+        float4 o = make_float4(g[0], g[1], g[2], g[3]);
+        if (accumulate) { const float4 d = dst[idx]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+        dst[idx] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void nchw_to_cnhw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         int N, int C, int HW)
+{
+    const long total = (long)N * C * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        // i indexes the output [C][N][HW]
+        const int c = (int)(i / ((long)N * HW));
+        const long r = i - (long)c * N * HW;
+        const int n = (int)(r / HW);
+        const int hw = (int)(r - (long)n * HW);
+        out[i] = in[((long)n * C + c) * HW + hw];
+    }
+}
+
+__global__ __launch_bounds__(NT) void cnhw_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         int N, int C, int HW)
+{
+    const long total = (long)N * C * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        // i indexes the output [N][C][HW]
+        const int n = (int)(i / ((long)C * HW));
+        const long r = i - (long)n * C * HW;
+        const int c = (int)(r / HW);
+        const int hw = (int)(r - (long)c * HW);
+        out[i] = in[((long)c * N + n) * HW + hw];
+    }
+}
+
+__global__ __launch_bounds__(NT) void affine_c_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                     const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                     int C, long per_c, int relu_in, int relu_out)
+{
+    const long total = (long)C * per_c;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i / per_c);
+        float v = in[i];
+        if (relu_in) v = fmaxf(v, 0.f);
+        // at::native batch_norm inference: out = x * (w * invstd) + (b - mean * w * invstd), no fused multiply-add
+        v = __fadd_rn(__fmul_rn(v, alpha[c]), beta[c]);
+        if (relu_out) v = fmaxf(v, 0.f);
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void affine_c_kernel_v4(const float4* __restrict__ in, float4* __restrict__ out,
+                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                        int C, long per_c4, int relu_in, int relu_out)
+{
+    const long total = (long)C * per_c4;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i / per_c4);
+        const float al = alpha[c], be = beta[c];
+        float4 v = in[i];
+        float q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = q[k];
+            if (relu_in) t = fmaxf(t, 0.f);
+            t = __fadd_rn(__fmul_rn(t, al), be);
+            if (relu_out) t = fmaxf(t, 0.f);
+            q[k] = t;
+        }
+        out[i] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+}
+
+__global__ __launch_bounds__(NT) void scale_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float f,
+                                                  int relu_in)
+{
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        float v = in[i];
+        if (relu_in) v = fmaxf(v, 0.f);
+        out[i] = v * f;
+    }
+}
+
+__global__ __launch_bounds__(NT) void add2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ out, long n, int relu_a, int relu_b, int relu_out)
+{
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        float x = a[i], y = b[i];
+        if (relu_a) x = fmaxf(x, 0.f);
+        if (relu_b) y = fmaxf(y, 0.f);
+        float v = x + y;
+        if (relu_out) v = fmaxf(v, 0.f);
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void add2_kernel_v4(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                    float4* __restrict__ out, long n4, int relu_a, int relu_b, int relu_out)
+{
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        float4 x = a[i], y = b[i];
+        if (relu_a) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+        if (relu_b) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void copy_acc_kernel(const float* __restrict__ src, float* __restrict__ dst, long n,
+                                                     int accumulate)
+{
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        float v = src[i];
+        if (accumulate) v += dst[i];
+        dst[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void fill_kernel(float* __restrict__ p, long n, float v)
+{
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) p[i] = v;
+}
+
+// MaxPool2d forward: at::max_pool2d semantics -- the window is clipped to the input (padding = -inf), the first
+// maximum in (kh, kw) scan order wins, NaN propagates.  idx stores the window-local offset dh*k+dw of the winner.
+__global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        uint8_t* __restrict__ idx, int CN, int H, int W, int OH, int OW,
+                                                        int k, int stride, int pad)
+{
+    const long total = (long)CN * OH * OW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int cn = (int)(i / ((long)OH * OW));
+        const int r = (int)(i - (long)cn * OH * OW);
+        const int oh = r / OW, ow = r - oh * OW;
+        const float* src = in + (long)cn * H * W;
+        float best = -INFINITY;
+        int bi = 0;
+        bool first = true;
+        for (int dh = 0; dh < k; ++dh) {
+            const int ih = oh * stride - pad + dh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int dw = 0; dw < k; ++dw) {
+                const int iw = ow * stride - pad + dw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float v = src[ih * W + iw];
+                if (first || v > best || v != v) { best = v; bi = dh * k + dw; first = false; }
+            }
+        }
+        out[i] = best;
+        idx[i] = (uint8_t)bi;
+    }
+}
+
+__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
+                                                        float* __restrict__ gin, int accumulate, int C, int SB, int B,
+                                                        int H, int W, int OH, int OW, int k, int stride, int pad)
+{
+    const long total = (long)C * SB * H * W;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int csb = (int)(i / ((long)H * W));
+        const int r = (int)(i - (long)csb * H * W);
+        const int ih = r / W, iw = r - ih * W;
+        const int c = csb / SB, sb = csb - c * SB;
+        const int b = sb % B;
+        const uint8_t* ix = idx + ((long)c * B + b) * OH * OW;
+        const float* go = gout + (long)csb * OH * OW;
+        // output windows that contain (ih, iw): oh in [ceil((ih+pad-k+1)/stride), floor((ih+pad)/stride)]
+        int oh_lo = ih + pad - k + 1;
+        oh_lo = oh_lo > 0 ? (oh_lo + stride - 1) / stride : 0;
+        int oh_hi = (ih + pad) / stride;
+        if (oh_hi > OH - 1) oh_hi = OH - 1;
+        int ow_lo = iw + pad - k + 1;
+        ow_lo = ow_lo > 0 ? (ow_lo + stride - 1) / stride : 0;
+        int ow_hi = (iw + pad) / stride;
+        if (ow_hi > OW - 1) ow_hi = OW - 1;
+        float acc = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int dh = ih - (oh * stride - pad), dw = iw - (ow * stride - pad);
+                if ((int)ix[oh * OW + ow] == dh * k + dw) acc += go[oh * OW + ow];
+            }
+        if (accumulate) acc += gin[i];
+        gin[i] = acc;
+    }
+}
+
+// AvgPool2d, no padding (resnet.py:186,211; resnet50_128.py pool5; lightcnn.py:237): mean over k*k
+__global__ __launch_bounds__(NT) void avgpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int CN,
+                                                        int H, int W, int OH, int OW, int k, int stride, int relu_in)
+{
+    const long total = (long)CN * OH * OW;
+    const float inv = 1.0f / (float)(k * k);
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int cn = (int)(i / ((long)OH * OW));
+        const int r = (int)(i - (long)cn * OH * OW);
+        const int oh = r / OW, ow = r - oh * OW;
+        const float* src = in + (long)cn * H * W + (long)(oh * stride) * W + ow * stride;
+        float acc = 0.f;
+        for (int dh = 0; dh < k; ++dh)
+            for (int dw = 0; dw < k; ++dw) {
+                float v = src[dh * W + dw];
+                if (relu_in) v = fmaxf(v, 0.f);
+                acc += v;
+            }
+        out[i] = (k == 1) ? acc : acc * inv;
+    }
+}
+
+__global__ __launch_bounds__(NT) void avgpool_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin,
+                                                        int accumulate, int CN, int H, int W, int OH, int OW, int k,
+                                                        int stride)
+{
+    const long total = (long)CN * H * W;
+    const float inv = 1.0f / (float)(k * k);
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int cn = (int)(i / ((long)H * W));
+        const int r = (int)(i - (long)cn * H * W);
+        const int ih = r / W, iw = r - ih * W;
+        const float* go = gout + (long)cn * OH * OW;
+        int oh_lo = ih - k + 1;
+        oh_lo = oh_lo > 0 ? (oh_lo + stride - 1) / stride : 0;
+        int oh_hi = ih / stride;
+        if (oh_hi > OH - 1) oh_hi = OH - 1;
+        int ow_lo = iw - k + 1;
+        ow_lo = ow_lo > 0 ? (ow_lo + stride - 1) / stride : 0;
+        int ow_hi = iw / stride;
+        if (ow_hi > OW - 1) ow_hi = OW - 1;
+        float acc = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) acc += go[oh * OW + ow];
+        acc = (k == 1) ? acc : acc * inv;
+        if (accumulate) acc += gin[i];
+        gin[i] = acc;
+    }
+}
+
+// MaxFeatureMap glue: torch.max(split[0], split[1])  (lightcnn.py:62)
+__global__ __launch_bounds__(NT) void maxhalves_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int Co,
+                                                          long per_c, int relu_in)
+{
+    const long total = (long)Co * per_c;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        float a = in[i], b = in[i + total];
+        if (relu_in) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+        out[i] = (a != a) ? a : ((b != b) ? b : fmaxf(a, b));
+    }
+}
+
+__global__ __launch_bounds__(NT) void maxhalves_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ tin,
+                                                          float* __restrict__ gin, int accumulate, int Co, int SB, int B,
+                                                          int HW)
+{
+    const long per_c = (long)SB * HW;
+    const long total = (long)Co * per_c;
+    const long tper_c = (long)B * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i / per_c);
+        const long r = i - (long)c * per_c;
+        const int sb = (int)(r / HW);
+        const int hw = (int)(r - (long)sb * HW);
+        const long t = ((long)c * B + (sb % B)) * HW + hw;
+        const float a = tin[t], b = tin[t + (long)Co * tper_c];
+        const float g = gout[i];
+        // at::maximum backward: grad/2 to both on ties, else all to the larger
+        float ga = (a == b) ? g * 0.5f : (a > b ? g : 0.f);
+        float gb = (a == b) ? g * 0.5f : (a < b ? g : 0.f);
+        if (accumulate) { ga += gin[i]; gb += gin[i + total]; }
+        gin[i] = ga;
+        gin[i + total] = gb;
+    }
+}
+
+// F.normalize(x, p=2, dim=1) on a [C][NB] tensor: x / max(||x||_2, 1e-12)   (resnet.py:250)
+__global__ __launch_bounds__(64) void normalize_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          float* __restrict__ norms, int C, int NB, int relu_in)
+{
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) { float v = in[(long)c * NB + n]; if (relu_in) v = fmaxf(v, 0.f); acc += v * v; }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    acc = __shfl(acc, 0);
+    const float nrm = fmaxf(sqrtf(acc), 1e-12f);
+    if (lane == 0 && norms) norms[n] = nrm;
+    for (int c = lane; c < C; c += 64) {
+        float v = in[(long)c * NB + n];
+        if (relu_in) v = fmaxf(v, 0.f);
+        out[(long)c * NB + n] = v / nrm;
+    }
+}
+
+// VJP of y = x / ||x||:  gx = (g - y * <g, y>) / ||x||    (norm above the clamp)
+__global__ __launch_bounds__(64) void normalize_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ tin,
+                                                          const float* __restrict__ norms, float* __restrict__ gin,
+                                                          int accumulate, int C, int SB, int B)
+{
+    const int sb = blockIdx.x;
+    const int b = sb % B;
+    const int lane = threadIdx.x;
+    const float nrm = norms[b];
+    float dot = 0.f;
+    for (int c = lane; c < C; c += 64) dot += gout[(long)c * SB + sb] * (tin[(long)c * B + b] / nrm);
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
+    dot = __shfl(dot, 0);
+    for (int c = lane; c < C; c += 64) {
+        const float y = tin[(long)c * B + b] / nrm;
+        float v = (gout[(long)c * SB + sb] - y * dot) / nrm;
+        if (accumulate) v += gin[(long)c * SB + sb];
+        gin[(long)c * SB + sb] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void seed_to_cnhw_kernel(const float* __restrict__ seed, float* __restrict__ g, int SB,
+                                                         int C, int HW)
+{
+    const long total = (long)SB * C * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i / ((long)SB * HW));
+        const long r = i - (long)c * SB * HW;
+        const int sb = (int)(r / HW);
+        const int hw = (int)(r - (long)sb * HW);
+        g[i] = seed[((long)sb * C + c) * HW + hw];
+    }
+}
+
+}  // namespace
+
+void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain& chain, int C, int SB, int B, int HW,
+                     float eps, hipStream_t s)
+{
+    bool trace = false;
+    for (int i = 0; i < chain.n; ++i) if (chain.s[i].type == EW_HOOK && chain.s[i].trace) trace = true;
+    const long total = (long)C * SB * HW;
+    if (!trace && (HW % 4) == 0) {
+        hipLaunchKernelGGL(ew_chain_kernel_v4, dim3(grid_for(total / 4)), dim3(NT), 0, s,
+                           reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), accumulate, chain, C, SB, B,
+                           HW / 4, eps);
+    } else if (trace) {
+        hipLaunchKernelGGL(ew_chain_kernel<true>, dim3(grid_for(total)), dim3(NT), 0, s, src, dst, accumulate, chain, C, SB,
+                           B, HW, eps);
+    } else {
+        hipLaunchKernelGGL(ew_chain_kernel<false>, dim3(grid_for(total)), dim3(NT), 0, s, src, dst, accumulate, chain, C, SB,
+                           B, HW, eps);
+    }
+}
+
+void launch_nchw_to_cnhw(const float* in, float* out, int N, int C, int HW, hipStream_t s)
+{
+    hipLaunchKernelGGL(nchw_to_cnhw_kernel, dim3(grid_for((long)N * C * HW)), dim3(NT), 0, s, in, out, N, C, HW);
+}
+void launch_cnhw_to_nchw(const float* in, float* out, int N, int C, int HW, hipStream_t s)
+{
+    hipLaunchKernelGGL(cnhw_to_nchw_kernel, dim3(grid_for((long)N * C * HW)), dim3(NT), 0, s, in, out, N, C, HW);
+}
+void launch_affine_c(const float* in, float* out, const float* alpha, const float* beta, int C, long per_c, int relu_in,
+                     int relu_out, hipStream_t s)
+{
+    if ((per_c % 4) == 0)
+        hipLaunchKernelGGL(affine_c_kernel_v4, dim3(grid_for((long)C * per_c / 4)), dim3(NT), 0, s,
+                           reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), alpha, beta, C, per_c / 4,
+                           relu_in, relu_out);
+    else
+        hipLaunchKernelGGL(affine_c_kernel, dim3(grid_for((long)C * per_c)), dim3(NT), 0, s, in, out, alpha, beta, C, per_c,
+                           relu_in, relu_out);
+}
+void launch_relu(const float* in, float* out, long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(NT), 0, s, in, out, n, 1.0f, 1);
+}
+void launch_scale(const float* in, float* out, long n, float f, int relu_in, hipStream_t s)
+{
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(NT), 0, s, in, out, n, f, relu_in);
+}
+void launch_add2(const float* a, const float* b, float* out, long n, int relu_a, int relu_b, int relu_out, hipStream_t s)
+{
+    if ((n % 4) == 0)
+        hipLaunchKernelGGL(add2_kernel_v4, dim3(grid_for(n / 4)), dim3(NT), 0, s, reinterpret_cast<const float4*>(a),
+                           reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n / 4, relu_a, relu_b, relu_out);
+    else
+        hipLaunchKernelGGL(add2_kernel, dim3(grid_for(n)), dim3(NT), 0, s, a, b, out, n, relu_a, relu_b, relu_out);
+}
+void launch_copy_acc(const float* src, float* dst, long n, int accumulate, hipStream_t s)
+{
+    hipLaunchKernelGGL(copy_acc_kernel, dim3(grid_for(n)), dim3(NT), 0, s, src, dst, n, accumulate);
+}
+void launch_fill(float* p, long n, float v, hipStream_t s)
+{
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(NT), 0, s, p, n, v);
+}
+void launch_maxpool_fwd(const float* in, float* out, uint8_t* idx, int CN, int H, int W, int OH, int OW, int k, int stride,
+                        int pad, hipStream_t s)
+{
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long)CN * OH * OW)), dim3(NT), 0, s, in, out, idx, CN, H, W, OH, OW,
+                       k, stride, pad);
+}
+void launch_maxpool_bwd(const float* gout, const uint8_t* idx, float* gin, int accumulate, int C, int SB, int B, int H, int W,
+                        int OH, int OW, int k, int stride, int pad, hipStream_t s)
+{
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)C * SB * H * W)), dim3(NT), 0, s, gout, idx, gin, accumulate,
+                       C, SB, B, H, W, OH, OW, k, stride, pad);
+}
+void launch_avgpool_fwd(const float* in, float* out, int CN, int H, int W, int OH, int OW, int k, int stride, int relu_in,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)CN * OH * OW)), dim3(NT), 0, s, in, out, CN, H, W, OH, OW, k,
+                       stride, relu_in);
+}
+void launch_avgpool_bwd(const float* gout, float* gin, int accumulate, int CN, int H, int W, int OH, int OW, int k, int stride,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)CN * H * W)), dim3(NT), 0, s, gout, gin, accumulate, CN, H, W,
+                       OH, OW, k, stride);
+}
+void launch_maxhalves_fwd(const float* in, float* out, int Co, long per_c, int relu_in, hipStream_t s)
+{
+    hipLaunchKernelGGL(maxhalves_fwd_kernel, dim3(grid_for((long)Co * per_c)), dim3(NT), 0, s, in, out, Co, per_c, relu_in);
+}
+void launch_maxhalves_bwd(const float* gout, const float* tin, float* gin, int accumulate, int Co, int SB, int B, int HW,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(maxhalves_bwd_kernel, dim3(grid_for((long)Co * SB * HW)), dim3(NT), 0, s, gout, tin, gin, accumulate,
+                       Co, SB, B, HW);
+}
+void launch_normalize_fwd(const float* in, float* out, float* norms, int C, int NB, int relu_in, hipStream_t s)
+{
+    hipLaunchKernelGGL(normalize_fwd_kernel, dim3(NB), dim3(64), 0, s, in, out, norms, C, NB, relu_in);
+}
+void launch_normalize_bwd(const float* gout, const float* tin, const float* norms, float* gin, int accumulate, int C, int SB,
+                          int B, hipStream_t s)
+{
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(SB), dim3(64), 0, s, gout, tin, norms, gin, accumulate, C, SB, B);
+}
+void launch_seed_to_cnhw(const float* seed, float* g, int SB, int C, int HW, hipStream_t s)
+{
+    hipLaunchKernelGGL(seed_to_cnhw_kernel, dim3(grid_for((long)SB * C * HW)), dim3(NT), 0, s, seed, g, SB, C, HW);
+}

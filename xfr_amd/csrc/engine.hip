@@ -1,0 +1,1206 @@
+// engine.hip -- the C ABI (include/xfr_amd.h) and the layer-program executor of the EBP engine.
+//
+// What the reference does with forward hooks, pre-forward hooks, tensor hooks and a freshly recorded autograd
+// graph on every call (whitebox.py:306-437, :482-504) is done here once, at engine creation:
+//   * shape inference over the static layer program;
+//   * the hook table: which (module call, input) hooks sit on which tensor, in registration order, with the
+//     in-place-ReLU placement and the late-binding (a, x) of two-input Add modules;
+//   * a static analysis of the 'positive_activation' pass (whitebox.py:315-330): for every tensor whether its
+//     positive-pass value equals the true value (EQ), equals relu(true value) (RELU) or has to be computed
+//     (OTHER), so that X is only materialised where it differs from A;
+//   * the backward schedule: GEMMs for conv/linear VJPs with relu(W), and every elementwise step between two
+//     GEMMs (tensor hooks, ReLU masks, BatchNorm / Multiply VJPs) fused into one EwChain launch.
+#include "../../include/xfr_amd.h"
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+xfr_status fail(xfr_status st, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(_e == hipErrorOutOfMemory ? XFR_OOM : XFR_HIP_ERROR, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                                       \
+    } while (0)
+
+enum PState { PS_EQ = 0, PS_RELU = 1, PS_OTHER = 2 };
+
+struct Hook {
+    int op;        // hooked module call
+    int j;         // which input of that call
+    int a_tensor;  // tensor providing a (and x): the LAST input of the call (whitebox.py:379-381 late binding)
+};
+
+struct Tensor {
+    int C = 0, H = 0, W = 0;
+    int producer = -1;
+    std::vector<int> consumers;
+    bool nonneg = false;
+    int pstate = PS_OTHER;
+    int alias = -1;          // shares T storage with this tensor (in-place ReLU, Split)
+    size_t t_off = 0, pv_off = 0, g_off = 0;   // offsets (floats) into the workspace
+    bool need_pv = false;
+    std::vector<Hook> hooks;
+    long per_n() const { return (long)C * H * W; }
+    int HW() const { return H * W; }
+};
+
+struct OpRec {
+    xfr_op_desc d;
+    // packed parameter offsets (floats) into the arena; -1 if absent
+    long w_true = -1, w_pos = -1, w_bwd = -1;
+    long b_true = -1, b_pos = -1;            // conv/linear bias and relu(bias)
+    long bn_alpha_t = -1, bn_beta_t = -1, bn_alpha_p = -1, bn_beta_p = -1, bn_beta_pb = -1;
+    int ldw = 0, ldb = 0;
+    int Cin = 0, K = 0, Kb = 0;
+    size_t idx_off = 0;                      // maxpool argmax (bytes into idx workspace)
+    size_t norm_off = 0;                     // normalize: norms (floats into misc workspace)
+    bool fuse_relu = false;                  // forward: the following in-place ReLU is applied in this op's kernel
+    bool relu_fused_away = false;            // forward: this ReLU is executed by its producer
+};
+
+enum StepKind { ST_EW, ST_CONV_BWD, ST_MAXPOOL_BWD, ST_AVGPOOL_BWD, ST_COPY, ST_MAXHALVES_BWD, ST_NORMALIZE_BWD, ST_ZERO };
+
+struct HookRef { int tensor; int hook; int slot; };
+
+struct BwdStep {
+    int kind;
+    int op = -1;
+    int src_t = -1, dst_t = -1;
+    int accumulate = 0;
+    long copy_elems_per_sb = 0;   // ST_COPY: channels to copy (prefix), dst/src channel counts differ for concat
+    // ST_EW: symbolic chain (resolved to pointers at run time)
+    struct Sym { int type; int action; int t0; int x_t; float f; int op; int slot; bool tap; };
+    std::vector<Sym> chain;
+    int ew_t = -1;     // tensor whose shape the chain runs over
+};
+
+struct BwdPlan {
+    int seed_tensor = -1;
+    int mode = -1;
+    std::vector<BwdStep> steps;
+    std::vector<int> firing_kinds;   // xfr_op_kind per firing, reference order
+    int n_firings = 0;
+};
+
+}  // namespace
+
+struct xfr_engine {
+    int device = 0;
+    int max_batch = 0;
+    int in_c = 0, in_h = 0, in_w = 0;
+    std::vector<OpRec> ops;
+    std::vector<Tensor> tens;
+    int n_weights = 0;
+    // parameters
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    bool weights_loaded = false;
+    // workspace
+    float* ws = nullptr;
+    size_t ws_floats = 0;
+    uint8_t* idx_ws = nullptr;
+    size_t idx_bytes = 0;
+    size_t x_off = 0, seed_off = 0, tap_off = 0, pooled_off = 0, blur_a_off = 0, blur_b_off = 0, misc_off = 0, thr_off = 0;
+    double* dbl_ws = nullptr;      // sums [2*maxB] + trace
+    size_t trace_cap = 0;          // firings capacity
+    void* trunc_ws = nullptr;
+    // mode
+    int mode = XFR_MODE_AFFINEONLY_WITH_PRIOR;
+    float eps = 1e-16f;
+    int with_bias = 0;
+    bool need_dirty = true;
+    // plans
+    std::vector<BwdPlan> plans;
+    // trace / profile
+    int trace_on = 0;
+    int last_trace_firings = 0, last_trace_sb = 0;
+    std::vector<int> last_trace_kinds;
+    int profile_on = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double prof_flops = 0.0;
+    double last_gemm_ms = 0.0;
+    long last_gemm_launches = 0;
+    double last_gemm_flops = 0.0;
+
+    float* T(int t) { const Tensor& x = tens[t]; return ws + tens[x.alias >= 0 ? root(t) : t].t_off; }
+    float* Pv(int t) { return ws + tens[t].pv_off; }
+    float* G(int t) { return ws + tens[t].g_off; }
+    int root(int t) const { while (tens[t].alias >= 0) t = tens[t].alias; return t; }
+};
+
+namespace {
+
+bool is_hooked(int kind) { return kind >= XFR_OP_CONV && kind <= XFR_OP_SPLIT; }
+bool is_affine_name(int kind)
+{   // whitebox.py:399/:409: 'Conv' | 'Linear' | 'AvgPool' | 'BatchNorm' in str(module)
+    return kind == XFR_OP_CONV || kind == XFR_OP_LINEAR || kind == XFR_OP_AVGPOOL || kind == XFR_OP_BATCHNORM;
+}
+
+int hook_action(int mode, int kind)
+{
+    switch (mode) {
+        case XFR_MODE_AFFINEONLY: return is_affine_name(kind) ? HOOK_DIV : HOOK_PASS;
+        case XFR_MODE_AFFINEONLY_WITH_PRIOR: return is_affine_name(kind) ? HOOK_DIV : HOOK_RELU;
+        default: return HOOK_DIV;   // 'norelu' without priors and 'all' (whitebox.py:416-428)
+    }
+}
+
+int pool_out(int in, int k, int s, int p, bool ceil_mode)
+{
+    int num = in + 2 * p - k;
+    int o = (ceil_mode ? (num + s - 1) / s : num / s) + 1;
+    if (ceil_mode && (o - 1) * s >= in + p) --o;   // last window must start inside the (left-padded) input
+    return o;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------------------------
+xfr_status build(xfr_engine* e, const xfr_op_desc* ops, int n_ops)
+{
+    e->tens.resize(n_ops + 1);
+    e->ops.resize(n_ops);
+    Tensor& in = e->tens[0];
+    in.C = e->in_c; in.H = e->in_h; in.W = e->in_w;
+    in.pstate = PS_EQ;
+    for (int k = 0; k < n_ops; ++k) {
+        OpRec& o = e->ops[k];
+        o.d = ops[k];
+        const xfr_op_desc& d = o.d;
+        if (d.out != k + 1) return fail(XFR_INVALID_ARG, "op %d: out tensor id must be %d (got %d)", k, k + 1, d.out);
+        if (d.in0 < 0 || d.in0 > k) return fail(XFR_INVALID_ARG, "op %d: bad in0 %d", k, d.in0);
+        const bool two = (d.kind == XFR_OP_ADD || d.kind == XFR_OP_G_ADD);
+        if (two && (d.in1 < 0 || d.in1 > k)) return fail(XFR_INVALID_ARG, "op %d: bad in1 %d", k, d.in1);
+        auto chkw = [&](int w) { return w >= -1 && w < e->n_weights; };
+        if (!chkw(d.w_weight) || !chkw(d.w_bias) || !chkw(d.w_mean) || !chkw(d.w_var))
+            return fail(XFR_INVALID_ARG, "op %d: weight index out of range", k);
+        const Tensor& a = e->tens[d.in0];
+        Tensor& t = e->tens[d.out];
+        t.producer = k;
+        e->tens[d.in0].consumers.push_back(k);
+        if (two) e->tens[d.in1].consumers.push_back(k);
+        switch (d.kind) {
+            case XFR_OP_CONV:
+            case XFR_OP_LINEAR: {
+                if (d.cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.stride <= 0 || d.pad < 0 || d.w_weight < 0)
+                    return fail(XFR_INVALID_ARG, "op %d: bad conv/linear geometry", k);
+                if (d.kind == XFR_OP_LINEAR && (d.kh != a.H || d.kw != a.W || d.pad != 0))
+                    return fail(XFR_INVALID_ARG, "op %d: linear kernel must equal the input extent %dx%d", k, a.H, a.W);
+                t.C = d.cout;
+                t.H = (a.H + 2 * d.pad - d.kh) / d.stride + 1;
+                t.W = (a.W + 2 * d.pad - d.kw) / d.stride + 1;
+                if (t.H <= 0 || t.W <= 0) return fail(XFR_INVALID_ARG, "op %d: empty conv output", k);
+                if (d.stride > 1 && !(d.kh == 1 && d.kw == 1) && k != 0)
+                    return fail(XFR_UNSUPPORTED_LAYER, "op %d: strided %dx%d convolution is only supported as the first layer "
+                                "(its backward-data pass is not needed for P[-2])", k, d.kh, d.kw);
+                o.Cin = a.C; o.K = a.C * d.kh * d.kw; o.Kb = d.cout * d.kh * d.kw;
+                t.nonneg = false; t.pstate = PS_OTHER;
+                break;
+            }
+            case XFR_OP_BATCHNORM:
+                if (d.w_weight < 0 || d.w_bias < 0 || d.w_mean < 0 || d.w_var < 0)
+                    return fail(XFR_INVALID_ARG, "op %d: batchnorm needs weight, bias, running_mean, running_var", k);
+                t.C = a.C; t.H = a.H; t.W = a.W; t.nonneg = false; t.pstate = PS_OTHER;
+                break;
+            case XFR_OP_RELU:
+                t.C = a.C; t.H = a.H; t.W = a.W; t.nonneg = true; t.pstate = PS_EQ;
+                if (d.inplace) {
+                    if (e->tens[d.in0].consumers.size() != 1)
+                        return fail(XFR_UNSUPPORTED_LAYER, "op %d: in-place ReLU on a tensor with other consumers", k);
+                    t.alias = d.in0;
+                }
+                break;
+            case XFR_OP_MAXPOOL:
+                if (d.kh != d.kw || d.kh <= 0 || d.kh > 15 || d.stride <= 0) return fail(XFR_INVALID_ARG, "op %d: bad maxpool", k);
+                t.C = a.C; t.H = pool_out(a.H, d.kh, d.stride, d.pad, d.ceil_mode != 0);
+                t.W = pool_out(a.W, d.kw, d.stride, d.pad, d.ceil_mode != 0);
+                t.nonneg = a.nonneg; t.pstate = a.nonneg ? PS_EQ : PS_RELU;
+                break;
+            case XFR_OP_AVGPOOL:
+                if (d.kh != d.kw || d.kh <= 0 || d.stride <= 0 || d.pad != 0) return fail(XFR_INVALID_ARG, "op %d: bad avgpool", k);
+                t.C = a.C; t.H = (a.H - d.kh) / d.stride + 1; t.W = (a.W - d.kw) / d.stride + 1;
+                t.nonneg = a.nonneg; t.pstate = a.nonneg ? PS_EQ : PS_OTHER;
+                break;
+            case XFR_OP_ADD:
+            case XFR_OP_G_ADD: {
+                const Tensor& b = e->tens[d.in1];
+                if (a.C != b.C || a.H != b.H || a.W != b.W) return fail(XFR_INVALID_ARG, "op %d: add shape mismatch", k);
+                t.C = a.C; t.H = a.H; t.W = a.W; t.nonneg = a.nonneg && b.nonneg;
+                if (d.kind == XFR_OP_ADD) t.pstate = (a.nonneg && b.nonneg) ? PS_EQ : PS_OTHER;
+                else t.pstate = (a.pstate == PS_EQ && b.pstate == PS_EQ) ? PS_EQ : PS_OTHER;
+                break;
+            }
+            case XFR_OP_CONCAT:
+                if (d.cout < 0) return fail(XFR_INVALID_ARG, "op %d: bad concat", k);
+                t.C = a.C * (1 + d.cout); t.H = a.H; t.W = a.W; t.nonneg = a.nonneg; t.pstate = a.nonneg ? PS_EQ : PS_RELU;
+                break;
+            case XFR_OP_MULTIPLY:
+                if (!(d.fparam > 0.f)) return fail(XFR_UNSUPPORTED_LAYER, "op %d: Multiply(n) needs n > 0", k);
+                t.C = a.C; t.H = a.H; t.W = a.W; t.nonneg = a.nonneg; t.pstate = a.nonneg ? PS_EQ : PS_RELU;
+                break;
+            case XFR_OP_SPLIT:
+                t.C = a.C; t.H = a.H; t.W = a.W; t.nonneg = a.nonneg; t.pstate = a.nonneg ? PS_EQ : PS_RELU;
+                t.alias = d.in0;
+                break;
+            case XFR_OP_G_MAXHALVES:
+                if (a.C % 2) return fail(XFR_INVALID_ARG, "op %d: max-of-halves needs an even channel count", k);
+                t.C = a.C / 2; t.H = a.H; t.W = a.W; t.nonneg = a.nonneg; t.pstate = a.pstate;
+                break;
+            case XFR_OP_G_NORMALIZE:
+                if (a.H != 1 || a.W != 1) return fail(XFR_UNSUPPORTED_LAYER, "op %d: normalize is only supported on N x C vectors", k);
+                t.C = a.C; t.H = 1; t.W = 1; t.nonneg = false; t.pstate = (a.pstate == PS_EQ) ? PS_EQ : PS_OTHER;
+                break;
+            default:
+                return fail(XFR_UNSUPPORTED_LAYER, "op %d: unsupported layer kind %d (Sigmoid/ELU/Tanh and friends are not "
+                            "supported, see whitebox.py:403)", k, d.kind);
+        }
+        if (t.nonneg && t.pstate == PS_RELU) t.pstate = PS_EQ;
+    }
+    // hook table (registration order == call order)
+    for (int k = 0; k < n_ops; ++k) {
+        const xfr_op_desc& d = e->ops[k].d;
+        if (!is_hooked(d.kind)) continue;
+        const int nin = (d.kind == XFR_OP_ADD) ? 2 : 1;
+        const int last_in = (nin == 2) ? d.in1 : d.in0;
+        for (int j = 0; j < nin; ++j) {
+            const int tin = (j == 0) ? d.in0 : d.in1;
+            const int ht = (d.kind == XFR_OP_RELU && d.inplace) ? d.out : tin;
+            Hook h; h.op = k; h.j = j; h.a_tensor = (d.kind == XFR_OP_RELU && d.inplace) ? d.out : last_in;
+            e->tens[ht].hooks.push_back(h);
+        }
+    }
+    // forward fusion: <BatchNorm | Add | functional add> followed by an in-place ReLU on its output
+    for (int k = 0; k + 1 < n_ops; ++k) {
+        const xfr_op_desc& d = e->ops[k].d;
+        const xfr_op_desc& nx = e->ops[k + 1].d;
+        if ((d.kind == XFR_OP_BATCHNORM || d.kind == XFR_OP_ADD || d.kind == XFR_OP_G_ADD) && nx.kind == XFR_OP_RELU &&
+            nx.inplace && nx.in0 == d.out) {
+            e->ops[k].fuse_relu = true;
+            e->ops[k + 1].relu_fused_away = true;
+        }
+    }
+    return XFR_OK;
+}
+
+// x source of a hook / positive-pass value of a tensor, as (pointer, relu-on-load)
+struct Src { const float* p; int relu; };
+
+Src pv_src(xfr_engine* e, int t)
+{
+    const Tensor& x = e->tens[t];
+    if (x.pstate == PS_EQ) return {e->T(t), 0};
+    if (x.pstate == PS_RELU) return {e->T(t), 1};
+    return {e->Pv(t), 0};
+}
+
+void mark_need(xfr_engine* e, int t)
+{
+    Tensor& x = e->tens[t];
+    if (x.pstate != PS_OTHER || x.need_pv) return;
+    x.need_pv = true;
+    if (x.producer < 0) return;
+    const xfr_op_desc& d = e->ops[x.producer].d;
+    if (!is_hooked(d.kind)) {   // glue consumes positive-pass values of its inputs
+        mark_need(e, d.in0);
+        if (d.kind == XFR_OP_G_ADD) mark_need(e, d.in1);
+    }
+}
+
+void compute_need(xfr_engine* e)
+{
+    for (auto& t : e->tens) t.need_pv = false;
+    for (size_t t = 0; t < e->tens.size(); ++t)
+        for (const Hook& h : e->tens[t].hooks)
+            if (hook_action(e->mode, e->ops[h.op].d.kind) == HOOK_DIV) {
+                // x of the hook = relu(positive-pass value of the call's LAST input); for an in-place ReLU the call's input
+                const xfr_op_desc& d = e->ops[h.op].d;
+                const int xt = (d.kind == XFR_OP_ADD) ? d.in1 : d.in0;
+                mark_need(e, xt);
+            }
+    e->need_dirty = false;
+    e->plans.clear();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+xfr_status allocate(xfr_engine* e)
+{
+    const size_t B = (size_t)e->max_batch;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
+    e->x_off = take(B * e->tens[0].per_n());
+    for (size_t t = 0; t < e->tens.size(); ++t) {
+        Tensor& x = e->tens[t];
+        if (x.alias < 0) x.t_off = take(B * x.per_n());
+    }
+    for (size_t t = 0; t < e->tens.size(); ++t) {
+        Tensor& x = e->tens[t];
+        if (x.pstate == PS_OTHER) x.pv_off = take(B * x.per_n());
+    }
+    for (size_t t = 1; t < e->tens.size(); ++t) e->tens[t].g_off = take(2 * B * e->tens[t].per_n());
+    size_t max_per_n = 0;
+    for (auto& x : e->tens) max_per_n = std::max(max_per_n, (size_t)x.per_n());
+    e->seed_off = take(2 * B * max_per_n);
+    const Tensor& t1 = e->tens[1];
+    e->tap_off = take(2 * B * t1.per_n());
+    e->pooled_off = take(2 * B * t1.HW());
+    e->blur_a_off = take(2 * B * std::max(t1.HW(), 1));
+    e->blur_b_off = take(2 * B * std::max(t1.HW(), 1));
+    e->thr_off = take(B);
+    // misc: normalize norms
+    size_t misc = 0;
+    size_t idxb = 0;
+    for (auto& o : e->ops) {
+        if (o.d.kind == XFR_OP_G_NORMALIZE) { o.norm_off = misc; misc += align_up(B, 64); }
+        if (o.d.kind == XFR_OP_MAXPOOL) { o.idx_off = idxb; idxb += align_up(B * e->tens[o.d.out].per_n(), 256); }
+    }
+    e->misc_off = take(std::max<size_t>(misc, 64));
+    e->ws_floats = off;
+    e->idx_bytes = std::max<size_t>(idxb, 256);
+    HIP_TRY(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
+    HIP_TRY(hipMalloc(&e->idx_ws, e->idx_bytes));
+    size_t hooks = 0;
+    for (auto& x : e->tens) hooks += x.hooks.size();
+    e->trace_cap = hooks;
+    HIP_TRY(hipMalloc(&e->dbl_ws, sizeof(double) * (2 * B + hooks * 2 * B + 64)));
+    HIP_TRY(hipMalloc(&e->trunc_ws, truncation_scratch_bytes((int)B)));
+    return XFR_OK;
+}
+
+// parameter arena layout
+xfr_status layout_arena(xfr_engine* e)
+{
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return (long)o; };
+    for (size_t k = 0; k < e->ops.size(); ++k) {
+        OpRec& o = e->ops[k];
+        const xfr_op_desc& d = o.d;
+        if (d.kind == XFR_OP_CONV || d.kind == XFR_OP_LINEAR) {
+            o.ldw = (int)align_up(d.cout, 128);
+            o.w_true = take((size_t)o.K * o.ldw);
+            o.w_pos = take((size_t)o.K * o.ldw);
+            if (k != 0) {
+                o.ldb = (int)align_up(o.Cin, 128);
+                o.w_bwd = take((size_t)o.Kb * o.ldb);
+            }
+            if (d.w_bias >= 0) { o.b_true = take(d.cout); o.b_pos = take(d.cout); }
+        } else if (d.kind == XFR_OP_BATCHNORM) {
+            const int C = e->tens[d.out].C;
+            o.bn_alpha_t = take(C); o.bn_beta_t = take(C); o.bn_alpha_p = take(C); o.bn_beta_p = take(C); o.bn_beta_pb = take(C);
+        }
+    }
+    e->arena_floats = std::max<size_t>(off, 64);
+    HIP_TRY(hipMalloc(&e->arena, e->arena_floats * sizeof(float)));
+    return XFR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct Prof {
+    xfr_engine* e;
+    hipStream_t s;
+};
+
+xfr_status run_conv(xfr_engine* e, const ConvParams& p, hipStream_t s)
+{
+    if (e->profile_on) {
+        if (e->ev_used == e->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            e->ev_pool.emplace_back(a, b);
+        }
+        auto& ev = e->ev_pool[e->ev_used++];
+        HIP_TRY(hipEventRecord(ev.first, s));
+        launch_conv_gemm(p, s);
+        HIP_TRY(hipEventRecord(ev.second, s));
+        e->prof_flops += 2.0 * (double)p.K * (double)p.M * (double)p.CoutTot;
+    } else {
+        launch_conv_gemm(p, s);
+    }
+    return XFR_OK;
+}
+
+void conv_geometry(xfr_engine* e, int k, int NB, ConvParams& p)
+{
+    const OpRec& o = e->ops[k];
+    const xfr_op_desc& d = o.d;
+    const Tensor& a = e->tens[d.in0];
+    const Tensor& t = e->tens[d.out];
+    memset(&p, 0, sizeof(p));
+    p.Cin = a.C; p.H = a.H; p.W = a.W; p.NB = NB;
+    p.kh = d.kh; p.kw = d.kw; p.stride = d.stride; p.pad = d.pad;
+    p.OH = t.H; p.OW = t.W;
+    p.K = o.K; p.M = NB * t.H * t.W;
+    p.ldw = o.ldw;
+    p.out_H = t.H; p.out_W = t.W; p.out_stride = 1;
+}
+
+// forward of op k on true values (and, for "dual" convolutions, the positive output in the same launch)
+xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
+{
+    OpRec& o = e->ops[k];
+    const xfr_op_desc& d = o.d;
+    const Tensor& a = e->tens[d.in0];
+    const Tensor& t = e->tens[d.out];
+    const long n_in = (long)B * a.per_n(), n_out = (long)B * t.per_n();
+    switch (d.kind) {
+        case XFR_OP_CONV:
+        case XFR_OP_LINEAR: {
+            ConvParams p;
+            conv_geometry(e, k, B, p);
+            p.in = e->T(d.in0);
+            p.w = e->arena + o.w_true;
+            p.bias = o.b_true >= 0 ? e->arena + o.b_true : nullptr;
+            p.out0 = e->T(d.out);
+            p.out1 = nullptr;
+            p.CoutTot = d.cout;
+            // dual launch: positive activations X = relu(W)*A + b from the same staged input tile.  Valid when the true
+            // input is already A (provably >= 0).
+            const bool dual = want_pos && t.need_pv && a.nonneg;
+            if (dual) {
+                p.w_pos = e->arena + o.w_pos;
+                p.bias_pos = o.b_true >= 0 ? e->arena + (e->with_bias ? o.b_pos : o.b_true) : nullptr;
+                p.out1 = e->Pv(d.out);
+                p.nhalves = 2;
+            } else p.nhalves = 1;
+            return run_conv(e, p, s);
+        }
+        case XFR_OP_BATCHNORM:
+            launch_affine_c(e->T(d.in0), e->T(d.out), e->arena + o.bn_alpha_t, e->arena + o.bn_beta_t, t.C, (long)B * t.HW(), 0,
+                            o.fuse_relu ? 1 : 0, s);
+            return XFR_OK;
+        case XFR_OP_RELU:
+            if (o.relu_fused_away) return XFR_OK;
+            launch_relu(e->T(d.in0), e->T(d.out), n_in, s);
+            return XFR_OK;
+        case XFR_OP_MAXPOOL:
+            launch_maxpool_fwd(e->T(d.in0), e->T(d.out), e->idx_ws + o.idx_off, a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, d.pad, s);
+            return XFR_OK;
+        case XFR_OP_AVGPOOL:
+            launch_avgpool_fwd(e->T(d.in0), e->T(d.out), a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, 0, s);
+            return XFR_OK;
+        case XFR_OP_ADD:
+        case XFR_OP_G_ADD:
+            launch_add2(e->T(d.in0), e->T(d.in1), e->T(d.out), n_out, 0, 0, o.fuse_relu ? 1 : 0, s);
+            return XFR_OK;
+        case XFR_OP_CONCAT:
+            launch_copy_acc(e->T(d.in0), e->T(d.out), n_in, 0, s);
+            if (n_out > n_in) launch_fill(e->T(d.out) + n_in, n_out - n_in, 0.f, s);
+            return XFR_OK;
+        case XFR_OP_MULTIPLY:
+            launch_scale(e->T(d.in0), e->T(d.out), n_in, d.fparam, 0, s);
+            return XFR_OK;
+        case XFR_OP_SPLIT:
+            return XFR_OK;
+        case XFR_OP_G_MAXHALVES:
+            launch_maxhalves_fwd(e->T(d.in0), e->T(d.out), t.C, (long)B * t.HW(), 0, s);
+            return XFR_OK;
+        case XFR_OP_G_NORMALIZE:
+            launch_normalize_fwd(e->T(d.in0), e->T(d.out), e->ws + e->misc_off + o.norm_off, t.C, B, 0, s);
+            return XFR_OK;
+    }
+    return fail(XFR_UNSUPPORTED_LAYER, "forward: unsupported kind %d", d.kind);
+}
+
+// positive pass for tensor out(k) (only called when need_pv and not produced by a dual launch)
+xfr_status pos_op(xfr_engine* e, int k, int B, hipStream_t s)
+{
+    OpRec& o = e->ops[k];
+    const xfr_op_desc& d = o.d;
+    const Tensor& a = e->tens[d.in0];
+    const Tensor& t = e->tens[d.out];
+    const long n_out = (long)B * t.per_n();
+    switch (d.kind) {
+        case XFR_OP_CONV:
+        case XFR_OP_LINEAR: {
+            ConvParams p;
+            conv_geometry(e, k, B, p);
+            p.in = e->T(d.in0);
+            p.relu_in = a.nonneg ? 0 : 1;
+            p.w = e->arena + o.w_pos;
+            p.bias = o.b_true >= 0 ? e->arena + (e->with_bias ? o.b_pos : o.b_true) : nullptr;
+            p.out0 = e->Pv(d.out);
+            p.CoutTot = d.cout; p.nhalves = 1;
+            return run_conv(e, p, s);
+        }
+        case XFR_OP_BATCHNORM:
+            launch_affine_c(e->T(d.in0), e->Pv(d.out), e->arena + o.bn_alpha_p, e->arena + (e->with_bias ? o.bn_beta_pb : o.bn_beta_p),
+                            t.C, (long)B * t.HW(), a.nonneg ? 0 : 1, 0, s);
+            return XFR_OK;
+        case XFR_OP_AVGPOOL:
+            launch_avgpool_fwd(e->T(d.in0), e->Pv(d.out), a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, a.nonneg ? 0 : 1, s);
+            return XFR_OK;
+        case XFR_OP_ADD: {
+            const Tensor& b = e->tens[d.in1];
+            launch_add2(e->T(d.in0), e->T(d.in1), e->Pv(d.out), n_out, a.nonneg ? 0 : 1, b.nonneg ? 0 : 1, 0, s);
+            return XFR_OK;
+        }
+        case XFR_OP_G_ADD: {
+            const Src x = pv_src(e, d.in0), y = pv_src(e, d.in1);
+            launch_add2(x.p, y.p, e->Pv(d.out), n_out, x.relu, y.relu, 0, s);
+            return XFR_OK;
+        }
+        case XFR_OP_G_MAXHALVES: {
+            const Src x = pv_src(e, d.in0);
+            launch_maxhalves_fwd(x.p, e->Pv(d.out), t.C, (long)B * t.HW(), x.relu, s);
+            return XFR_OK;
+        }
+        case XFR_OP_G_NORMALIZE: {
+            const Src x = pv_src(e, d.in0);
+            launch_normalize_fwd(x.p, e->Pv(d.out), nullptr, t.C, B, x.relu, s);
+            return XFR_OK;
+        }
+    }
+    return fail(XFR_UNSUPPORTED_LAYER, "positive pass: kind %d cannot have a computed positive value", d.kind);
+}
+
+xfr_status forward_all(xfr_engine* e, const float* x_dev, int B, int last_tensor, bool with_pos, hipStream_t s)
+{
+    const Tensor& in = e->tens[0];
+    launch_nchw_to_cnhw(x_dev, e->T(0), B, in.C, in.HW(), s);
+    const int last_op = e->tens[last_tensor].producer;
+    for (int k = 0; k <= last_op; ++k) {
+        xfr_status st = fwd_op(e, k, B, with_pos, s);
+        if (st != XFR_OK) return st;
+        if (with_pos) {
+            const Tensor& t = e->tens[e->ops[k].d.out];
+            const xfr_op_desc& d = e->ops[k].d;
+            if (t.need_pv) {
+                const bool dual_done = (d.kind == XFR_OP_CONV || d.kind == XFR_OP_LINEAR) && e->tens[d.in0].nonneg;
+                if (!dual_done) { st = pos_op(e, k, B, s); if (st != XFR_OK) return st; }
+            }
+        }
+    }
+    return XFR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward schedule
+bool unary_elementwise(int kind)
+{
+    return kind == XFR_OP_RELU || kind == XFR_OP_BATCHNORM || kind == XFR_OP_MULTIPLY || kind == XFR_OP_SPLIT;
+}
+
+xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan)
+{
+    const int nt = (int)e->tens.size();
+    plan.seed_tensor = seed_tensor;
+    plan.mode = e->mode;
+    plan.steps.clear();
+    // reachability: every op propagates to all of its inputs
+    std::vector<char> reach(nt, 0);
+    reach[seed_tensor] = 1;
+    for (int k = e->tens[seed_tensor].producer; k >= 0; --k) {
+        const xfr_op_desc& d = e->ops[k].d;
+        if (!reach[d.out]) continue;
+        reach[d.in0] = 1;
+        if (d.kind == XFR_OP_ADD || d.kind == XFR_OP_G_ADD) reach[d.in1] = 1;
+    }
+    // number of gradient contributors per tensor
+    std::vector<int> contrib(nt, 0);
+    for (int k = 0; k <= e->tens[seed_tensor].producer; ++k) {
+        const xfr_op_desc& d = e->ops[k].d;
+        if (!reach[d.out]) continue;
+        contrib[d.in0]++;
+        if (d.kind == XFR_OP_ADD || d.kind == XFR_OP_G_ADD) contrib[d.in1]++;
+    }
+    // firing order (reference): descending producer index, registration order within a tensor; image last
+    std::vector<std::vector<int>> slot(nt);
+    plan.firing_kinds.clear();
+    for (int k = e->tens[seed_tensor].producer; k >= 0; --k) {
+        const int t = e->ops[k].d.out;
+        if (!reach[t]) continue;
+        for (const Hook& h : e->tens[t].hooks) {
+            if (e->ops[h.op].d.out > seed_tensor) { slot[t].push_back(-1); continue; }   // call beyond the seed
+            slot[t].push_back((int)plan.firing_kinds.size());
+            plan.firing_kinds.push_back(e->ops[h.op].d.kind);
+        }
+    }
+    plan.n_firings = (int)plan.firing_kinds.size();   // (+1 for the image hook of op 0, which is not computed)
+
+    std::vector<char> written(nt, 0), hooks_done(nt, 0), op_done(e->ops.size(), 0);
+    written[seed_tensor] = 1;
+
+    auto append_hooks = [&](BwdStep& st, int t) -> bool {
+        const Tensor& x = e->tens[t];
+        for (size_t i = 0; i < x.hooks.size(); ++i) {
+            const Hook& h = x.hooks[i];
+            if (slot[t][i] < 0) continue;   // hook of a call that lies beyond the seed tensor
+            const xfr_op_desc& hd = e->ops[h.op].d;
+            BwdStep::Sym sy;
+            sy.type = EW_HOOK;
+            sy.action = hook_action(e->mode, hd.kind);
+            sy.t0 = h.a_tensor;
+            const int xt = (hd.kind == XFR_OP_ADD) ? hd.in1 : hd.in0;
+            sy.x_t = (e->tens[xt].pstate == PS_OTHER) ? xt : -1;   // -1: x == a
+            sy.f = 0.f; sy.op = h.op; sy.slot = slot[t][i]; sy.tap = false;
+            st.chain.push_back(sy);
+        }
+        hooks_done[t] = 1;
+        return true;
+    };
+
+    for (int k = e->tens[seed_tensor].producer; k >= 1; --k) {
+        if (op_done[k]) continue;
+        const int t0 = e->ops[k].d.out;
+        if (!reach[t0]) continue;
+        BwdStep ew;
+        ew.kind = ST_EW;
+        ew.src_t = t0;
+        ew.ew_t = t0;
+        if (!hooks_done[t0]) append_hooks(ew, t0);
+        int cur_op = k;
+        int cur_t = t0;
+        bool emitted = false;
+        while (true) {
+            const xfr_op_desc& d = e->ops[cur_op].d;
+            if (!unary_elementwise(d.kind)) break;
+            // VJP of the elementwise op
+            BwdStep::Sym sy;
+            sy.action = 0; sy.x_t = -1; sy.f = 0.f; sy.op = cur_op; sy.slot = -1; sy.tap = false; sy.t0 = -1;
+            bool has = true;
+            if (d.kind == XFR_OP_RELU) { sy.type = EW_MASK; sy.t0 = d.out; }
+            else if (d.kind == XFR_OP_BATCHNORM) { sy.type = EW_SCALE_C; }
+            else if (d.kind == XFR_OP_MULTIPLY) { sy.type = EW_SCALE; sy.f = d.fparam; }
+            else has = false;
+            if (has) ew.chain.push_back(sy);
+            op_done[cur_op] = 1;
+            const int ti = d.in0;
+            if (ti == 0) {   // reached the image: nothing below
+                emitted = true;   // nothing to store
+                ew.chain.clear();
+                break;
+            }
+            const bool single = (contrib[ti] == 1);
+            const bool room = (ew.chain.size() + e->tens[ti].hooks.size() + 2 <= XFR_MAX_EW_STEPS);
+            if (single && room && ti != 1) {
+                append_hooks(ew, ti);
+                cur_t = ti;
+                cur_op = e->tens[ti].producer;
+                if (op_done[cur_op]) break;
+                continue;
+            }
+            if (single && room && ti == 1) {
+                // tensor 1 = output of the first layer: its last hook is P[-2] (whitebox.py:499); stop here
+                append_hooks(ew, ti);
+                for (int q = (int)ew.chain.size() - 1; q >= 0; --q)
+                    if (ew.chain[q].type == EW_HOOK) { ew.chain[q].tap = true; break; }
+                ew.dst_t = 1; ew.accumulate = 0;
+                plan.steps.push_back(ew);
+                return XFR_OK;
+            }
+            // store into G[ti] (possibly accumulating); its hooks fire later when its producer is visited
+            ew.dst_t = ti; ew.accumulate = written[ti] ? 1 : 0;
+            written[ti] = 1;
+            plan.steps.push_back(ew);
+            emitted = true;
+            break;
+        }
+        if (emitted) continue;
+        // cur_t's producer (cur_op) is not elementwise (or already done): flush the chain in place, then its VJP
+        if (cur_t == 1) {
+            // hooks of tensor 1 were appended by a chain that started above; mark the tap
+            for (int q = (int)ew.chain.size() - 1; q >= 0; --q)
+                if (ew.chain[q].type == EW_HOOK) { ew.chain[q].tap = true; break; }
+            ew.dst_t = 1; ew.accumulate = 0;
+            plan.steps.push_back(ew);
+            return XFR_OK;
+        }
+        if (!ew.chain.empty() || cur_t != t0) {
+            ew.dst_t = cur_t; ew.accumulate = 0;
+            plan.steps.push_back(ew);
+            written[cur_t] = 1;
+        }
+        if (op_done[cur_op]) continue;
+        op_done[cur_op] = 1;
+        const xfr_op_desc& d = e->ops[cur_op].d;
+        BwdStep st;
+        st.op = cur_op; st.src_t = cur_t;
+        auto target = [&](int ti, BwdStep s2) {
+            if (ti == 0) return;   // no gradient wrt the image is needed for P[-2]
+            s2.dst_t = ti; s2.accumulate = written[ti] ? 1 : 0; written[ti] = 1;
+            plan.steps.push_back(s2);
+        };
+        switch (d.kind) {
+            case XFR_OP_CONV:
+            case XFR_OP_LINEAR:
+                if (d.stride > 1 && d.in0 != 0 && !written[d.in0]) {
+                    BwdStep z; z.kind = ST_ZERO; z.dst_t = d.in0; plan.steps.push_back(z); written[d.in0] = 1;
+                }
+                st.kind = ST_CONV_BWD; target(d.in0, st); break;
+            case XFR_OP_MAXPOOL: st.kind = ST_MAXPOOL_BWD; target(d.in0, st); break;
+            case XFR_OP_AVGPOOL: st.kind = ST_AVGPOOL_BWD; target(d.in0, st); break;
+            case XFR_OP_ADD:
+            case XFR_OP_G_ADD:
+                st.kind = ST_COPY; st.copy_elems_per_sb = e->tens[cur_t].C;
+                target(d.in0, st); target(d.in1, st); break;
+            case XFR_OP_CONCAT:
+                st.kind = ST_COPY; st.copy_elems_per_sb = e->tens[d.in0].C; target(d.in0, st); break;
+            case XFR_OP_G_MAXHALVES: st.kind = ST_MAXHALVES_BWD; target(d.in0, st); break;
+            case XFR_OP_G_NORMALIZE: st.kind = ST_NORMALIZE_BWD; target(d.in0, st); break;
+            default:
+                return fail(XFR_UNSUPPORTED_LAYER, "backward: unsupported kind %d", d.kind);
+        }
+    }
+    return fail(XFR_STATE_ERROR, "backward schedule never reached the first layer's output");
+}
+
+xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out)
+{
+    for (auto& p : e->plans)
+        if (p.seed_tensor == seed_tensor && p.mode == e->mode) { *out = &p; return XFR_OK; }
+    e->plans.emplace_back();
+    xfr_status st = make_plan(e, seed_tensor, e->plans.back());
+    if (st != XFR_OK) { e->plans.pop_back(); return st; }
+    *out = &e->plans.back();
+    return XFR_OK;
+}
+
+xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t s)
+{
+    const int SB = S * B;
+    double* trace = e->dbl_ws + 2 * e->max_batch;
+    if (e->trace_on) {
+        HIP_TRY(hipMemsetAsync(trace, 0, sizeof(double) * (size_t)plan.n_firings * SB, s));
+        e->last_trace_firings = plan.n_firings;
+        e->last_trace_sb = SB;
+        e->last_trace_kinds = plan.firing_kinds;
+    }
+    for (const BwdStep& st : plan.steps) {
+        switch (st.kind) {
+            case ST_EW: {
+                EwChain ch;
+                ch.n = 0;
+                for (const auto& sy : st.chain) {
+                    EwStep& q = ch.s[ch.n++];
+                    memset(&q, 0, sizeof(q));
+                    q.type = sy.type;
+                    q.action = sy.action;
+                    q.f = sy.f;
+                    if (sy.type == EW_HOOK) {
+                        q.p0 = e->T(sy.t0);
+                        q.p1 = sy.x_t >= 0 ? e->Pv(sy.x_t) : nullptr;
+                        if (sy.tap) q.pstore = e->ws + e->tap_off;
+                        if (e->trace_on && sy.slot >= 0) q.trace = trace + (size_t)sy.slot * SB;
+                    } else if (sy.type == EW_MASK) {
+                        q.p0 = e->T(sy.t0);
+                    } else if (sy.type == EW_SCALE_C) {
+                        q.p0 = e->arena + e->ops[sy.op].bn_alpha_p;
+                    }
+                }
+                const Tensor& x = e->tens[st.ew_t];
+                launch_ew_chain(e->G(st.src_t), e->G(st.dst_t), st.accumulate, ch, x.C, SB, B, x.HW(), e->eps, s);
+                break;
+            }
+            case ST_ZERO:
+                launch_fill(e->G(st.dst_t), (long)SB * e->tens[st.dst_t].per_n(), 0.f, s);
+                break;
+            case ST_CONV_BWD: {
+                const OpRec& o = e->ops[st.op];
+                const xfr_op_desc& d = o.d;
+                const Tensor& a = e->tens[d.in0];
+                const Tensor& t = e->tens[d.out];
+                ConvParams p;
+                memset(&p, 0, sizeof(p));
+                p.in = e->G(st.src_t);
+                p.w = e->arena + o.w_bwd;
+                p.out0 = e->G(st.dst_t);
+                p.Cin = t.C; p.H = t.H; p.W = t.W; p.NB = SB;
+                p.CoutTot = a.C; p.nhalves = 1; p.ldw = o.ldb;
+                p.K = o.Kb;
+                p.accumulate = st.accumulate;
+                if (d.stride == 1) {
+                    // backward-data of a stride-1 convolution == convolution with the flipped, transposed kernel and
+                    // padding k-1-p
+                    p.kh = d.kh; p.kw = d.kw; p.stride = 1; p.pad = d.kh - 1 - d.pad;
+                    p.OH = a.H; p.OW = a.W;
+                    p.out_H = a.H; p.out_W = a.W; p.out_stride = 1;
+                } else {
+                    // 1x1 stride-s: the gradient lands on the sampled grid only
+                    p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0;
+                    p.OH = t.H; p.OW = t.W;
+                    p.out_H = a.H; p.out_W = a.W; p.out_stride = d.stride;
+                    p.accumulate = 1;   // the target was zero-filled or already holds other contributions
+                }
+                p.M = SB * p.OH * p.OW;
+                xfr_status rs = run_conv(e, p, s);
+                if (rs != XFR_OK) return rs;
+                break;
+            }
+            case ST_MAXPOOL_BWD: {
+                const OpRec& o = e->ops[st.op];
+                const xfr_op_desc& d = o.d;
+                const Tensor& a = e->tens[d.in0];
+                const Tensor& t = e->tens[d.out];
+                launch_maxpool_bwd(e->G(st.src_t), e->idx_ws + o.idx_off, e->G(st.dst_t), st.accumulate, a.C, SB, B, a.H, a.W, t.H,
+                                   t.W, d.kh, d.stride, d.pad, s);
+                break;
+            }
+            case ST_AVGPOOL_BWD: {
+                const xfr_op_desc& d = e->ops[st.op].d;
+                const Tensor& a = e->tens[d.in0];
+                const Tensor& t = e->tens[d.out];
+                launch_avgpool_bwd(e->G(st.src_t), e->G(st.dst_t), st.accumulate, a.C * SB, a.H, a.W, t.H, t.W, d.kh, d.stride, s);
+                break;
+            }
+            case ST_COPY: {
+                const Tensor& dt = e->tens[st.dst_t];
+                launch_copy_acc(e->G(st.src_t), e->G(st.dst_t), (long)st.copy_elems_per_sb * SB * dt.HW(), st.accumulate, s);
+                break;
+            }
+            case ST_MAXHALVES_BWD: {
+                const xfr_op_desc& d = e->ops[st.op].d;
+                const Tensor& t = e->tens[d.out];
+                launch_maxhalves_bwd(e->G(st.src_t), e->T(d.in0), e->G(st.dst_t), st.accumulate, t.C, SB, B, t.HW(), s);
+                break;
+            }
+            case ST_NORMALIZE_BWD: {
+                const OpRec& o = e->ops[st.op];
+                const xfr_op_desc& d = o.d;
+                const Tensor& t = e->tens[d.out];
+                launch_normalize_bwd(e->G(st.src_t), e->T(d.in0), e->ws + e->misc_off + o.norm_off, e->G(st.dst_t), st.accumulate,
+                                     t.C, SB, B, s);
+                break;
+            }
+        }
+    }
+    return XFR_OK;
+}
+
+xfr_status check_run(xfr_engine* e, const void* x, int n)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    if (!e->weights_loaded) return fail(XFR_STATE_ERROR, "weights not loaded");
+    if (!x) return fail(XFR_INVALID_ARG, "null input");
+    if (n < 1 || n > e->max_batch) return fail(XFR_INVALID_ARG, "batch %d outside [1, %d]", n, e->max_batch);
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->need_dirty) compute_need(e);
+    return XFR_OK;
+}
+
+void prof_begin(xfr_engine* e) { e->ev_used = 0; e->prof_flops = 0.0; }
+
+xfr_status prof_end(xfr_engine* e, hipStream_t s)
+{
+    if (!e->profile_on) return XFR_OK;
+    HIP_TRY(hipStreamSynchronize(s));
+    double ms = 0.0;
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e->ev_pool[i].first, e->ev_pool[i].second));
+        ms += t;
+    }
+    e->last_gemm_ms = ms;
+    e->last_gemm_launches = (long)e->ev_used;
+    e->last_gemm_flops = e->prof_flops;
+    return XFR_OK;
+}
+
+xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_tensor, const float* seed_dev, hipStream_t s)
+{
+    if (seed_tensor < 2 || seed_tensor >= (int)e->tens.size()) return fail(XFR_INVALID_ARG, "bad seed tensor %d", seed_tensor);
+    if (!seed_dev) return fail(XFR_INVALID_ARG, "null seed");
+    BwdPlan* plan = nullptr;
+    xfr_status st = get_plan(e, seed_tensor, &plan);
+    if (st != XFR_OK) return st;
+    st = forward_all(e, x_dev, n, seed_tensor, true, s);
+    if (st != XFR_OK) return st;
+    const Tensor& sd = e->tens[seed_tensor];
+    launch_seed_to_cnhw(seed_dev, e->G(seed_tensor), S * n, sd.C, sd.HW(), s);
+    return run_backward(e, *plan, n, S, s);
+}
+
+}  // namespace
+
+// ===================================================================================================================
+extern "C" {
+
+int32_t xfr_abi_version(void) { return XFR_AMD_ABI_VERSION; }
+
+const char* xfr_last_error(void) { return g_err.c_str(); }
+
+xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_weights, int32_t in_c, int32_t in_h, int32_t in_w,
+                             int32_t max_batch, int32_t device, xfr_engine** out)
+{
+    if (!ops || n_ops < 2 || !out || in_c < 1 || in_h < 1 || in_w < 1 || max_batch < 1 || n_weights < 0)
+        return fail(XFR_INVALID_ARG, "xfr_engine_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(XFR_HIP_ERROR, "no HIP device visible: the xfr_amd engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(XFR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    if (ops[0].kind != XFR_OP_CONV || ops[0].in0 != 0)
+        return fail(XFR_UNSUPPORTED_LAYER, "the first layer must be a convolution on the input image");
+    xfr_engine* e = new xfr_engine();
+    e->device = device; e->max_batch = max_batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
+    xfr_status st = build(e, ops, n_ops);
+    if (st == XFR_OK) st = layout_arena(e);
+    if (st == XFR_OK) st = allocate(e);
+    if (st != XFR_OK) { xfr_engine_destroy(e); return st; }
+    *out = e;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_destroy(xfr_engine* e)
+{
+    if (!e) return XFR_OK;
+    hipSetDevice(e->device);
+    if (e->ws) hipFree(e->ws);
+    if (e->idx_ws) hipFree(e->idx_ws);
+    if (e->arena) hipFree(e->arena);
+    if (e->dbl_ws) hipFree(e->dbl_ws);
+    if (e->trunc_ws) hipFree(e->trunc_ws);
+    for (auto& ev : e->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    delete e;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int32_t n_weights)
+{
+    if (!e || !w) return fail(XFR_INVALID_ARG, "null argument");
+    if (n_weights != e->n_weights) return fail(XFR_INVALID_ARG, "expected %d weight views, got %d", e->n_weights, n_weights);
+    HIP_TRY(hipSetDevice(e->device));
+    std::vector<float> host(e->arena_floats, 0.f);
+    for (size_t k = 0; k < e->ops.size(); ++k) {
+        const OpRec& o = e->ops[k];
+        const xfr_op_desc& d = o.d;
+        if (d.kind == XFR_OP_CONV || d.kind == XFR_OP_LINEAR) {
+            const xfr_tensor_view& wv = w[d.w_weight];
+            const int khw = d.kh * d.kw;
+            if (!wv.data || wv.numel != (int64_t)d.cout * o.Cin * khw)
+                return fail(XFR_INVALID_ARG, "op %zu: weight has %lld elements, expected %lld", k, (long long)wv.numel,
+                            (long long)d.cout * o.Cin * khw);
+            float* wt = host.data() + o.w_true;
+            float* wp = host.data() + o.w_pos;
+            // forward pack: [k = (ci,kh,kw)][co]
+            for (int co = 0; co < d.cout; ++co) {
+                const float* src = wv.data + (size_t)co * o.K;
+                for (int kk = 0; kk < o.K; ++kk) {
+                    const float v = src[kk];
+                    wt[(size_t)kk * o.ldw + co] = v;
+                    wp[(size_t)kk * o.ldw + co] = v > 0.f ? v : 0.f;   // relu(W): whitebox.py:319
+                }
+            }
+            if (o.w_bwd >= 0) {
+                // backward-data pack of relu(W): [k' = (co, kh', kw')][ci] with the kernel flipped
+                float* wb = host.data() + o.w_bwd;
+                for (int co = 0; co < d.cout; ++co)
+                    for (int ci = 0; ci < o.Cin; ++ci)
+                        for (int a = 0; a < d.kh; ++a)
+                            for (int b = 0; b < d.kw; ++b) {
+                                const float v = wv.data[(((size_t)co * o.Cin + ci) * d.kh + a) * d.kw + b];
+                                const int a2 = d.kh - 1 - a, b2 = d.kw - 1 - b;
+                                wb[((size_t)(co * d.kh + a2) * d.kw + b2) * o.ldb + ci] = v > 0.f ? v : 0.f;
+                            }
+            }
+            if (d.w_bias >= 0) {
+                const xfr_tensor_view& bv = w[d.w_bias];
+                if (!bv.data || bv.numel != d.cout) return fail(XFR_INVALID_ARG, "op %zu: bad bias size", k);
+                for (int co = 0; co < d.cout; ++co) {
+                    host[o.b_true + co] = bv.data[co];
+                    host[o.b_pos + co] = bv.data[co] > 0.f ? bv.data[co] : 0.f;   // whitebox.py:323 (with_bias)
+                }
+            }
+        } else if (d.kind == XFR_OP_BATCHNORM) {
+            const int C = e->tens[d.out].C;
+            const xfr_tensor_view &g = w[d.w_weight], &b = w[d.w_bias], &m = w[d.w_mean], &v = w[d.w_var];
+            if (!g.data || !b.data || !m.data || !v.data || g.numel != C || b.numel != C || m.numel != C || v.numel != C)
+                return fail(XFR_INVALID_ARG, "op %zu: bad batchnorm parameter sizes", k);
+            for (int c = 0; c < C; ++c) {
+                // at::native inference batch norm: alpha = w * invstd, beta = b - mean * alpha
+                const float invstd = 1.0f / sqrtf(v.data[c] + d.fparam);
+                const float gp = g.data[c] > 0.f ? g.data[c] : 0.f;            // relu(gamma): whitebox.py:317-320
+                const float bp = b.data[c] > 0.f ? b.data[c] : 0.f;
+                const float at = g.data[c] * invstd, ap = gp * invstd;
+                host[o.bn_alpha_t + c] = at;
+                host[o.bn_beta_t + c] = b.data[c] - m.data[c] * at;
+                host[o.bn_alpha_p + c] = ap;
+                host[o.bn_beta_p + c] = b.data[c] - m.data[c] * ap;
+                host[o.bn_beta_pb + c] = bp - m.data[c] * ap;
+            }
+        }
+    }
+    HIP_TRY(hipMemcpy(e->arena, host.data(), e->arena_floats * sizeof(float), hipMemcpyHostToDevice));
+    e->weights_loaded = true;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_weight_arena(xfr_engine* e, void** dev_ptr, size_t* bytes)
+{
+    if (!e || !dev_ptr || !bytes) return fail(XFR_INVALID_ARG, "null argument");
+    *dev_ptr = e->arena;
+    *bytes = e->arena_floats * sizeof(float);
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_mark_weights_loaded(xfr_engine* e)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->weights_loaded = true;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_set_mode(xfr_engine* e, int32_t subtree_mode, float eps, int32_t with_bias)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    if (subtree_mode < 0 || subtree_mode > 3) return fail(XFR_INVALID_ARG, "Invalid subtree mode %d", subtree_mode);
+    if (!(eps >= 0.f)) return fail(XFR_INVALID_ARG, "eps must be >= 0");
+    e->mode = subtree_mode; e->eps = eps; e->with_bias = with_bias ? 1 : 0;
+    e->need_dirty = true;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_tensor_shape(xfr_engine* e, int32_t t, int32_t* c, int32_t* h, int32_t* w)
+{
+    if (!e || t < 0 || t >= (int)e->tens.size()) return fail(XFR_INVALID_ARG, "bad tensor id");
+    if (c) *c = e->tens[t].C;
+    if (h) *h = e->tens[t].H;
+    if (w) *w = e->tens[t].W;
+    return XFR_OK;
+}
+
+xfr_status xfr_forward(xfr_engine* e, const float* x_dev, int32_t n, int32_t tensor_id, float* out_dev, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, n);
+    if (st != XFR_OK) return st;
+    if (tensor_id < 1 || tensor_id >= (int)e->tens.size() || !out_dev) return fail(XFR_INVALID_ARG, "bad tensor id / null output");
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(e);
+    st = forward_all(e, x_dev, n, tensor_id, false, s);
+    if (st != XFR_OK) return st;
+    const Tensor& t = e->tens[tensor_id];
+    launch_cnhw_to_nchw(e->T(tensor_id), out_dev, n, t.C, t.HW(), s);
+    HIP_TRY(hipGetLastError());
+    return prof_end(e, s);
+}
+
+xfr_status xfr_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32_t n_streams, int32_t seed_tensor, const float* seed_dev,
+                   float* mwp_dev, float* pooled_dev, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, n);
+    if (st != XFR_OK) return st;
+    if (n_streams < 1 || n_streams > 2) return fail(XFR_INVALID_ARG, "n_streams must be 1 or 2");
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(e);
+    st = ebp_core(e, x_dev, n, n_streams, seed_tensor, seed_dev, s);
+    if (st != XFR_OK) return st;
+    const Tensor& t1 = e->tens[1];
+    const int SB = n_streams * n;
+    if (mwp_dev) launch_cnhw_to_nchw(e->ws + e->tap_off, mwp_dev, SB, t1.C, t1.HW(), s);
+    if (pooled_dev) launch_channel_pool(e->ws + e->tap_off, pooled_dev, t1.C, SB, t1.HW(), s);
+    HIP_TRY(hipGetLastError());
+    return prof_end(e, s);
+}
+
+xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                           float percentile, float* sal_dev, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, n);
+    if (st != XFR_OK) return st;
+    if (!sal_dev) return fail(XFR_INVALID_ARG, "null output");
+    if (percentile > 100.f) return fail(XFR_INVALID_ARG, "percentile must be <= 100 (or < 0 for plain contrastive)");
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(e);
+    st = ebp_core(e, x_dev, n, 2, seed_tensor, seed_dev, s);
+    if (st != XFR_OK) return st;
+    const Tensor& t1 = e->tens[1];
+    const float* P = e->ws + e->tap_off;
+    double* sums = e->dbl_ws;
+    launch_sample_sums(P, sums, t1.C, 2 * n, t1.HW(), s);
+    float* thr = nullptr;
+    if (percentile >= 0.f) {
+        thr = e->ws + e->thr_off;
+        launch_truncation_threshold(P, sums, percentile, thr, e->trunc_ws, t1.C, n, t1.HW(), s);
+    }
+    float* contrast = e->ws + e->blur_a_off;
+    launch_contrast(P, sums, thr, contrast, t1.C, n, t1.HW(), s);
+    launch_saliency_blur(contrast, e->ws + e->blur_b_off, sal_dev, n, t1.H, t1.W, e->eps, s);
+    HIP_TRY(hipGetLastError());
+    return prof_end(e, s);
+}
+
+xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w, float* sal_dev, void* stream)
+{
+    if (!e || !pooled_dev || !sal_dev) return fail(XFR_INVALID_ARG, "null argument");
+    if (n < 1 || (size_t)n * h * w > 2 * (size_t)e->max_batch * e->tens[1].HW())
+        return fail(XFR_INVALID_ARG, "xfr_mwp_to_saliency: %d maps of %dx%d exceed the engine's scratch", n, h, w);
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    launch_saliency_blur(pooled_dev, e->ws + e->blur_b_off, sal_dev, n, h, w, e->eps, s);
+    HIP_TRY(hipGetLastError());
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_set_trace(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->trace_on = enable ? 1 : 0;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_trace_size(xfr_engine* e, int32_t* n_firings)
+{
+    if (!e || !n_firings) return fail(XFR_INVALID_ARG, "null argument");
+    *n_firings = e->last_trace_firings;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_get_trace(xfr_engine* e, double* sums, int32_t* kinds, int32_t capacity)
+{
+    if (!e || !sums) return fail(XFR_INVALID_ARG, "null argument");
+    const int nf = e->last_trace_firings, SB = e->last_trace_sb;
+    if (capacity < nf * SB) return fail(XFR_INVALID_ARG, "trace needs %d doubles", nf * SB);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(sums, e->dbl_ws + 2 * e->max_batch, sizeof(double) * (size_t)nf * SB, hipMemcpyDeviceToHost));
+    if (kinds) for (int i = 0; i < nf; ++i) kinds[i] = e->last_trace_kinds[i];
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_memory(xfr_engine* e, size_t* weight_bytes, size_t* workspace_bytes)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    if (weight_bytes) *weight_bytes = e->arena_floats * sizeof(float);
+    if (workspace_bytes) *workspace_bytes = e->ws_floats * sizeof(float) + e->idx_bytes;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_set_profile(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->profile_on = enable ? 1 : 0;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_get_profile(xfr_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    if (gemm_ms) *gemm_ms = e->last_gemm_ms;
+    if (gemm_launches) *gemm_launches = e->last_gemm_launches;
+    if (gemm_flops) *gemm_flops = e->last_gemm_flops;
+    return XFR_OK;
+}
+
+}  // extern "C"

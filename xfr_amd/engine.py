@@ -1,0 +1,181 @@
+"""Python handle on one HIP engine (one backbone, one device).  PyTorch tensors are only the container for
+device memory and the source of the HIP stream; all arithmetic happens inside libxfr_amd.so."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .program import LAYER_NAMES, OpKind
+
+MODES = {'affineonly': 0, 'affineonly_with_prior': 1, 'norelu': 2, 'all': 3}
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine(object):
+    def __init__(self, program, max_batch, device):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('xfr_amd: no HIP device visible; the engine has no CPU fallback')
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('xfr_amd: the engine runs on a HIP device, got %s' % (device,))
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.program = program
+        self.max_batch = int(max_batch)
+        self._h = ctypes.c_void_p()
+        ops = program.op_array()
+        c, h, w = program.in_shape
+        _lib.check(self.lib.xfr_engine_create(ops, len(program.ops), len(program.weight_names), c, h, w,
+                                              self.max_batch, self.device.index, ctypes.byref(self._h)))
+        self._mode = None
+        self.loaded_version = None
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self.lib.xfr_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------
+    def load_weights(self, state_dict):
+        names = self.program.weight_names
+        views = (_lib.TensorView * len(names))()
+        keep = []
+        for i, n in enumerate(names):
+            if n not in state_dict:
+                raise KeyError('xfr_amd: parameter "%s" missing from the state_dict' % n)
+            t = state_dict[n].detach().to('cpu', torch.float32).contiguous()
+            keep.append(t)
+            views[i].data = t.data_ptr()
+            views[i].numel = t.numel()
+        _lib.check(self.lib.xfr_engine_load_weights(self._h, views, len(names)))
+
+    def weight_arena(self):
+        """The packed parameter arena as a uint8 CUDA tensor view (for torch.distributed.broadcast)."""
+        p = ctypes.c_void_p()
+        nbytes = ctypes.c_size_t()
+        _lib.check(self.lib.xfr_engine_weight_arena(self._h, ctypes.byref(p), ctypes.byref(nbytes)))
+
+        class _Arr(object):
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = {'shape': (nbytes.value,), 'typestr': '|u1', 'data': (p.value, False),
+                                      'version': 2}
+        with torch.cuda.device(self.device):
+            t = torch.as_tensor(a, device=self.device)
+        return t
+
+    def mark_weights_loaded(self):
+        _lib.check(self.lib.xfr_engine_mark_weights_loaded(self._h))
+
+    def set_mode(self, subtree_mode, eps=1e-16, with_bias=False):
+        if subtree_mode not in MODES:
+            raise ValueError('Invalid subtree mode "%s"' % subtree_mode)
+        key = (subtree_mode, float(eps), bool(with_bias))
+        if key != self._mode:
+            _lib.check(self.lib.xfr_engine_set_mode(self._h, MODES[subtree_mode], float(eps), 1 if with_bias else 0))
+            self._mode = key
+
+    def tensor_shape(self, tid):
+        c, h, w = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self.lib.xfr_engine_tensor_shape(self._h, int(tid), ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+        return (c.value, h.value, w.value)
+
+    def memory(self):
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(self.lib.xfr_engine_memory(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    # ------------------------------------------------------------------------------------------------
+    def _prep(self, x):
+        if x.dim() != 4 or tuple(x.shape[1:]) != tuple(self.program.in_shape):
+            raise ValueError('expected input N x %s, got %s' % (self.program.in_shape, tuple(x.shape)))
+        if x.shape[0] > self.max_batch:
+            raise ValueError('batch %d exceeds the engine max_batch %d' % (x.shape[0], self.max_batch))
+        return x.detach().to(self.device, torch.float32).contiguous()
+
+    def forward(self, x, tensor_id):
+        x = self._prep(x)
+        c, h, w = self.tensor_shape(tensor_id)
+        out = torch.empty((x.shape[0], c, h, w), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_forward(self._h, x.data_ptr(), x.shape[0], int(tensor_id), out.data_ptr(),
+                                            _stream_ptr(self.device)))
+        return out
+
+    def ebp(self, x, seed_tensor, seed, want_mwp=False, want_pooled=True):
+        """seed: S x N x D.  Returns (mwp S x N x C1 x H1 x W1 or None, pooled S x N x H1 x W1 or None)."""
+        x = self._prep(x)
+        n = x.shape[0]
+        seed = seed.detach().to(self.device, torch.float32).contiguous()
+        S = seed.shape[0]
+        d = int(np.prod(self.tensor_shape(seed_tensor)))
+        if seed.dim() != 3 or seed.shape[1] != n or seed.shape[2] != d:
+            raise ValueError('seed must be S x %d x %d, got %s' % (n, d, tuple(seed.shape)))
+        c1, h1, w1 = self.tensor_shape(1)
+        mwp = torch.empty((S, n, c1, h1, w1), device=self.device) if want_mwp else None
+        pooled = torch.empty((S, n, h1, w1), device=self.device) if want_pooled else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_ebp(self._h, x.data_ptr(), n, S, int(seed_tensor), seed.data_ptr(),
+                                        mwp.data_ptr() if want_mwp else None,
+                                        pooled.data_ptr() if want_pooled else None, _stream_ptr(self.device)))
+        return mwp, pooled
+
+    def contrastive(self, x, seed_tensor, seed, percentile=None):
+        """seed: 2 x N x D (mate, non-mate).  Returns N x H1 x W1 saliency maps."""
+        x = self._prep(x)
+        n = x.shape[0]
+        seed = seed.detach().to(self.device, torch.float32).contiguous()
+        d = int(np.prod(self.tensor_shape(seed_tensor)))
+        if tuple(seed.shape) != (2, n, d):
+            raise ValueError('seed must be 2 x %d x %d, got %s' % (n, d, tuple(seed.shape)))
+        c1, h1, w1 = self.tensor_shape(1)
+        sal = torch.empty((n, h1, w1), device=self.device)
+        pct = -1.0 if percentile is None else float(percentile)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_contrastive(self._h, x.data_ptr(), n, int(seed_tensor), seed.data_ptr(), pct,
+                                                sal.data_ptr(), _stream_ptr(self.device)))
+        return sal
+
+    def mwp_to_saliency(self, pooled):
+        pooled = pooled.detach().to(self.device, torch.float32).contiguous()
+        n, h, w = pooled.shape
+        out = torch.empty_like(pooled)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_mwp_to_saliency(self._h, pooled.data_ptr(), n, h, w, out.data_ptr(),
+                                                    _stream_ptr(self.device)))
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    def set_trace(self, on):
+        _lib.check(self.lib.xfr_engine_set_trace(self._h, 1 if on else 0))
+
+    def get_trace(self):
+        """(sums [n_firings, S*N] float64, names [n_firings]) of the last ebp call, reference firing order."""
+        nf = ctypes.c_int32()
+        _lib.check(self.lib.xfr_engine_trace_size(self._h, ctypes.byref(nf)))
+        cap = nf.value * 2 * self.max_batch
+        sums = (ctypes.c_double * max(cap, 1))()
+        kinds = (ctypes.c_int32 * max(nf.value, 1))()
+        _lib.check(self.lib.xfr_engine_get_trace(self._h, sums, kinds, cap))
+        arr = np.frombuffer(sums, dtype=np.float64)
+        names = [LAYER_NAMES[OpKind(k)] for k in list(kinds)[:nf.value]]
+        return arr, names, nf.value
+
+    def set_profile(self, on):
+        _lib.check(self.lib.xfr_engine_set_profile(self._h, 1 if on else 0))
+
+    def get_profile(self):
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self.lib.xfr_engine_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+        return ms.value, n.value, fl.value

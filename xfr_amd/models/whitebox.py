@@ -1,0 +1,380 @@
+"""Drop-in mirror of python/xfr/models/whitebox.py for the excitation-backprop hot path.
+
+Same classes, method names, argument meaning, return types and error behaviour as the reference
+(`WhiteboxNetwork`, `WhiteboxSTResnet`, `WhiteboxLightCNN`, `Whitebox_resnet50_128`, `Whitebox`), but no
+hooks and no autograd: every call is a few launches of the HIP engine (xfr_amd/csrc) through the C ABI of
+include/xfr_amd.h.  Additive API: `*_batch` methods that run many independent probes in one engine call
+(the reference is batch-1 only for contrastive EBP: whitebox.py:512,524).
+
+Not provided (outside the hot path): layerwise_ebp / weighted_subtree_ebp
+(whitebox.py:561-737, "next" row), Whitebox_senet50_256 (unsupported by the reference itself:
+whitebox.py:402-403), DataFrame / image_loader inputs of `embeddings`.
+"""
+import numpy as np
+import PIL
+import PIL.Image
+import PIL.ImageFilter
+import torch
+
+from ..engine import Engine
+from .lightcnn import lightcnn_preprocess
+from .resnet import convert_resnet101v4_image
+
+
+class _TripletClassifier(object):
+    """Stand-in for the nn.Linear(D, 2, bias=False) that set_triplet_classifier installs
+    (whitebox.py:95-96,123-124,220).  It is created after hook registration, hence un-hooked."""
+
+    def __init__(self, weight):
+        self.weight = weight.detach().clone().float()
+        self.out_features = int(weight.shape[0])
+        self.in_features = int(weight.shape[1])
+        self.bias = None
+
+
+class WhiteboxNetwork(object):
+    """whitebox.py:25-85.  `net` is an xfr_amd backbone (parameter store + layer program)."""
+
+    default_max_batch = 32
+
+    def __init__(self, net):
+        self.net = net
+        self.net.eval()
+        self._engine = None
+        self._engine_key = None
+        self._classifier = None      # _TripletClassifier or None (hooked classifier inside the program)
+
+    # -- engine plumbing -----------------------------------------------------------------------------------
+    def engine(self, min_batch=1):
+        dev = self.net.device
+        want = max(int(min_batch), self.default_max_batch)
+        key = (str(dev), id(self.net))
+        if self._engine is None or self._engine_key != key or self._engine.max_batch < min_batch:
+            if self._engine is not None:
+                self._engine.close()
+            self._program = self.net.build_program()
+            self._engine = Engine(self._program, want, dev)
+            self._engine_key = key
+        if self._engine.loaded_version != self.net.version:
+            self._engine.load_weights(self.net.state_dict())
+            self._engine.loaded_version = self.net.version
+        return self._engine
+
+    def _mark(self, name):
+        self.engine()
+        return self._program.marks[name]
+
+    def _cls_weight(self, device):
+        return self._classifier.weight.to(device)
+
+    def seed_for(self, Pn, n):
+        """Gradient seed of `Xn.backward(Pn)` (whitebox.py:498): (tensor id, N x D seed)."""
+        eng = self.engine(n)
+        Pn = torch.as_tensor(Pn, dtype=torch.float32)
+        if Pn.dim() == 1:
+            Pn = Pn.unsqueeze(0)
+        if Pn.shape[0] == 1 and n > 1:
+            Pn = Pn.expand(n, -1)
+        Pn = Pn.to(eng.device)
+        if self._classifier is None:
+            return self._program.marks['classify'], Pn.contiguous()
+        return self._program.marks['encode'], (Pn @ self._cls_weight(eng.device)).contiguous()
+
+    # -- reference surface ---------------------------------------------------------------------------------
+    def _layer_visitor(self, f_forward=None, f_preforward=None, net=None):
+        """whitebox.py:34-56.  There are no hooks to register here; returns the layer list for inspection."""
+        from ..program import LAYER_NAMES, OpKind
+        prog = self.net.build_program()
+        return [{'name': LAYER_NAMES[OpKind(o.kind)], 'hooks': []} for o in prog.ops if o.kind < OpKind.G_ADD]
+
+    def encode(self, x):
+        eng = self.engine(x.shape[0])
+        out = eng.forward(x, self._program.marks['encode'])
+        return out.reshape(out.shape[0], -1).to(x.device)
+
+    def classify(self, x):
+        eng = self.engine(x.shape[0])
+        if self._classifier is None:
+            out = eng.forward(x, self._program.marks['classify'])
+            return out.reshape(out.shape[0], -1).to(x.device)
+        enc = eng.forward(x, self._program.marks['encode']).reshape(x.shape[0], -1)
+        return (enc @ self._cls_weight(eng.device).t()).to(x.device)
+
+    def clear(self):
+        """whitebox.py:66-71: zero parameter gradients.  The engine keeps no gradient state between calls."""
+        return None
+
+    def set_triplet_classifier(self, x_mate, x_nonmate):
+        raise NotImplementedError
+
+    def num_classes(self):
+        raise NotImplementedError
+
+    def preprocess(self, im):
+        raise NotImplementedError
+
+
+class WhiteboxSTResnet(WhiteboxNetwork):
+    """whitebox.py:87-110"""
+
+    def set_triplet_classifier(self, x_mate, x_nonmate):
+        w = torch.cat((x_mate.detach().cpu().float().reshape(1, -1), x_nonmate.detach().cpu().float().reshape(1, -1)), dim=0)
+        self._classifier = _TripletClassifier(w)
+        self.net.fc2 = self._classifier
+
+    def num_classes(self):
+        return self._classifier.out_features if self._classifier is not None else self.net.num_classes
+
+    def preprocess(self, im):
+        return convert_resnet101v4_image(im.resize((224, 224))).unsqueeze(0)
+
+
+class WhiteboxLightCNN(WhiteboxNetwork):
+    """whitebox.py:113-159"""
+    default_max_batch = 32
+
+    def __init__(self, net):
+        WhiteboxNetwork.__init__(self, net)
+        self.f_preprocess = lightcnn_preprocess()
+
+    def set_triplet_classifier(self, x_mate, x_nonmate):
+        w = torch.cat((x_mate.detach().cpu().float().reshape(1, -1), x_nonmate.detach().cpu().float().reshape(1, -1)), dim=0)
+        self._classifier = _TripletClassifier(w)
+        self.net.fc2 = self._classifier
+
+    def num_classes(self):
+        return self._classifier.out_features if self._classifier is not None else self.net.num_classes
+
+    def preprocess(self, im):
+        return self.f_preprocess(im)
+
+
+class Whitebox_resnet50_128(WhiteboxNetwork):
+    """whitebox.py:210-258: the 2-way classifier `fc1` lives on the wrapper and is never hooked."""
+
+    def __init__(self, net):
+        WhiteboxNetwork.__init__(self, net)
+        g = torch.Generator().manual_seed(0)
+        self._classifier = _TripletClassifier((torch.rand((2, 128), generator=g) * 2 - 1) / np.sqrt(128.0))
+        self.fc1 = self._classifier
+
+    def set_triplet_classifier(self, x_mate, x_nonmate):
+        w = torch.cat((x_mate.detach().cpu().float().reshape(1, -1), x_nonmate.detach().cpu().float().reshape(1, -1)), dim=0)
+        self._classifier = _TripletClassifier(w)
+        self.fc1 = self._classifier
+
+    def num_classes(self):
+        return 128 if self.fc1 is None else self.fc1.out_features
+
+    def preprocess(self, img):
+        """whitebox.py:235-258"""
+        mean = (131.0912, 103.8827, 91.4953)
+        short_size = 224.0
+        crop_size = (224, 224, 3)
+        im_shape = np.array(img.size)
+        img = img.convert('RGB')
+        ratio = float(short_size) / np.min(im_shape)
+        img = img.resize(size=(int(np.ceil(im_shape[0] * ratio)), int(np.ceil(im_shape[1] * ratio))),
+                         resample=PIL.Image.BILINEAR)
+        x = np.array(img)
+        newshape = x.shape[:2]
+        h_start = (newshape[0] - crop_size[0]) // 2
+        w_start = (newshape[1] - crop_size[1]) // 2
+        x = x[h_start:h_start + crop_size[0], w_start:w_start + crop_size[1]]
+        x = x - mean
+        return torch.from_numpy(x.transpose(2, 0, 1).astype(np.float32)).unsqueeze(0)
+
+
+class _PList(object):
+    """`Whitebox.P` (whitebox.py:294,394): the reference keeps all MWP tensors of the last sweep; the engine keeps
+    the one the callers use, P[-2] (MWP at the first convolution's output, whitebox.py:499,524)."""
+
+    def __init__(self, p_minus2, n_firings):
+        self._p2 = p_minus2
+        self._n = n_firings
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if i == -2 or (self._n and i == self._n - 2):
+            return self._p2
+        raise IndexError('xfr_amd keeps only P[-2] of the MWP sweep (enable the engine trace for per-layer sums)')
+
+
+class Whitebox(object):
+    """whitebox.py:261-304."""
+
+    def __init__(self, net, ebp_version=None, with_bias=None, eps=1E-16, ebp_subtree_mode='affineonly_with_prior'):
+        assert (isinstance(net, WhiteboxNetwork))
+        self.net = net
+        self.eps = eps
+        self.layerlist = None
+        self.ebp_ver = ebp_version
+        if self.ebp_ver is None:
+            self.ebp_ver = 6
+        elif self.ebp_ver < 4:
+            raise RuntimeError('ebp version, if set, must be at least 4')
+        self.convert_saliency_uint8 = (self.ebp_ver != 6)
+        if with_bias is not None:
+            self._ebp_with_bias = with_bias
+        else:
+            self._ebp_with_bias = self.ebp_ver == 11
+        self.dA = []
+        self.A = []
+        self.X = []
+        self.P = []
+        self.P_prior = []
+        self.P_layername = []
+        self.batch_size = 32
+        self._ebp_mode = 'disable'
+        self.layerlist = self.net._layer_visitor()
+        if ebp_subtree_mode not in ('affineonly', 'affineonly_with_prior', 'norelu', 'all'):
+            raise ValueError('Invalid subtree mode "%s"' % ebp_subtree_mode)
+        self._ebp_subtree_mode = ebp_subtree_mode
+        self.debug_trace = False
+
+    # nn.Module-ish no-ops used by the reference's callers (eval/create_wbnet.py:38-42)
+    def to(self, device):
+        self.net.net.to(device)
+        return self
+
+    def eval(self):
+        return self
+
+    def _engine(self, n=1):
+        eng = self.net.engine(n)
+        eng.set_mode(self._ebp_subtree_mode, self.eps, self._ebp_with_bias)
+        return eng
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def _float32_to_uint8(self, img):
+        return np.uint8(255 * ((img - np.min(img)) / (self.eps + (np.max(img) - np.min(img)))))
+
+    def _scale_normalized(self, img):
+        img = np.float32(img)
+        return (img - np.min(img)) / (self.eps + (np.max(img) - np.min(img)))
+
+    def _mwp_to_saliency(self, P, blur_radius=2):
+        """whitebox.py:448-460.  ebp_ver 6: HIP blur (gaussian sigma=2, nearest) + clamp + /sum.  Other versions:
+        the uint8 PIL path of the reference, on the host (not on the hot path)."""
+        img = P
+        if self.convert_saliency_uint8:
+            img = np.uint8(255 * ((img - np.min(img)) / (self.eps + (np.max(img) - np.min(img)))))
+            img = np.array(PIL.Image.fromarray(img).filter(PIL.ImageFilter.GaussianBlur(radius=blur_radius)))
+            img = np.uint8(255 * ((img - np.min(img)) / (self.eps + (np.max(img) - np.min(img)))))
+            return img
+        if blur_radius != 2:
+            raise ValueError('xfr_amd implements the reference blur radius (2) only')
+        eng = self._engine()
+        t = torch.as_tensor(np.asarray(P, dtype=np.float32))
+        squeeze = (t.dim() == 2)
+        if squeeze:
+            t = t.unsqueeze(0)
+        out = eng.mwp_to_saliency(t).cpu().numpy()
+        return out[0] if squeeze else out
+
+    def _clear(self):
+        (self.P, self.P_layername, self.dA, self.A, self.X) = ([], [], [], [], [])
+        self.net.clear()
+
+    # -- EBP -------------------------------------------------------------------------------------------------
+    def ebp(self, x, Pn, mwp=False):
+        """Excitation backprop (whitebox.py:482-504).  x: N x C x U x V; Pn: N x num_classes (or 1 x ...)."""
+        n = x.shape[0]
+        eng = self._engine(n)
+        self._clear()
+        seed_tensor, seed = self.net.seed_for(Pn, n)
+        if self.debug_trace:
+            eng.set_trace(True)
+        mwp_full, pooled = eng.ebp(x, seed_tensor, seed.unsqueeze(0), want_mwp=True, want_pooled=True)
+        if self.debug_trace:
+            sums, names, nf = eng.get_trace()
+            self.P_layername = names
+            self.P_trace = sums[:nf * n].reshape(nf, n).copy()
+            eng.set_trace(False)
+        self.P = _PList(mwp_full[0], len(self.P_layername) + 1 if self.P_layername else 0)
+        P = np.squeeze(pooled[0].cpu().numpy()).astype(np.float32)
+        return self._mwp_to_saliency(P) if not mwp else P
+
+    def _class_seeds(self, n, k_pos, k_neg):
+        assert (k_pos >= 0 and k_pos < self.net.num_classes())
+        assert (k_neg >= 0 and k_neg < self.net.num_classes())
+        C = self.net.num_classes()
+        P0 = torch.zeros((1, C))
+        P0[0][k_pos] = 1.0
+        P1 = torch.zeros((1, C))
+        P1[0][k_neg] = 1.0
+        t0, s0 = self.net.seed_for(P0, n)
+        t1, s1 = self.net.seed_for(P1, n)
+        return t0, torch.stack((s0, s1), dim=0)
+
+    def _squeeze(self, sal):
+        out = sal.cpu().numpy().astype(np.float32)
+        return out[0] if out.shape[0] == 1 else out
+
+    def contrastive_ebp(self, img_probe, k_poschannel, k_negchannel):
+        """Contrastive excitation backprop (whitebox.py:506-527); per sample when N > 1."""
+        if self.convert_saliency_uint8:
+            raise NotImplementedError('xfr_amd implements ebp_version 6 saliency for contrastive EBP')
+        n = img_probe.shape[0]
+        eng = self._engine(n)
+        seed_tensor, seeds = self._class_seeds(n, k_poschannel, k_negchannel)
+        return self._squeeze(eng.contrastive(img_probe, seed_tensor, seeds, None))
+
+    def truncated_contrastive_ebp(self, img_probe, k_poschannel, k_negchannel, percentile=20):
+        """Truncated contrastive excitation backprop (whitebox.py:529-558)."""
+        if self.convert_saliency_uint8:
+            raise NotImplementedError('xfr_amd implements ebp_version 6 saliency for contrastive EBP')
+        n = img_probe.shape[0]
+        eng = self._engine(n)
+        seed_tensor, seeds = self._class_seeds(n, k_poschannel, k_negchannel)
+        return self._squeeze(eng.contrastive(img_probe, seed_tensor, seeds, float(percentile)))
+
+    # -- additive batched API --------------------------------------------------------------------------------
+    def contrastive_triplet_ebp_batch(self, img_probes, x_mates, x_nonmates, percentile=None):
+        """N independent (mate, non-mate, probe) triplets in one call: for sample i equivalent to
+        set_triplet_classifier(x_mates[i], x_nonmates[i]); (truncated_)contrastive_ebp(img_probes[i:i+1], 0, 1).
+        x_mates / x_nonmates: N x D classifier rows (already scaled, e.g. encoding/2500:
+        demo/test_whitebox.py:129).  Returns N x H x W float32 (torch, on the engine device)."""
+        n = img_probes.shape[0]
+        eng = self._engine(n)
+        prog_marks = self.net._program.marks
+        seeds = torch.stack((torch.as_tensor(x_mates, dtype=torch.float32).reshape(n, -1),
+                             torch.as_tensor(x_nonmates, dtype=torch.float32).reshape(n, -1)), dim=0)
+        return eng.contrastive(img_probes, prog_marks['encode'], seeds, percentile)
+
+    def layerwise_ebp(self, *args, **kwargs):
+        raise NotImplementedError('layerwise_ebp (whitebox.py:561-581) is a "next" row of the scope table')
+
+    def weighted_subtree_ebp(self, *args, **kwargs):
+        raise NotImplementedError('weighted_subtree_ebp (whitebox.py:647-737) is a "next" row of the scope table')
+
+    def ebp_subtree_mode(self):
+        return self._ebp_subtree_mode
+
+    def encode(self, x):
+        return self.net.encode(x)
+
+    def embeddings(self, images, norm=True):
+        """whitebox.py:747-785 for tensors / numpy arrays already in network format."""
+        if isinstance(images[0], torch.Tensor):
+            assert images[0].ndim == 3
+            imagesT = images
+        elif isinstance(images[0], np.ndarray):
+            assert images[0].shape[0] in (1, 3)
+            imagesT = [torch.from_numpy(im).float() for im in images]
+        else:
+            raise NotImplementedError('embeddings(): DataFrame / file inputs go through xfr.utils.image_loader, '
+                                      'which is outside the hot path')
+        if not isinstance(imagesT, torch.Tensor):
+            imagesT = torch.stack(list(imagesT))
+        batches = torch.split(imagesT, self.batch_size, dim=0)
+        embeds = []
+        for k, batch in enumerate(batches):
+            embeds.append(self.encode(batch).detach().cpu().numpy())
+        embeds = np.concatenate(embeds)
+        if norm:
+            embeds = (embeds.reshape((embeds.shape[0], -1)) /
+                      np.linalg.norm(embeds.reshape((embeds.shape[0], -1)), axis=1, keepdims=True)).reshape(embeds.shape)
+        return embeds
