@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- triplet-contrastive-EBP saliency maps/sec, ResNet-101 224x224 (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of B synthetic triplets per GPU, inputs resident in HBM:
+    encode(mates[B]); encode(nonmates[B]);                      (demo/test_whitebox.py:71-72)
+    classifier rows = encoding / 2500                           (demo/test_whitebox.py:129)
+    contrastive_ebp(probes[B], 0, 1) -> B saliency maps 112x112 (whitebox.py:506-527), per-triplet classifier
+Workload = BASELINE.json configs[1]: ResNet-101 triplet contrastive EBP, batch=32 synthetic 224x224 triplets per
+GPU, ebp_subtree_mode 'affineonly_with_prior' (the demo default), fp32 throughout.
+
+Multi-GPU: one process per GPU (torch.distributed.run), triplets sharded embarrassingly, weights packed on rank 0
+and broadcast once over RCCL; no steady-state collective => "scaling": "weak" (B triplets per GPU).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_FWD_R101 = 14.419e9            # 2*MAC over conv+linear, measured on the reference modules
+FLOPS_PER_TRIPLET = 6 * F_FWD_R101   # 2 encodes + true fwd + relu(W) fwd + 2 backward-data sweeps = 86.51 GFLOP
+PEAK_F32_MFMA = 157.3e12         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
+
+
+def cpu_baseline(sd, probes, mates, nonmates, mode, budget_s=25.0):
+    """The oracle (kind "port": hook-free CPU restatement of the reference, bit-exact against it in the build
+    container) timed on this box's host cores on a bounded sample of the same workload: whole triplets
+    (2 encodes + contrastive EBP) until ~budget_s of CPU time is spent (at least one)."""
+    import torch
+    from oracle import ebp_oracle as O
+    ow = O.OracleWhitebox('stresnet101', sd, ('hooked', None), mode)
+    n = 0
+    t0 = time.time()
+    while True:
+        i = n % probes.shape[0]
+        xm = ow.encode(mates[i:i + 1]) / 2500.0
+        xn = ow.encode(nonmates[i:i + 1]) / 2500.0
+        ow.set_triplet_classifier(xm, xn)
+        ow.contrastive_ebp(probes[i:i + 1], 0, 1)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 8:
+            break
+    dt = time.time() - t0
+    return {'value': n / dt, 'unit': 'maps/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': '%d ResNet-101 triplet(s) (2 encodes + contrastive_ebp each), batch 1, %.1f s' % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=32, help='triplets per GPU per step')
+    ap.add_argument('--mode', default='affineonly_with_prior')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from xfr_amd import shard, synth
+    from xfr_amd.models import resnet, whitebox as WB
+
+    rank, world, local = shard.init_process_group()
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)\n' % (args.gpus, world))
+        if args.gpus != 1 or world != 1:
+            sys.exit(2)
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    B = args.batch
+
+    bb = resnet.ResNet([3, 4, 23, 3], num_classes=2)   # fc2 is replaced by the per-triplet classifier anyway
+    bb.to(dev)
+    wbn = WB.WhiteboxSTResnet(bb)
+    wbn.default_max_batch = B
+    wb = WB.Whitebox(wbn, ebp_subtree_mode=args.mode)
+    sd_holder = {}
+
+    def make_sd():
+        sd_holder['sd'] = synth.synth_state_dict(bb, seed=0, recipe='mild')
+        return sd_holder['sd']
+    # engine without weights; rank 0 packs, everybody receives the arena over RCCL
+    from xfr_amd.engine import Engine
+    wbn._program = bb.build_program()
+    wbn._engine = Engine(wbn._program, B, dev)
+    wbn._engine_key = (str(bb.device), id(bb))
+    shard.load_and_broadcast(wbn._engine, make_sd, src=0)
+    wbn._engine.loaded_version = bb.version
+    eng = wb._engine(B)
+    enc_t = wbn._program.marks['encode']
+
+    # synthetic triplets of this rank's shard, resident in HBM (uint8-valued ~U[0,255] minus the RGB mean)
+    lo = rank * B
+    imgs = synth.synth_images(3 * B, (3, 224, 224), seed=1234 + rank, mean=resnet.MEAN_RGB)
+    mates, nonmates, probes = imgs[0:B].to(dev), imgs[B:2 * B].to(dev), imgs[2 * B:3 * B].to(dev)
+
+    def step():
+        xm = eng.forward(mates, enc_t).reshape(B, -1)
+        xn = eng.forward(nonmates, enc_t).reshape(B, -1)
+        seeds = torch.stack((xm, xn), dim=0) * (1.0 / 2500.0)
+        return eng.contrastive(probes, enc_t, seeds, None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sal = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sal = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = bool(torch.isfinite(sal).all().item()) and abs(float(sal[0].sum().item()) - 1.0) < 1e-3
+
+    roof = None
+    if not args.no_profile:
+        # live GEMM timing: HIP events around every conv_gemm launch on the launch stream, separate steps after the
+        # timed region
+        eng.set_profile(True)
+        tot_ms, tot_n, tot_fl = 0.0, 0, 0.0
+        reps = 2
+        for _ in range(reps):
+            xm = eng.forward(mates, enc_t).reshape(B, -1)
+            ms, n, fl = eng.get_profile(); tot_ms += ms; tot_n += n; tot_fl += fl
+            xn = eng.forward(nonmates, enc_t).reshape(B, -1)
+            ms, n, fl = eng.get_profile(); tot_ms += ms; tot_n += n; tot_fl += fl
+            eng.contrastive(probes, enc_t, torch.stack((xm, xn), dim=0) * (1.0 / 2500.0), None)
+            ms, n, fl = eng.get_profile(); tot_ms += ms; tot_n += n; tot_fl += fl
+        eng.set_profile(False)
+        alg = FLOPS_PER_TRIPLET * B * reps
+        achieved = alg / (tot_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA / 1e12, 'unit': 'TFLOP/s',
+                'frac': achieved / (PEAK_F32_MFMA / 1e12), 'traffic': None,
+                'kernel': 'conv_gemm_kernel (all shapes of one step)', 'launches_per_step': tot_n // reps,
+                'avg_launch_ms': tot_ms / max(tot_n, 1), 'gemm_ms_per_step': tot_ms / reps,
+                'executed_flop_per_step': tot_fl / reps, 'algorithmic_flop_per_step': alg / reps}
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        line = {
+            'metric': 'triplet-contrastive-EBP saliency maps/sec, ResNet-101 224x224',
+            'value': value, 'unit': 'maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'ResNet-101 triplet contrastive EBP, batch=%d synthetic 224x224 triplets per GPU '
+                                   '(2 encodes + contrastive_ebp per triplet), mode %s, eps 1e-16' % (B, args.mode),
+                       'triplets_per_gpu': B, 'parallelism': 'independent triplets, %d process(es), weights broadcast once' % world},
+            'outputs_ok': ok,
+        }
+        if roof is not None:
+            line['roofline'] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(sd_holder['sd'], probes.cpu(), mates.cpu(), nonmates.cpu(), args.mode)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

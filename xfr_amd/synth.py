@@ -77,7 +77,9 @@ def synth_images(n, shape, seed=1234, mean=None, scale255=True):
 
 
 def synth_smooth_images(n, shape, seed=1234, mean=None, scale255=True):
-    """Low-frequency 'face-like' blobs (sum of a few random Gaussians), so saliency maps have structure."""
+    """Low-frequency 'face-like' blobs (sum of a few random Gaussians) plus 15 % pixel noise, so saliency maps have
+    structure but no two receptive fields are identical (exact plateaus make max-pool argmax a coin toss between
+    implementations that differ in the last bit)."""
     g = torch.Generator().manual_seed(int(seed))
     c, h, w = shape
     yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32),
@@ -91,7 +93,7 @@ def synth_smooth_images(n, shape, seed=1234, mean=None, scale255=True):
                 s = 8 + 40 * torch.rand(1, generator=g)
                 amp = torch.rand(1, generator=g)
                 img += amp * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
-            img = img / img.max()
+            img = 0.85 * img / img.max() + 0.15 * torch.rand((h, w), generator=g)
             out[i, ch] = img
     if scale255:
         out = torch.floor(out * 255.0)
