@@ -21,7 +21,10 @@ struct ConvParams {
     const float* bias_pos;
     float* out0;        // output of half 0 (w, bias)
     float* out1;        // output of half 1 (w_pos, bias_pos) when nhalves == 2
-    int Cin, H, W, NB;
+    int Cin, H, W, NB;  // NB: images covered by this launch (M = NB*OH*OW)
+    int in_nb, out_nb;  // images per channel row of the input / output tensors (>= NB: a launch may cover a batch prefix)
+    unsigned in_bytes;  // byte size of the input tensor (buffer descriptor range; < 2^31)
+    int tap_major;      // K ordered (kh, kw, ci) instead of (ci, kh, kw); requires Cin % 16 == 0
     int kh, kw, stride, pad;
     int OH, OW;
     int K, M;           // M = NB*OH*OW

@@ -6,21 +6,28 @@
 // GEMM view (per launch):   Out[co][m] = sum_k Wp[k][co] * Im2col[k][m]  (+ bias[co])
 //     co : output channel            -> MFMA "A" operand index i (register-mapped rows of the 32x32 D tile)
 //     m  : (n, oh, ow) flattened     -> MFMA "B" operand index j (lane-mapped columns of D)  => contiguous in HBM
-//     k  : (ci, kh, kw) flattened    -> reduction
+//     k  : reduction index, (tap, ci) "tap-major" when Cin % 16 == 0, else (ci, kh, kw)
 // Tensors are CNHW (common.h), so for a fixed k the B row is a shifted, masked, contiguous run of the input and
-// the D tile is stored with 128-byte coalesced rows.  Weights are pre-packed K-major ([K][ldw]) at load time, so
-// the A tile is read with float4 loads.  A "dual" launch (nhalves == 2) runs W (-> out0 = true activations) and
-// relu(W) (-> out1 = positive activations X) as two halves of one grid whose co-tiles of the same m-tile are
-// scheduled back-to-back on one XCD, so the activation tile is fetched from HBM once for both.
+// the D tile is stored with 128-byte coalesced rows.  Weights are pre-packed K-major ([K][ldw]) at load time.
+// A "dual" launch (nhalves == 2) runs W (-> out0 = true activations) and relu(W) (-> out1 = positive activations
+// X) as two halves of one grid whose co-tiles of the same m-tile are scheduled back-to-back on one XCD, so the
+// activation tile is fetched from HBM once for both.
 //
 // The same kernel runs the backward-data GEMMs of the MWP sweep: the engine packs relu(W) transposed and
 // spatially flipped, which turns conv-backward-data (stride 1) into a forward convolution; 1x1 stride-2
 // backward scatters its output grid (out_stride = 2).
 //
 // MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD, 157 TFLOP/s chip peak).  Block = 256 threads =
-// 4 waves in a 2x2 arrangement, each wave owns (TCO/2)x(TM/2) of the block tile as (TCO/64)x(TM/64) MFMA tiles.
-// K is consumed in steps of 16 through double-buffered LDS (register-staged prefetch of the next step overlaps
-// the 32*MI*NJ/4 MFMAs of the current one); one barrier per step.
+// 4 waves (2x2), each wave owns (TCO/2)x(TM/2) of the block tile as (TCO/64)x(TM/64) MFMA tiles.
+//
+// Feeding: fp32 MFMA needs few bytes per flop, so the enemy is latency, not bandwidth (the layer-3/4 GEMMs of a
+// 32-image batch give each CU only 1-3 workgroups).  Operands therefore go global -> LDS directly
+// (global_load_lds, no VGPR round trip) through an NST-deep ring of LDS stages: the loads of K-step kt+NST-1 are
+// issued before the MFMAs of step kt, and a counted `s_waitcnt vmcnt((NST-2)*L)` + one raw s_barrier per step is
+// the only synchronisation -- loads stay in flight across barriers.  Loads are buffer-addressed
+// (buffer_load ... lds): per-lane 32-bit offsets are precomputed, the K walk is a scalar soffset, and masked im2col
+// elements (padding, K/M tails) are out-of-range offsets for which the hardware writes 0.0 -- the K-loop carries
+// no per-element address arithmetic and no branches.
 #include "common.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -30,37 +37,60 @@ namespace {
 constexpr int BK = 16;
 constexpr int NT = 256;
 
-template <int KS>
-struct KDecode {
-    // k -> (ci, dh, dw)
-    __device__ static inline void run(int k, int kh, int kw, int& ci, int& dh, int& dw) {
-        if (KS == 1) { ci = k; dh = 0; dw = 0; }
-        else if (KS > 1) { ci = k / (KS * KS); int r = k - ci * (KS * KS); dh = r / KS; dw = r - dh * KS; }
-        else { int kk = kh * kw; ci = k / kk; int r = k - ci * kk; dh = r / kw; dw = r - dh * kw; }
-    }
-};
-
 // XCD-aware block -> tile mapping.  The dispatcher places block b on XCD b % 8; remap so that each XCD walks a
 // contiguous range of logical tiles, ordered co-fastest: the blocks that share one activation (m) tile run
 // back-to-back on the same XCD and hit its private L2.  Bijective for any grid size.
-__device__ inline int xcd_remap(int bid, int nblk) {
+__device__ inline int xcd_remap(int bid, int nblk)
+{
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, loc = bid >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + loc;
 }
 
-template <int TCO, int TM, int KS, bool VEC>
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Buffer-addressed global -> LDS loads.  address = rsrc.base + voffset (per lane) + soffset (wave-uniform); a lane
+// whose voffset is >= rsrc.num_records (we use 0x80000000 for masked im2col elements) is out of range and the
+// hardware writes 0.0 into its LDS slot -- padding, M tails and K tails cost no branch and no zero page.
+__device__ inline void bload16(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)l, 16, (int)voff, (int)soff, 0, 0);
+}
+__device__ inline void bload4(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)l, 4, (int)voff, (int)soff, 0, 0);
+}
+
+constexpr unsigned OOB = 0x80000000u;
+
+enum { MODE_VEC = 0, MODE_TAP = 1, MODE_GEN = 2 };
+
+template <int N>
+__device__ inline void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TCO, int TM, int NST, int MODE, bool RELU>
 __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     constexpr int MI = TCO / 64;   // MFMA tiles per wave along co
     constexpr int NJ = TM / 64;    // MFMA tiles per wave along m
-    __shared__ float As[2][BK][TCO];
-    __shared__ float Bs[2][BK][TM];
+    constexpr int A_FLOATS = BK * TCO, B_FLOATS = BK * TM;
+    constexpr int STAGE = A_FLOATS + B_FLOATS;
+    constexpr int A_PER_WAVE = A_FLOATS / 256 / 4;                        // 16-byte wave-loads per wave per stage
+    constexpr int B_PER_WAVE = (MODE == MODE_VEC) ? B_FLOATS / 256 / 4    // 16-byte wave-loads
+                                                  : B_FLOATS / 64 / 4;    // 4-byte wave-loads (one k row x 64 m)
+    constexpr int L = A_PER_WAVE + B_PER_WAVE;
+    constexpr int MSLOTS = TM / 64;                                       // m columns owned by a lane in the dword modes
+    constexpr int ROWS_PER_WAVE = (MODE == MODE_VEC) ? 1 : B_PER_WAVE / MSLOTS;   // k rows a wave loads per stage
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wrow = wave >> 1, wcol = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -77,93 +107,109 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
     float* __restrict__ osel = half ? p.out1 : p.out0;
 
-    // ---- A (weights) staging geometry: float4 along co
-    constexpr int A_F4_ROW = TCO / 4;
-    constexpr int A_ROWS_PASS = NT / A_F4_ROW;
-    constexpr int A_PASSES = BK / A_ROWS_PASS;
-    const int a_row = tid / A_F4_ROW;
-    const int a_c4 = tid - a_row * A_F4_ROW;
-    const float* wbase = wsel + co0 + a_c4 * 4;
-    float4 areg[A_PASSES];
+    const int nk = (p.K + BK - 1) / BK;
+    const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
+    // weights are packed with K padded to a multiple of BK (zero rows): no K tail on the A side
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, nk * BK * p.ldw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
 
-    // ---- B (im2col) staging geometry
-    // generic: one m column per thread, BK*TM/NT rows
-    constexpr int B_PER_T = BK * TM / NT;
-    constexpr int B_KSTEP = NT / TM;
-    const int b_m = tid % TM;
-    const int b_k0 = tid / TM;
-    // vector (1x1 stride 1, M % 4 == 0): float4 along m
-    constexpr int B_F4_ROW = TM / 4;
-    constexpr int B_ROWS_PASS = NT / B_F4_ROW;
-    constexpr int B_PASSES = BK / B_ROWS_PASS;
-    const int bv_row = tid / B_F4_ROW;
-    const int bv_c4 = tid - bv_row * B_F4_ROW;
-
-    float breg[VEC ? 1 : B_PER_T];
-    float4 bvreg[VEC ? B_PASSES : 1];
-
-    long base_m = 0;
-    int ih0 = 0, iw0 = 0;
-    bool m_ok = false;
-    const long chan_stride = (long)p.NB * p.H * p.W;
-    if (!VEC) {
-        const int m = m0 + b_m;
-        m_ok = m < p.M;
-        const int mm = m_ok ? m : 0;
-        const int ohw = p.OH * p.OW;
-        const int n = mm / ohw;
-        const int r = mm - n * ohw;
-        const int oh = r / p.OW;
-        const int ow = r - oh * p.OW;
-        ih0 = oh * p.stride - p.pad;
-        iw0 = ow * p.stride - p.pad;
-        base_m = (long)n * p.H * p.W + (long)ih0 * p.W + iw0;
+    // ---- A side: per-lane byte offsets inside a K-step are constant; soffset walks k0
+    unsigned voffA[A_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int f = (wave * A_PER_WAVE + i) * 256 + lane * 4;
+        const int row = f / TCO, col = f - row * TCO;
+        voffA[i] = (unsigned)(row * p.ldw + co0 + col) * 4u;
     }
+    const unsigned a_step = (unsigned)BK * p.ldw * 4u;
 
-    auto load_tiles = [&](int k0) {
+    // ---- B side
+    unsigned voffB[(MODE == MODE_VEC) ? B_PER_WAVE : MSLOTS];
+    int base_m[MSLOTS], ih0[MSLOTS], iw0[MSLOTS];
+    unsigned long long tapmask[MSLOTS];
+    if (MODE == MODE_VEC) {
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) {
-            const int k = k0 + a_row + ps * A_ROWS_PASS;
-            if (k < p.K) areg[ps] = *reinterpret_cast<const float4*>(wbase + (long)k * p.ldw);
-            else areg[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < B_PER_WAVE; ++i) {
+            const int f = (wave * B_PER_WAVE + i) * 256 + lane * 4;
+            const int row = f / TM, col = f - row * TM;
+            const int m = m0 + col;
+            // columns beyond M are never stored; keep them inside the row so the read stays in range
+            voffB[i] = (m < p.M) ? (unsigned)row * chan_bytes + (unsigned)m * 4u : OOB;
         }
-        if (VEC) {
+    } else {
 #pragma unroll
-            for (int ps = 0; ps < B_PASSES; ++ps) {
-                const int k = k0 + bv_row + ps * B_ROWS_PASS;
-                const int m = m0 + bv_c4 * 4;
-                if (k < p.K && m < p.M) {
-                    float4 v = *reinterpret_cast<const float4*>(p.in + (long)k * p.M + m);
-                    if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    bvreg[ps] = v;
-                } else bvreg[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < MSLOTS; ++s) {
+            const int m = m0 + s * 64 + lane;
+            const bool m_ok = m < p.M;
+            const int mm = m_ok ? m : 0;
+            const int ohw = p.OH * p.OW;
+            const int n = mm / ohw;
+            const int r = mm - n * ohw;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            ih0[s] = m_ok ? oh * p.stride - p.pad : -(1 << 28);
+            iw0[s] = ow * p.stride - p.pad;
+            base_m[s] = n * p.H * p.W + (oh * p.stride - p.pad) * p.W + iw0[s];
+            unsigned long long mk = 0ull;
+            if (MODE == MODE_TAP && m_ok) {
+                for (int dh = 0; dh < p.kh; ++dh)
+                    for (int dw = 0; dw < p.kw; ++dw)
+                        if ((unsigned)(ih0[s] + dh) < (unsigned)p.H && (unsigned)(iw0[s] + dw) < (unsigned)p.W)
+                            mk |= 1ull << (dh * p.kw + dw);
             }
+            tapmask[s] = mk;
+            voffB[s] = OOB;
+        }
+    }
+    int iss_tap = 0, iss_ci0 = 0;     // (tap, first input channel) of the next K-step to be issued
+    bool tap_dirty = true;
+
+    // ---- issue the loads of one K-step into LDS stage `st`
+    auto issue = [&](int kt, int st) {
+        float* As = smem + st * STAGE;
+        float* Bs = As + A_FLOATS;
+        const int k0 = kt * BK;
+        const bool live = kt < nk;      // steps past the end load nothing real (uniform vmcnt accounting)
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i)
+            bload16(rW, As + (wave * A_PER_WAVE + i) * 256, live ? voffA[i] : OOB, (unsigned)kt * a_step);
+        if (MODE == MODE_VEC) {
+#pragma unroll
+            for (int i = 0; i < B_PER_WAVE; ++i)
+                bload16(rIn, Bs + (wave * B_PER_WAVE + i) * 256, live ? voffB[i] : OOB, (unsigned)k0 * chan_bytes);
+        } else if (MODE == MODE_TAP) {
+            // Cin % 16 == 0: one tap per K-step; K-steps are issued in order, so (tap, ci0) advance incrementally
+            const int tap = iss_tap, ci0 = iss_ci0;
+            if (tap_dirty) {                          // wave-uniform: new tap => new per-lane shifted offsets
+                tap_dirty = false;
+                const int dh = tap / p.kw, dw = tap - dh * p.kw;
+                const int shift = dh * p.W + dw;
+#pragma unroll
+                for (int s = 0; s < MSLOTS; ++s)
+                    voffB[s] = (live && ((tapmask[s] >> tap) & 1ull)) ? (unsigned)(base_m[s] + shift) * 4u : OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER_WAVE; ++i) {
+                const int q = wave * B_PER_WAVE + i;  // (k row, 64-wide m segment)
+                const int row = q / MSLOTS, s = q - row * MSLOTS;
+                bload4(rIn, Bs + q * 64, voffB[s], (unsigned)(ci0 + row) * chan_bytes);
+            }
+            iss_ci0 += BK;
+            if (iss_ci0 >= p.Cin) { iss_ci0 = 0; iss_tap += 1; tap_dirty = true; }
         } else {
 #pragma unroll
-            for (int i = 0; i < B_PER_T; ++i) {
-                const int k = k0 + b_k0 + i * B_KSTEP;
-                int ci, dh, dw;
-                KDecode<KS>::run(k, p.kh, p.kw, ci, dh, dw);
-                const bool ok = m_ok && (k < p.K) && ((unsigned)(ih0 + dh) < (unsigned)p.H) &&
-                                ((unsigned)(iw0 + dw) < (unsigned)p.W);
-                float v = 0.f;
-                if (ok) v = p.in[(long)ci * chan_stride + base_m + dh * p.W + dw];
-                if (p.relu_in) v = fmaxf(v, 0.f);
-                breg[i] = v;
+            for (int i = 0; i < B_PER_WAVE; ++i) {
+                const int q = wave * B_PER_WAVE + i;
+                const int row = q / MSLOTS, s = q - row * MSLOTS;
+                const int k = k0 + row;
+                const int kk = p.kh * p.kw;
+                const int ci = k / kk;
+                const int r = k - ci * kk;
+                const int dh = r / p.kw, dw = r - dh * p.kw;
+                const bool ok = (k < p.K) && ((unsigned)(ih0[s] + dh) < (unsigned)p.H) &&
+                                ((unsigned)(iw0[s] + dw) < (unsigned)p.W);
+                bload4(rIn, Bs + q * 64, ok ? (unsigned)(base_m[s] + dh * p.W + dw) * 4u : OOB, (unsigned)ci * chan_bytes);
             }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps)
-            *reinterpret_cast<float4*>(&As[buf][a_row + ps * A_ROWS_PASS][a_c4 * 4]) = areg[ps];
-        if (VEC) {
-#pragma unroll
-            for (int ps = 0; ps < B_PASSES; ++ps)
-                *reinterpret_cast<float4*>(&Bs[buf][bv_row + ps * B_ROWS_PASS][bv_c4 * 4]) = bvreg[ps];
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_PER_T; ++i) Bs[buf][b_k0 + i * B_KSTEP][b_m] = breg[i];
         }
     };
 
@@ -175,33 +221,56 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
+    // prologue: fill NST-1 stages
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(s, s);
 
     const int a_off = wrow * (TCO / 2) + l31;
     const int b_off = wcol * (TM / 2) + l31;
 
+    int st = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        // stage kt has landed once at most (NST-2) younger stages are still in flight; the barrier then also
+        // guarantees every wave is done reading the stage we are about to refill.
+        wait_vmcnt<(NST - 2) * L>();
+        __builtin_amdgcn_s_barrier();
+        int st_fill = st + NST - 1;
+        if (st_fill >= NST) st_fill -= NST;
+        issue(kt + NST - 1, st_fill);
+        const float* As = smem + st * STAGE;
+        const float* Bs = As + A_FLOATS;
+        // software-pipelined LDS reads: the fragments of k-pair kk+2 are in flight while the MFMAs of kk run
+        float a_cur[MI], b_cur[NJ], a_nxt[MI], b_nxt[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a_cur[i] = As[lhi * TCO + a_off + i * 32];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b_cur[j] = Bs[lhi * TM + b_off + j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[MI], b[NJ];
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = As[buf][kk + lhi][a_off + i * 32];
+                for (int i = 0; i < MI; ++i) a_nxt[i] = As[(kk + 2 + lhi) * TCO + a_off + i * 32];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = Bs[buf][kk + lhi][b_off + j * 32];
+                for (int j = 0; j < NJ; ++j) b_nxt[j] = Bs[(kk + 2 + lhi) * TM + b_off + j * 32];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (RELU) b_cur[j] = fmaxf(b_cur[j], 0.f);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b_cur[j] = b_nxt[j];
+            }
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
+        st = (st + 1 == NST) ? 0 : st + 1;
     }
+    wait_vmcnt<0>();   // drain the tail loads before the LDS is released
 
     // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
 #pragma unroll
@@ -212,7 +281,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         long row_stride;
         if (p.out_stride == 1) {
             col = m;
-            row_stride = p.M;
+            row_stride = (long)p.out_nb * p.OH * p.OW;
         } else {
             const int ohw = p.OH * p.OW;
             const int n = m / ohw;
@@ -220,7 +289,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
             const int oh = r / p.OW;
             const int ow = r - oh * p.OW;
             col = ((long)n * p.out_H + (long)oh * p.out_stride) * p.out_W + (long)ow * p.out_stride;
-            row_stride = (long)p.NB * p.out_H * p.out_W;
+            row_stride = (long)p.out_nb * p.out_H * p.out_W;
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -239,18 +308,24 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     }
 }
 
-template <int TCO, int TM>
-void launch_cfg(const ConvParams& p, hipStream_t s)
+template <int TCO, int TM, int NST, int MODE>
+void launch_one(const ConvParams& p, hipStream_t s)
 {
     const int n_co = ((p.CoutTot + TCO - 1) / TCO) * p.nhalves;
     const int n_m = (p.M + TM - 1) / TM;
-    dim3 grid(n_co * n_m), block(NT);
-    const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 &&
-                      p.OH == p.H && p.OW == p.W);
-    if (vec) hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, 1, true>), grid, block, 0, s, p, n_co, n_m);
-    else if (p.kh == 1 && p.kw == 1) hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, 1, false>), grid, block, 0, s, p, n_co, n_m);
-    else if (p.kh == 3 && p.kw == 3) hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, 3, false>), grid, block, 0, s, p, n_co, n_m);
-    else hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, 0, false>), grid, block, 0, s, p, n_co, n_m);
+    const size_t lds = (size_t)NST * BK * (TCO + TM) * sizeof(float);
+    if (p.relu_in) hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, NST, MODE, true>), dim3(n_co * n_m), dim3(NT), lds, s, p, n_co, n_m);
+    else hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, NST, MODE, false>), dim3(n_co * n_m), dim3(NT), lds, s, p, n_co, n_m);
+}
+
+template <int TCO, int TM, int NST>
+void launch_cfg(const ConvParams& p, hipStream_t s)
+{
+    const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H &&
+                      p.OW == p.W && p.in_nb == p.NB);
+    if (vec) launch_one<TCO, TM, NST, MODE_VEC>(p, s);
+    else if (p.tap_major) launch_one<TCO, TM, NST, MODE_TAP>(p, s);
+    else launch_one<TCO, TM, NST, MODE_GEN>(p, s);
 }
 
 }  // namespace
@@ -260,8 +335,8 @@ void launch_conv_gemm(const ConvParams& p, hipStream_t s)
     // Tile choice: biggest tile that still gives every CU >= 2 workgroups (256 CUs); otherwise shrink.
     auto blocks = [&](int tco, int tm) { return (long)((p.CoutTot + tco - 1) / tco) * p.nhalves * ((p.M + tm - 1) / tm); };
     const long want = 512;
-    if (p.CoutTot > 64 && blocks(128, 128) >= want) launch_cfg<128, 128>(p, s);
-    else if (blocks(64, 128) >= want) launch_cfg<64, 128>(p, s);
-    else if (p.CoutTot > 64 && blocks(128, 64) >= want && p.M <= 64 * 1024) launch_cfg<128, 64>(p, s);
-    else launch_cfg<64, 64>(p, s);
+    if (p.CoutTot > 64 && blocks(128, 128) >= want) launch_cfg<128, 128, 3>(p, s);
+    else if (blocks(64, 128) >= want) launch_cfg<64, 128, 4>(p, s);
+    else if (p.CoutTot > 64 && blocks(128, 64) >= want) launch_cfg<128, 64, 4>(p, s);
+    else launch_cfg<64, 64, 4>(p, s);
 }

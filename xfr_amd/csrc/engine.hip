@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,6 +74,7 @@ struct OpRec {
     long b_true = -1, b_pos = -1;            // conv/linear bias and relu(bias)
     long bn_alpha_t = -1, bn_beta_t = -1, bn_alpha_p = -1, bn_beta_p = -1, bn_beta_pb = -1;
     int ldw = 0, ldb = 0;
+    bool tap_fwd = false, tap_bwd = false;   // K packed tap-major (kh,kw,ci) for the forward / backward-data GEMM
     int Cin = 0, K = 0, Kb = 0;
     size_t idx_off = 0;                      // maxpool argmax (bytes into idx workspace)
     size_t norm_off = 0;                     // normalize: norms (floats into misc workspace)
@@ -139,6 +141,7 @@ struct xfr_engine {
     std::vector<int> last_trace_kinds;
     int profile_on = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<ConvParams> ev_params;
     size_t ev_used = 0;
     double prof_flops = 0.0;
     double last_gemm_ms = 0.0;
@@ -348,6 +351,9 @@ void compute_need(xfr_engine* e)
 xfr_status allocate(xfr_engine* e)
 {
     const size_t B = (size_t)e->max_batch;
+    for (auto& x : e->tens)
+        if (2 * B * (size_t)x.per_n() * sizeof(float) >= (1ull << 31))
+            return fail(XFR_INVALID_ARG, "max_batch %d makes a tensor exceed 2 GiB (32-bit buffer offsets)", e->max_batch);
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
     e->x_off = take(B * e->tens[0].per_n());
@@ -377,6 +383,7 @@ xfr_status allocate(xfr_engine* e)
         if (o.d.kind == XFR_OP_MAXPOOL) { o.idx_off = idxb; idxb += align_up(B * e->tens[o.d.out].per_n(), 256); }
     }
     e->misc_off = take(std::max<size_t>(misc, 64));
+    take(4096);   // slack: vector loads of a tile's dead columns may run past the last tensor
     e->ws_floats = off;
     e->idx_bytes = std::max<size_t>(idxb, 256);
     HIP_TRY(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
@@ -399,11 +406,13 @@ xfr_status layout_arena(xfr_engine* e)
         const xfr_op_desc& d = o.d;
         if (d.kind == XFR_OP_CONV || d.kind == XFR_OP_LINEAR) {
             o.ldw = (int)align_up(d.cout, 128);
-            o.w_true = take((size_t)o.K * o.ldw);
-            o.w_pos = take((size_t)o.K * o.ldw);
+            o.tap_fwd = (d.kh * d.kw > 1) && (o.Cin % 16 == 0) && (d.kh * d.kw <= 64);
+            o.tap_bwd = (d.kh * d.kw > 1) && (d.cout % 16 == 0) && (d.kh * d.kw <= 64);
+            o.w_true = take(align_up(o.K, 16) * o.ldw);
+            o.w_pos = take(align_up(o.K, 16) * o.ldw);
             if (k != 0) {
                 o.ldb = (int)align_up(o.Cin, 128);
-                o.w_bwd = take((size_t)o.Kb * o.ldb);
+                o.w_bwd = take(align_up(o.Kb, 16) * o.ldb);
             }
             if (d.w_bias >= 0) { o.b_true = take(d.cout); o.b_pos = take(d.cout); }
         } else if (d.kind == XFR_OP_BATCHNORM) {
@@ -431,11 +440,13 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p, hipStream_t s)
             HIP_TRY(hipEventCreate(&b));
             e->ev_pool.emplace_back(a, b);
         }
+        if (e->ev_params.size() < e->ev_pool.size()) e->ev_params.resize(e->ev_pool.size());
+        e->ev_params[e->ev_used] = p;
         auto& ev = e->ev_pool[e->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, s));
         launch_conv_gemm(p, s);
         HIP_TRY(hipEventRecord(ev.second, s));
-        e->prof_flops += 2.0 * (double)p.K * (double)p.M * (double)p.CoutTot;
+        e->prof_flops += 2.0 * (double)p.K * (double)p.M * (double)p.CoutTot * (double)p.nhalves;
     } else {
         launch_conv_gemm(p, s);
     }
@@ -455,6 +466,9 @@ void conv_geometry(xfr_engine* e, int k, int NB, ConvParams& p)
     p.K = o.K; p.M = NB * t.H * t.W;
     p.ldw = o.ldw;
     p.out_H = t.H; p.out_W = t.W; p.out_stride = 1;
+    p.in_nb = NB; p.out_nb = NB;
+    p.in_bytes = (unsigned)((size_t)NB * a.per_n() * sizeof(float));
+    p.tap_major = o.tap_fwd ? 1 : 0;
 }
 
 // forward of op k on true values (and, for "dual" convolutions, the positive output in the same launch)
@@ -827,7 +841,9 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                 p.in = e->G(st.src_t);
                 p.w = e->arena + o.w_bwd;
                 p.out0 = e->G(st.dst_t);
-                p.Cin = t.C; p.H = t.H; p.W = t.W; p.NB = SB;
+                p.Cin = t.C; p.H = t.H; p.W = t.W; p.NB = SB; p.in_nb = SB; p.out_nb = SB;
+                p.tap_major = (d.stride == 1 && o.tap_bwd) ? 1 : 0;
+                p.in_bytes = (unsigned)((size_t)SB * t.per_n() * sizeof(float));
                 p.CoutTot = a.C; p.nhalves = 1; p.ldw = o.ldb;
                 p.K = o.Kb;
                 p.accumulate = st.accumulate;
@@ -907,11 +923,20 @@ xfr_status prof_end(xfr_engine* e, hipStream_t s)
     if (!e->profile_on) return XFR_OK;
     HIP_TRY(hipStreamSynchronize(s));
     double ms = 0.0;
+    const char* dump = getenv("XFR_PROFILE_DUMP");   // debug: per-launch GEMM records appended as CSV
+    FILE* f = dump ? fopen(dump, "a") : nullptr;
     for (size_t i = 0; i < e->ev_used; ++i) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, e->ev_pool[i].first, e->ev_pool[i].second));
         ms += t;
+        if (f) {
+            const ConvParams& p = e->ev_params[i];
+            const double fl = 2.0 * p.K * (double)p.M * p.CoutTot * p.nhalves;
+            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", p.CoutTot, p.nhalves, p.K, p.M, p.kh, p.stride, p.out_stride,
+                    p.relu_in, p.accumulate, t, fl / (t * 1e-3) / 1e12);
+        }
     }
+    if (f) fclose(f);
     e->last_gemm_ms = ms;
     e->last_gemm_launches = (long)e->ev_used;
     e->last_gemm_flops = e->prof_flops;
@@ -994,14 +1019,16 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
                             (long long)d.cout * o.Cin * khw);
             float* wt = host.data() + o.w_true;
             float* wp = host.data() + o.w_pos;
-            // forward pack: [k = (ci,kh,kw)][co]
+            // forward pack: [k][co], k = (ci,kh,kw) or tap-major (kh,kw,ci)
             for (int co = 0; co < d.cout; ++co) {
                 const float* src = wv.data + (size_t)co * o.K;
-                for (int kk = 0; kk < o.K; ++kk) {
-                    const float v = src[kk];
-                    wt[(size_t)kk * o.ldw + co] = v;
-                    wp[(size_t)kk * o.ldw + co] = v > 0.f ? v : 0.f;   // relu(W): whitebox.py:319
-                }
+                for (int ci = 0; ci < o.Cin; ++ci)
+                    for (int tp = 0; tp < khw; ++tp) {
+                        const float v = src[ci * khw + tp];
+                        const size_t kk = o.tap_fwd ? (size_t)tp * o.Cin + ci : (size_t)ci * khw + tp;
+                        wt[kk * o.ldw + co] = v;
+                        wp[kk * o.ldw + co] = v > 0.f ? v : 0.f;   // relu(W): whitebox.py:319
+                    }
             }
             if (o.w_bwd >= 0) {
                 // backward-data pack of relu(W): [k' = (co, kh', kw')][ci] with the kernel flipped
@@ -1012,7 +1039,9 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
                             for (int b = 0; b < d.kw; ++b) {
                                 const float v = wv.data[(((size_t)co * o.Cin + ci) * d.kh + a) * d.kw + b];
                                 const int a2 = d.kh - 1 - a, b2 = d.kw - 1 - b;
-                                wb[((size_t)(co * d.kh + a2) * d.kw + b2) * o.ldb + ci] = v > 0.f ? v : 0.f;
+                                const size_t kk = (o.tap_bwd && d.stride == 1) ? (size_t)(a2 * d.kw + b2) * d.cout + co
+                                                                               : (size_t)(co * d.kh + a2) * d.kw + b2;
+                                wb[kk * o.ldb + ci] = v > 0.f ? v : 0.f;
                             }
             }
             if (d.w_bias >= 0) {
