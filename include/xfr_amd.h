@@ -178,6 +178,14 @@ xfr_status xfr_engine_set_trace(xfr_engine* e, int32_t enable);
 xfr_status xfr_engine_trace_size(xfr_engine* e, int32_t* n_firings);
 xfr_status xfr_engine_get_trace(xfr_engine* e, double* sums, int32_t* kinds, int32_t capacity);
 
+/* Test / tuning hook: one forward convolution through the engine's implicit-GEMM kernel, outside any engine.
+ * in_dev/out_dev are CNHW device tensors ([C][NB][H][W]); w_host/bias_host are PyTorch-layout host arrays.
+ * cfg = 0 lets the launcher pick the tile configuration, cfg > 0 forces configuration `cfg`.  The kernel is run
+ * `reps` times after one untimed launch; *ms_out receives the average duration (HIP events on the null stream). */
+xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float* bias_host, float* out_dev, int32_t cin,
+                          int32_t h, int32_t w, int32_t nb, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
+                          int32_t pad, int32_t relu_in, int32_t cfg, int32_t reps, float* ms_out);
+
 /* Bytes of device memory held by the engine (weights + workspace). */
 xfr_status xfr_engine_memory(xfr_engine* e, size_t* weight_bytes, size_t* workspace_bytes);
 

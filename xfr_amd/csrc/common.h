@@ -24,6 +24,7 @@ struct ConvParams {
     int Cin, H, W, NB;  // NB: images covered by this launch (M = NB*OH*OW)
     int in_nb, out_nb;  // images per channel row of the input / output tensors (>= NB: a launch may cover a batch prefix)
     unsigned in_bytes;  // byte size of the input tensor (buffer descriptor range; < 2^31)
+    int force_cfg;      // 0 = heuristic tile choice, else a configuration id (tuning / tests)
     int tap_major;      // K ordered (kh, kw, ci) instead of (ci, kh, kw); requires Cin % 16 == 0
     int kh, kw, stride, pad;
     int OH, OW;
@@ -35,6 +36,7 @@ struct ConvParams {
 };
 
 void launch_conv_gemm(const ConvParams& p, hipStream_t s);
+int conv_gemm_pick_cfg(const ConvParams& p);
 
 // ---- fused elementwise backward chain ------------------------------------------------------------------------
 enum { EW_HOOK = 0, EW_MASK = 1, EW_SCALE_C = 2, EW_SCALE = 3 };

@@ -34,7 +34,6 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 16;
 constexpr int NT = 256;
 
 // XCD-aware block -> tile mapping.  The dispatcher places block b on XCD b % 8; remap so that each XCD walks a
@@ -72,7 +71,7 @@ __device__ inline void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TCO, int TM, int NST, int MODE, bool RELU>
+template <int TCO, int TM, int BK, int NST, int MODE, bool RELU>
 __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     constexpr int MI = TCO / 64;   // MFMA tiles per wave along co
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
     float* __restrict__ osel = half ? p.out1 : p.out0;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (p.K + BK - 1) / BK;   // the packed weights are zero-padded to a multiple of 32 rows
     const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
     // weights are packed with K padded to a multiple of BK (zero rows): no K tail on the A side
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, nk * BK * p.ldw * 4, 0x00020000);
@@ -308,35 +307,51 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     }
 }
 
-template <int TCO, int TM, int NST, int MODE>
+template <int TCO, int TM, int BK, int NST, int MODE>
 void launch_one(const ConvParams& p, hipStream_t s)
 {
     const int n_co = ((p.CoutTot + TCO - 1) / TCO) * p.nhalves;
     const int n_m = (p.M + TM - 1) / TM;
     const size_t lds = (size_t)NST * BK * (TCO + TM) * sizeof(float);
-    if (p.relu_in) hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, NST, MODE, true>), dim3(n_co * n_m), dim3(NT), lds, s, p, n_co, n_m);
-    else hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, NST, MODE, false>), dim3(n_co * n_m), dim3(NT), lds, s, p, n_co, n_m);
+    if (p.relu_in)
+        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, true>), dim3(n_co * n_m), dim3(NT), lds, s, p, n_co, n_m);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false>), dim3(n_co * n_m), dim3(NT), lds, s, p, n_co, n_m);
 }
 
-template <int TCO, int TM, int NST>
+template <int TCO, int TM, int BK, int NST>
 void launch_cfg(const ConvParams& p, hipStream_t s)
 {
-    const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H &&
-                      p.OW == p.W && p.in_nb == p.NB);
-    if (vec) launch_one<TCO, TM, NST, MODE_VEC>(p, s);
-    else if (p.tap_major) launch_one<TCO, TM, NST, MODE_TAP>(p, s);
-    else launch_one<TCO, TM, NST, MODE_GEN>(p, s);
+    const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H && p.OW == p.W);
+    if (vec) launch_one<TCO, TM, BK, NST, MODE_VEC>(p, s);
+    else if (p.tap_major && (p.Cin % BK) == 0) launch_one<TCO, TM, BK, NST, MODE_TAP>(p, s);
+    else if (p.tap_major) launch_one<TCO, TM, 16, 4, MODE_TAP>(p, s);
+    else launch_one<TCO, TM, 16, 4, MODE_GEN>(p, s);
 }
 
 }  // namespace
 
+int conv_gemm_pick_cfg(const ConvParams& p)
+{
+    // Measured on MI355X over the ResNet-101 / ResNet-50 / Light-CNN GEMM shapes (M = 1.5k..400k, K = 64..4608,
+    // Cout = 64..2048): the 64x64 tile wins or ties everywhere -- these grids are small (1-12 workgroups per CU), so
+    // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.  Deep-K,
+    // small-M layers (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers per MFMA.
+    if (p.K >= 1024 && p.M <= 8192 && (p.tap_major ? (p.Cin % 32 == 0) : true) ) return 5;
+    return 4;
+}
+
 void launch_conv_gemm(const ConvParams& p, hipStream_t s)
 {
-    // Tile choice: biggest tile that still gives every CU >= 2 workgroups (256 CUs); otherwise shrink.
-    auto blocks = [&](int tco, int tm) { return (long)((p.CoutTot + tco - 1) / tco) * p.nhalves * ((p.M + tm - 1) / tm); };
-    const long want = 512;
-    if (p.CoutTot > 64 && blocks(128, 128) >= want) launch_cfg<128, 128, 3>(p, s);
-    else if (blocks(64, 128) >= want) launch_cfg<64, 128, 4>(p, s);
-    else if (p.CoutTot > 64 && blocks(128, 64) >= want) launch_cfg<128, 64, 4>(p, s);
-    else launch_cfg<64, 64, 4>(p, s);
+    const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
+    switch (cfg) {
+        case 1: launch_cfg<128, 128, 16, 3>(p, s); break;
+        case 2: launch_cfg<64, 128, 16, 4>(p, s); break;
+        case 3: launch_cfg<128, 64, 16, 4>(p, s); break;
+        case 4: launch_cfg<64, 64, 16, 4>(p, s); break;
+        case 5: launch_cfg<64, 64, 32, 3>(p, s); break;
+        case 6: launch_cfg<64, 128, 32, 3>(p, s); break;
+        case 7: launch_cfg<128, 64, 32, 3>(p, s); break;
+        default: launch_cfg<64, 64, 16, 4>(p, s); break;
+    }
 }

@@ -408,11 +408,11 @@ xfr_status layout_arena(xfr_engine* e)
             o.ldw = (int)align_up(d.cout, 128);
             o.tap_fwd = (d.kh * d.kw > 1) && (o.Cin % 16 == 0) && (d.kh * d.kw <= 64);
             o.tap_bwd = (d.kh * d.kw > 1) && (d.cout % 16 == 0) && (d.kh * d.kw <= 64);
-            o.w_true = take(align_up(o.K, 16) * o.ldw);
-            o.w_pos = take(align_up(o.K, 16) * o.ldw);
+            o.w_true = take(align_up(o.K, 32) * o.ldw);
+            o.w_pos = take(align_up(o.K, 32) * o.ldw);
             if (k != 0) {
                 o.ldb = (int)align_up(o.Cin, 128);
-                o.w_bwd = take(align_up(o.Kb, 16) * o.ldb);
+                o.w_bwd = take(align_up(o.Kb, 32) * o.ldb);
             }
             if (d.w_bias >= 0) { o.b_true = take(d.cout); o.b_pos = take(d.cout); }
         } else if (d.kind == XFR_OP_BATCHNORM) {
@@ -991,13 +991,13 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
 xfr_status xfr_engine_destroy(xfr_engine* e)
 {
     if (!e) return XFR_OK;
-    hipSetDevice(e->device);
-    if (e->ws) hipFree(e->ws);
-    if (e->idx_ws) hipFree(e->idx_ws);
-    if (e->arena) hipFree(e->arena);
-    if (e->dbl_ws) hipFree(e->dbl_ws);
-    if (e->trunc_ws) hipFree(e->trunc_ws);
-    for (auto& ev : e->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    (void)hipSetDevice(e->device);
+    if (e->ws) (void)hipFree(e->ws);
+    if (e->idx_ws) (void)hipFree(e->idx_ws);
+    if (e->arena) (void)hipFree(e->arena);
+    if (e->dbl_ws) (void)hipFree(e->dbl_ws);
+    if (e->trunc_ws) (void)hipFree(e->trunc_ws);
+    for (auto& ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete e;
     return XFR_OK;
 }
@@ -1205,6 +1205,57 @@ xfr_status xfr_engine_get_trace(xfr_engine* e, double* sums, int32_t* kinds, int
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(sums, e->dbl_ws + 2 * e->max_batch, sizeof(double) * (size_t)nf * SB, hipMemcpyDeviceToHost));
     if (kinds) for (int i = 0; i < nf; ++i) kinds[i] = e->last_trace_kinds[i];
+    return XFR_OK;
+}
+
+xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float* bias_host, float* out_dev, int32_t cin, int32_t h,
+                          int32_t w, int32_t nb, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t relu_in,
+                          int32_t cfg, int32_t reps, float* ms_out)
+{
+    if (!in_dev || !w_host || !out_dev || cin < 1 || cout < 1 || kh < 1 || kw < 1 || stride < 1 || reps < 1)
+        return fail(XFR_INVALID_ARG, "xfr_debug_conv: bad arguments");
+    const int khw = kh * kw, K = cin * khw;
+    const int ldw = (int)align_up(cout, 128);
+    const bool tap = khw > 1 && (cin % 16 == 0) && khw <= 64;
+    std::vector<float> host(align_up(K, 32) * (size_t)ldw, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int tp = 0; tp < khw; ++tp) {
+                const size_t kk = tap ? (size_t)tp * cin + ci : (size_t)ci * khw + tp;
+                host[kk * ldw + co] = w_host[((size_t)co * cin + ci) * khw + tp];
+            }
+    float *wd = nullptr, *bd = nullptr;
+    HIP_TRY(hipMalloc(&wd, host.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(wd, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (bias_host) {
+        HIP_TRY(hipMalloc(&bd, cout * sizeof(float)));
+        HIP_TRY(hipMemcpy(bd, bias_host, cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = in_dev; p.w = wd; p.bias = bd; p.out0 = out_dev;
+    p.Cin = cin; p.H = h; p.W = w; p.NB = nb; p.in_nb = nb; p.out_nb = nb;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
+    p.OH = (h + 2 * pad - kh) / stride + 1; p.OW = (w + 2 * pad - kw) / stride + 1;
+    p.K = K; p.M = nb * p.OH * p.OW; p.CoutTot = cout; p.nhalves = 1; p.ldw = ldw;
+    p.relu_in = relu_in; p.out_H = p.OH; p.out_W = p.OW; p.out_stride = 1;
+    p.in_bytes = (unsigned)((size_t)cin * nb * h * w * sizeof(float));
+    p.tap_major = tap ? 1 : 0; p.force_cfg = cfg;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    launch_conv_gemm(p, 0);
+    HIP_TRY(hipEventRecord(a, 0));
+    for (int r = 0; r < reps; ++r) launch_conv_gemm(p, 0);
+    HIP_TRY(hipEventRecord(b, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    if (ms_out) *ms_out = ms / reps;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(wd);
+    if (bd) (void)hipFree(bd);
+    HIP_TRY(hipGetLastError());
     return XFR_OK;
 }
 

@@ -218,7 +218,7 @@ void launch_channel_pool(const float* P, float* pooled, int C, int SB, int HW, h
 
 void launch_sample_sums(const float* P, double* sums, int C, int SB, int HW, hipStream_t s)
 {
-    hipMemsetAsync(sums, 0, sizeof(double) * SB, s);
+    (void)hipMemsetAsync(sums, 0, sizeof(double) * SB, s);
     long chunks = ((long)C * HW + NT * 8 - 1) / (NT * 8);
     if (chunks > 512) chunks = 512;
     if (chunks < 1) chunks = 1;
