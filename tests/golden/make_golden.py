@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Generate the golden vectors by running the REAL reference (/root/reference, imported through ref_import.py).
+
+Run in the build container only (the reference does not travel):   python tests/golden/make_golden.py
+Outputs (committed):  tests/golden/*.npz  -- inputs that cannot be regenerated from a seed (the 4 bundled JPEGs of
+demo/test_whitebox.py, pre-resized to 224x224 uint8) and the reference's outputs for every case:
+    map     final saliency map as returned by the reference call
+    pooled  channel-pooled P[-2] of the LAST ebp sweep the call made (whitebox.py:499)
+    trace   sum(P[i]) for every entry of Whitebox.P of that sweep, reference firing order (float64)
+    names   class name of the module of every firing (P_layername with the argument list stripped)
+Weights are NOT stored: they are regenerated from (arch, seed, recipe) by xfr_amd.synth; `wsum` is their checksum.
+
+Where the demo (demo/test_whitebox.py) runs a face detector + crop before preprocess, the fixtures use the
+whole image resized to the network input (the detector's weights are LFS pointers and it is outside the hot path).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import PIL.Image
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+from parity_utils import R50_MEAN, make_backbone, make_images  # noqa: E402
+from xfr_amd import synth  # noqa: E402
+from xfr_amd.models import resnet as xresnet  # noqa: E402
+
+ns = ref_import.load()
+REF = ref_import.REF_ROOT
+torch.set_num_threads(8)
+
+JPEGS = ['demo_face.jpg', 'n00000001_00000117.JPEG', 'n00000002_00000100.JPEG', 'n00000001_00000384.JPEG']
+
+
+def load_jpegs():
+    out = {}
+    for f in JPEGS:
+        im = PIL.Image.open(os.path.join(REF, 'data', f)).convert('RGB').resize((224, 224))
+        out[f] = np.array(im, dtype=np.uint8)
+    return out
+
+
+def ref_net(arch, sd, num_classes):
+    if arch == 'stresnet101':
+        net = ns.resnet.ResNet(ns.resnet.Bottleneck, [3, 4, 23, 3], mode='encode', num_classes=num_classes)
+        net.load_state_dict(sd, strict=True)
+        return ns.whitebox.WhiteboxSTResnet(net)
+    if arch == 'stresnet_mini':
+        net = ns.resnet.ResNet(ns.resnet.Bottleneck, [1, 1, 1, 1], mode='encode', num_classes=num_classes)
+        net.load_state_dict(sd, strict=True)
+        return ns.whitebox.WhiteboxSTResnet(net)
+    if arch == 'resnet50_128':
+        net = ns.resnet50_128.resnet50_128()
+        net.load_state_dict(sd, strict=True)
+        return ns.whitebox.Whitebox_resnet50_128(net)
+    if arch == 'lightcnn29v2':
+        net = ns.lightcnn.LightCNN_29Layers_v2(num_classes=num_classes)
+        net.load_state_dict(sd, strict=True)
+        return ns.whitebox.WhiteboxLightCNN(net)
+    raise ValueError(arch)
+
+
+def record(wb, result):
+    P = [p.detach() for p in wb.P]
+    names = [n.split('(')[0] for n in wb.P_layername]
+    assert all(torch.isfinite(p).all() for p in P), 'non-finite P in the reference output'
+    assert np.isfinite(result).all()
+    return {
+        'map': np.asarray(result, dtype=np.float32),
+        'pooled': np.squeeze(np.sum(P[-2].numpy(), axis=1)).astype(np.float32),
+        'trace': np.array([float(p.double().sum()) for p in P], dtype=np.float64),
+        'names': np.array(names),
+    }
+
+
+def run_case(out, key, wb, call):
+    t = time.time()
+    res = call(wb)
+    rec = record(wb, res)
+    for k, v in rec.items():
+        out['%s/%s' % (key, k)] = v
+    print('  %-60s %.1fs  sum=%.6f' % (key, time.time() - t, float(np.sum(res))))
+    wb._ebp_mode = 'disable'
+
+
+def main():
+    jpegs = load_jpegs()
+    np.savez_compressed(os.path.join(HERE, 'inputs_jpeg.npz'), **{k.replace('.', '_'): v for k, v in jpegs.items()})
+
+    # ---- A: mini STR-ResNet, every mode, both recipes, hooked and triplet classifier -----------------------
+    out = {}
+    for recipe in ('mild', 'harsh'):
+        bb, sd = make_backbone('stresnet_mini', seed=3, recipe=recipe, num_classes=5)
+        out['mini/%s/wsum' % recipe] = np.array(synth.state_checksum(sd))
+        x = make_images('stresnet_mini', 1, seed=5)
+        for mode in ('affineonly_with_prior', 'norelu', 'all', 'affineonly'):
+            wbn = ref_net('stresnet_mini', sd, 5)
+            wb = ns.whitebox.Whitebox(wbn, ebp_subtree_mode=mode)
+            Pn = torch.zeros(1, 5)
+            Pn[0, 2] = 1
+            run_case(out, 'mini/%s/%s/hooked/ebp' % (recipe, mode), wb, lambda w: w.ebp(x, Pn, mwp=True))
+            xm = synth.unit_rows(1, 512, seed=1) / 2500
+            xn = synth.unit_rows(1, 512, seed=2) / 2500
+            wbn.set_triplet_classifier(xm, xn)
+            P2 = torch.zeros(1, 2)
+            P2[0, 1] = 1
+            run_case(out, 'mini/%s/%s/triplet/ebp' % (recipe, mode), wb, lambda w: w.ebp(x, P2, mwp=True))
+            if recipe == 'mild':
+                run_case(out, 'mini/%s/%s/triplet/contrastive' % (recipe, mode), wb, lambda w: w.contrastive_ebp(x, 0, 1))
+                run_case(out, 'mini/%s/%s/triplet/truncated' % (recipe, mode), wb,
+                         lambda w: w.truncated_contrastive_ebp(x, 0, 1, 20))
+    np.savez_compressed(os.path.join(HERE, 'golden_mini.npz'), **out)
+
+    # ---- B: ResNet-101, the demo call sequences (demo/test_whitebox.py:77-144) + the bench configuration --------
+    out = {}
+    NC = 65359
+    bb, sd = make_backbone('stresnet101', seed=0, recipe='mild', num_classes=NC)
+    out['r101/wsum'] = np.array(synth.state_checksum(sd))
+    conv = lambda a: xresnet.convert_resnet101v4_image(a).unsqueeze(0)   # noqa: E731
+    x_demo = conv(jpegs['demo_face.jpg'])
+    x_probe, x_non, x_mate = (conv(jpegs[JPEGS[1]]), conv(jpegs[JPEGS[2]]), conv(jpegs[JPEGS[3]]))
+    for mode in ('affineonly_with_prior', 'norelu'):
+        wbn = ref_net('stresnet101', sd, NC)
+        wb = ns.whitebox.Whitebox(wbn, ebp_subtree_mode=mode)
+        P = torch.zeros((1, NC))
+        P[0][0] = 1.0
+        if mode == 'affineonly_with_prior':
+            run_case(out, 'r101/%s/hooked/ebp' % mode, wb, lambda w: w.ebp(x_demo, P))                       # :77-92
+            run_case(out, 'r101/%s/hooked/contrastive' % mode, wb, lambda w: w.contrastive_ebp(x_demo, 0, 100))  # :94-101
+            run_case(out, 'r101/%s/hooked/truncated' % mode, wb,
+                     lambda w: w.truncated_contrastive_ebp(x_demo, 0, 100, 20))                               # :103-110
+        e_mate = wbn.encode(x_mate).detach()
+        e_non = wbn.encode(x_non).detach()
+        out['r101/%s/enc_mate' % mode] = e_mate.numpy()
+        out['r101/%s/enc_nonmate' % mode] = e_non.numpy()
+        wbn.set_triplet_classifier((1.0 / 2500.0) * e_mate, (1.0 / 2500.0) * e_non)                           # :129
+        P2 = torch.zeros((1, 2))
+        P2[0][0] = 1.0
+        run_case(out, 'r101/%s/triplet/ebp' % mode, wb, lambda w: w.ebp(x_probe, P2))                        # :112-122
+        run_case(out, 'r101/%s/triplet/contrastive' % mode, wb, lambda w: w.contrastive_ebp(x_probe, 0, 1))  # :124-133
+        run_case(out, 'r101/%s/triplet/truncated' % mode, wb,
+                 lambda w: w.truncated_contrastive_ebp(x_probe, 0, 1, 20))                                    # :135-144
+        # bench-style synthetic triplet (uniform-noise images, seed 1234)
+        imgs = synth.synth_images(3, (3, 224, 224), seed=1234, mean=xresnet.MEAN_RGB)
+        em = wbn.encode(imgs[0:1]).detach()
+        en = wbn.encode(imgs[1:2]).detach()
+        wbn.set_triplet_classifier(em / 2500.0, en / 2500.0)
+        run_case(out, 'r101/%s/synthetic/contrastive' % mode, wb, lambda w: w.contrastive_ebp(imgs[2:3], 0, 1))
+    np.savez_compressed(os.path.join(HERE, 'golden_r101.npz'), **out)
+
+    # ---- C: VGGFace2 ResNet-50-128d ----------------------------------------------------------------------------
+    out = {}
+    bb, sd = make_backbone('resnet50_128', seed=0, recipe='mild')
+    out['r50/wsum'] = np.array(synth.state_checksum(sd))
+    to_r50 = lambda a: torch.from_numpy((a.astype(np.float64) - np.array(R50_MEAN)).transpose(2, 0, 1).astype(np.float32)).unsqueeze(0)  # noqa: E731
+    x_demo = to_r50(jpegs['demo_face.jpg'])
+    x_probe, x_non, x_mate = (to_r50(jpegs[JPEGS[1]]), to_r50(jpegs[JPEGS[2]]), to_r50(jpegs[JPEGS[3]]))
+    for mode in ('affineonly_with_prior', 'norelu'):
+        wbn = ref_net('resnet50_128', sd, None)
+        wb = ns.whitebox.Whitebox(wbn, ebp_subtree_mode=mode)
+        e_mate = wbn.encode(x_mate).detach()
+        e_non = wbn.encode(x_non).detach()
+        out['r50/%s/enc_mate' % mode] = e_mate.numpy()
+        wbn.set_triplet_classifier(e_mate / 2500.0, e_non / 2500.0)
+        P2 = torch.zeros((1, 2))
+        P2[0][0] = 1.0
+        run_case(out, 'r50/%s/triplet/ebp' % mode, wb, lambda w: w.ebp(x_demo, P2, mwp=False))               # :240-254
+        run_case(out, 'r50/%s/triplet/contrastive' % mode, wb, lambda w: w.contrastive_ebp(x_probe, 0, 1))
+        run_case(out, 'r50/%s/triplet/truncated' % mode, wb, lambda w: w.truncated_contrastive_ebp(x_probe, 0, 1, 20))
+    np.savez_compressed(os.path.join(HERE, 'golden_r50.npz'), **out)
+
+    # ---- D: Light-CNN-29 v2 ------------------------------------------------------------------------------------
+    out = {}
+    NCL = 80013
+    bb, sd = make_backbone('lightcnn29v2', seed=0, recipe='mild', num_classes=NCL)
+    out['lcnn/wsum'] = np.array(synth.state_checksum(sd))
+
+    def to_lcnn(a):
+        im = PIL.Image.fromarray(a).resize((128, 128), PIL.Image.BILINEAR)
+        return ns.lightcnn.prepare_lightCNN_image(im)
+    x_demo = to_lcnn(jpegs['demo_face.jpg'])
+    x_probe, x_non, x_mate = (to_lcnn(jpegs[JPEGS[1]]), to_lcnn(jpegs[JPEGS[2]]), to_lcnn(jpegs[JPEGS[3]]))
+    out['lcnn/x_demo'] = x_demo.numpy()
+    out['lcnn/x_probe'] = x_probe.numpy()
+    out['lcnn/x_non'] = x_non.numpy()
+    out['lcnn/x_mate'] = x_mate.numpy()
+    for mode in ('affineonly', 'affineonly_with_prior', 'all'):
+        wbn = ref_net('lightcnn29v2', sd, NCL)
+        wb = ns.whitebox.Whitebox(wbn, ebp_subtree_mode=mode)
+        P = torch.zeros((1, NCL))
+        P[0][0] = 1.0
+        run_case(out, 'lcnn/%s/hooked/ebp' % mode, wb, lambda w: w.ebp(x_demo, P, mwp=False))                 # :202-217
+        if mode != 'affineonly':
+            e_mate = wbn.encode(x_mate).detach()
+            e_non = wbn.encode(x_non).detach()
+            out['lcnn/%s/enc_mate' % mode] = e_mate.numpy()
+            wbn.set_triplet_classifier(e_mate / 2500.0, e_non / 2500.0)
+            run_case(out, 'lcnn/%s/triplet/contrastive' % mode, wb, lambda w: w.contrastive_ebp(x_probe, 0, 1))
+            run_case(out, 'lcnn/%s/triplet/truncated' % mode, wb,
+                     lambda w: w.truncated_contrastive_ebp(x_probe, 0, 1, 20))
+    np.savez_compressed(os.path.join(HERE, 'golden_lcnn.npz'), **out)
+
+    # ---- E: structure pins: state_dict keys/shapes of the reference modules, hooked call counts ------------------
+    out = {}
+    for arch, nc in (('stresnet101', 65359), ('resnet50_128', None), ('lightcnn29v2', 80013)):
+        bb, sd = make_backbone(arch, seed=0, num_classes=nc)
+        wbn = ref_net(arch, sd, nc)
+        rsd = wbn.net.state_dict()
+        out['%s/keys' % arch] = np.array(list(rsd.keys()))
+        out['%s/shapes' % arch] = np.array([','.join(str(s) for s in v.shape) for v in rsd.values()])
+    np.savez_compressed(os.path.join(HERE, 'golden_structure.npz'), **out)
+    print('done')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,180 @@
+"""The golden cases of tests/golden/make_golden.py, replayable against any subject exposing the Whitebox surface
+(the CPU oracle, or the HIP engine behind xfr_amd.models.whitebox)."""
+import os
+
+import numpy as np
+import PIL.Image
+import torch
+
+from parity_utils import R50_MEAN, make_backbone, make_images
+from xfr_amd import synth
+from xfr_amd.models import lightcnn as xlightcnn
+from xfr_amd.models import resnet as xresnet
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+JPEGS = ['demo_face.jpg', 'n00000001_00000117.JPEG', 'n00000002_00000100.JPEG', 'n00000001_00000384.JPEG']
+
+_cache = {}
+
+
+def golden(name):
+    if name not in _cache:
+        _cache[name] = np.load(os.path.join(GOLDEN_DIR, name + '.npz'), allow_pickle=False)
+    return _cache[name]
+
+
+def jpegs():
+    g = golden('inputs_jpeg')
+    return {f: g[f.replace('.', '_')] for f in JPEGS}
+
+
+def net_inputs(arch):
+    """(x_demo, x_probe, x_nonmate, x_mate) exactly as make_golden.py built them."""
+    j = jpegs()
+    if arch in ('stresnet101',):
+        conv = lambda a: xresnet.convert_resnet101v4_image(a).unsqueeze(0)   # noqa: E731
+    elif arch == 'resnet50_128':
+        conv = lambda a: torch.from_numpy((a.astype(np.float64) - np.array(R50_MEAN)).transpose(2, 0, 1).astype(np.float32)).unsqueeze(0)  # noqa: E731
+    else:
+        def conv(a):
+            im = PIL.Image.fromarray(a).resize((128, 128), PIL.Image.BILINEAR)
+            return xlightcnn.prepare_lightCNN_image(im)
+    return tuple(conv(j[f]) for f in JPEGS)
+
+
+class Subject(object):
+    """Uniform handle: `wb` has ebp / contrastive_ebp / truncated_contrastive_ebp; `enc` encodes; `set_cls` installs the
+    triplet classifier; `trace()` returns (sums, names) of the last ebp sweep or None."""
+
+    def __init__(self, wb, enc, set_cls, trace=None, to_dev=None):
+        self.wb, self.enc, self.set_cls, self._trace, self.to_dev = wb, enc, set_cls, trace, (to_dev or (lambda t: t))
+
+    def trace(self):
+        return self._trace() if self._trace else None
+
+
+def oracle_subject(arch, sd, mode, num_classes=None):
+    from oracle import ebp_oracle as O
+    ow = O.OracleWhitebox(arch, sd, ('hooked', None), mode)
+
+    def trace():
+        return (np.array([float(p.double().sum()) for p in ow.P]), list(ow.P_layername))
+    return Subject(ow, ow.encode, ow.set_triplet_classifier, trace)
+
+
+def engine_subject(arch, bb, mode, device='cuda:0'):
+    from xfr_amd.models import whitebox as WB
+    bb.to(device)
+    if arch == 'resnet50_128':
+        wbn = WB.Whitebox_resnet50_128(bb)
+    elif arch == 'lightcnn29v2':
+        wbn = WB.WhiteboxLightCNN(bb)
+    else:
+        wbn = WB.WhiteboxSTResnet(bb)
+    wb = WB.Whitebox(wbn, ebp_subtree_mode=mode)
+    wb.debug_trace = True
+
+    def trace():
+        if not getattr(wb, 'P_layername', None):
+            return None
+        return (np.asarray(wb.P_trace)[:, 0], list(wb.P_layername))
+    return Subject(wb, wbn.encode, wbn.set_triplet_classifier, trace)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# case tables: key -> function(subject, ctx) -> result map.  ctx carries inputs.
+# --------------------------------------------------------------------------------------------------------------
+def mini_cases(recipe, mode):
+    x = make_images('stresnet_mini', 1, seed=5)
+    xm = synth.unit_rows(1, 512, seed=1) / 2500
+    xn = synth.unit_rows(1, 512, seed=2) / 2500
+    Pn = torch.zeros(1, 5)
+    Pn[0, 2] = 1
+    P2 = torch.zeros(1, 2)
+    P2[0, 1] = 1
+    pre = 'mini/%s/%s/' % (recipe, mode)
+    cases = [(pre + 'hooked/ebp', lambda s: s.wb.ebp(x, Pn, mwp=True)),
+             ('__set__', lambda s: s.set_cls(xm, xn)),
+             (pre + 'triplet/ebp', lambda s: s.wb.ebp(x, P2, mwp=True))]
+    if recipe == 'mild':
+        cases += [(pre + 'triplet/contrastive', lambda s: s.wb.contrastive_ebp(x, 0, 1)),
+                  (pre + 'triplet/truncated', lambda s: s.wb.truncated_contrastive_ebp(x, 0, 1, 20))]
+    return cases
+
+
+def r101_cases(mode, which=None):
+    x_demo, x_probe, x_non, x_mate = net_inputs('stresnet101')
+    NC = 65359
+    P = torch.zeros((1, NC))
+    P[0][0] = 1.0
+    P2 = torch.zeros((1, 2))
+    P2[0][0] = 1.0
+    pre = 'r101/%s/' % mode
+    cases = []
+    if mode == 'affineonly_with_prior':
+        cases += [(pre + 'hooked/ebp', lambda s: s.wb.ebp(x_demo, P)),
+                  (pre + 'hooked/contrastive', lambda s: s.wb.contrastive_ebp(x_demo, 0, 100)),
+                  (pre + 'hooked/truncated', lambda s: s.wb.truncated_contrastive_ebp(x_demo, 0, 100, 20))]
+
+    def set_real(s):   # demo/test_whitebox.py:129 multiplies by the reciprocal
+        s.set_cls((1.0 / 2500.0) * s.enc(x_mate).detach().cpu(), (1.0 / 2500.0) * s.enc(x_non).detach().cpu())
+    imgs = synth.synth_images(3, (3, 224, 224), seed=1234, mean=xresnet.MEAN_RGB)
+
+    def set_synth(s):
+        s.set_cls(s.enc(imgs[0:1]).detach().cpu() / 2500.0, s.enc(imgs[1:2]).detach().cpu() / 2500.0)
+    cases += [('__set__', set_real),
+              (pre + 'triplet/ebp', lambda s: s.wb.ebp(x_probe, P2)),
+              (pre + 'triplet/contrastive', lambda s: s.wb.contrastive_ebp(x_probe, 0, 1)),
+              (pre + 'triplet/truncated', lambda s: s.wb.truncated_contrastive_ebp(x_probe, 0, 1, 20)),
+              ('__set__', set_synth),
+              (pre + 'synthetic/contrastive', lambda s: s.wb.contrastive_ebp(imgs[2:3], 0, 1))]
+    return _filter(cases, which)
+
+
+def r50_cases(mode, which=None):
+    x_demo, x_probe, x_non, x_mate = net_inputs('resnet50_128')
+    P2 = torch.zeros((1, 2))
+    P2[0][0] = 1.0
+    pre = 'r50/%s/' % mode
+
+    def set_real(s):
+        s.set_cls(s.enc(x_mate).detach().cpu() / 2500.0, s.enc(x_non).detach().cpu() / 2500.0)
+    cases = [('__set__', set_real),
+             (pre + 'triplet/ebp', lambda s: s.wb.ebp(x_demo, P2, mwp=False)),
+             (pre + 'triplet/contrastive', lambda s: s.wb.contrastive_ebp(x_probe, 0, 1)),
+             (pre + 'triplet/truncated', lambda s: s.wb.truncated_contrastive_ebp(x_probe, 0, 1, 20))]
+    return _filter(cases, which)
+
+
+def lcnn_cases(mode, which=None):
+    g = golden('golden_lcnn')
+    x_demo, x_probe, x_non, x_mate = (torch.from_numpy(g['lcnn/' + k]) for k in ('x_demo', 'x_probe', 'x_non', 'x_mate'))
+    NCL = 80013
+    P = torch.zeros((1, NCL))
+    P[0][0] = 1.0
+    pre = 'lcnn/%s/' % mode
+
+    def set_real(s):
+        s.set_cls(s.enc(x_mate).detach().cpu() / 2500.0, s.enc(x_non).detach().cpu() / 2500.0)
+    cases = [(pre + 'hooked/ebp', lambda s: s.wb.ebp(x_demo, P, mwp=False))]
+    if mode != 'affineonly':
+        cases += [('__set__', set_real),
+                  (pre + 'triplet/contrastive', lambda s: s.wb.contrastive_ebp(x_probe, 0, 1)),
+                  (pre + 'triplet/truncated', lambda s: s.wb.truncated_contrastive_ebp(x_probe, 0, 1, 20))]
+    return _filter(cases, which)
+
+
+def _filter(cases, which):
+    if which is None:
+        return cases
+    return [c for c in cases if c[0] == '__set__' or any(c[0].endswith(w) for w in which)]
+
+
+def replay(subject, cases, gold, check):
+    """Run `cases` in order on `subject`; for every non-setup case call check(key, result, trace, gold)."""
+    for key, fn in cases:
+        if key == '__set__':
+            fn(subject)
+            continue
+        res = fn(subject)
+        check(key, res, subject.trace(), gold)

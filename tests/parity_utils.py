@@ -1,8 +1,16 @@
 """Shared helpers of the parity tests: seeded backbones, the oracle twin, and the comparison metrics.
 
-Tolerance (stated once, used everywhere): the reference's own fp32-vs-fp64 self-consistency on these maps is
+Tolerance (stated once, used everywhere).  The reference's own fp32-vs-fp64 self-consistency on these maps is
 max|d|/max ~ 1e-4, so a GPU map is accepted when
-    max|gpu - oracle| / max|oracle| <= 1e-3   and   cosine(gpu, oracle) >= 0.99999.
+    max|gpu - ref| / max|ref| <= 1e-3   and   cosine(gpu, ref) >= 0.99999                    (assert_map_close)
+Two steps of the reference algorithm are DISCONTINUOUS in the activations and flip on last-bit differences between
+any two fp32 implementations (MKLDNN vs MFMA summation order), moving a whole gradient element:
+  * max-pool argmax near-ties (two window elements equal to ~1e-7 relative: ~10 windows per 64x112x112 image),
+  * the percentile mask of truncated_contrastive_ebp (elements within rounding of the cut value).
+Each flip perturbs a handful of pixels by up to a few percent of the map maximum and nothing else.  Where a case is
+exposed to this, the criterion is the robust one (assert_map_close_robust): cosine >= 0.99999, at most 0.2 % of the
+pixels off by more than 1e-3 of the maximum, none by more than 5e-2; the per-firing P sums (which flips preserve) are
+always held to 1e-4 relative.
 """
 import numpy as np
 import torch
@@ -59,3 +67,27 @@ def assert_map_close(got, want, what=''):
     assert rel <= MAP_RTOL and cos >= MAP_COS, '%s: max|d|/max = %.3e (tol %.0e), cosine = %.8f (tol %.5f)' % (
         what, rel, MAP_RTOL, cos, MAP_COS)
     return rel, cos
+
+
+def assert_map_close_robust(got, want, what='', frac=2e-3, cap=5e-2):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert np.isfinite(got).all(), 'non-finite values in %s' % what
+    mx = max(np.abs(want).max(), 1e-300)
+    d = np.abs(got - want) / mx
+    rel, cos = map_metrics(got, want)
+    bad = float((d > MAP_RTOL).mean())
+    assert cos >= MAP_COS and bad <= frac and d.max() <= cap, \
+        '%s: cosine %.8f, %.3f %% pixels beyond %.0e, max|d|/max %.3e' % (what, cos, 100 * bad, MAP_RTOL, d.max())
+    return rel, cos
+
+
+def assert_trace_close(sums, names, gsum, gnames, what='', rtol=1e-4):
+    """Per-firing sum(P[i]) against the reference list (which additionally holds the image hook P[-1] the engine does
+    not compute)."""
+    n = len(sums)
+    assert n in (len(gsum), len(gsum) - 1), '%s: %d firings vs %d in the reference' % (what, n, len(gsum))
+    assert list(names) == [str(x) for x in gnames[:n]], '%s: firing order differs' % what
+    err = np.abs(np.asarray(sums) - gsum[:n]) / np.maximum(np.abs(gsum[:n]), 1e-300)
+    i = int(err.argmax())
+    assert err.max() <= rtol, '%s: P-sum rel err %.3e at firing %d (%s)' % (what, err.max(), i, names[i])

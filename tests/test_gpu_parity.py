@@ -1,0 +1,214 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI (ctypes -> libxfr_amd.so);
+the HIP engine is compared with the golden vectors captured from the real reference and with the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as GC
+from parity_utils import (assert_map_close, assert_map_close_robust, assert_trace_close, emb_dim, make_backbone,
+                          make_images, map_metrics)
+from xfr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_factory(robust_pooled=False):
+    def check(key, res, trace, gold):
+        want = gold[key + '/map']
+        # final maps of *truncated* calls and P[-2]-level maps ride on discontinuous steps (see parity_utils docstring)
+        if key.endswith('truncated') or robust_pooled:
+            assert_map_close_robust(res, want, key)
+        else:
+            assert_map_close(res, want, key)
+        if trace is not None and key.endswith('/ebp'):
+            sums, names = trace
+            assert_trace_close(sums, names, gold[key + '/trace'], gold[key + '/names'], key)
+    return check
+
+
+# ---- kernel-level ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [
+    # cin, h, w, nb, cout, k, stride, pad
+    (3, 32, 32, 3, 64, 7, 2, 3),       # stem-like: generic (ci,kh,kw) gather, K tail (147)
+    (1, 20, 20, 2, 96, 5, 1, 2),       # Light-CNN conv1
+    (64, 14, 14, 5, 64, 3, 1, 1),      # tap-major 3x3, ragged M (980)
+    (48, 9, 9, 3, 96, 3, 1, 1),        # Cin % 32 != 0
+    (256, 7, 7, 2, 130, 1, 1, 0),      # 1x1 float4 path needs M % 4 == 0: M = 98 -> dword path; ragged Cout
+    (128, 8, 8, 4, 256, 1, 1, 0),      # 1x1 vector path
+    (64, 16, 16, 2, 32, 1, 2, 0),      # strided 1x1
+    (128, 8, 8, 2, 40, 8, 1, 0),       # Linear on a flattened 8x8 map (64 taps)
+])
+@pytest.mark.parametrize('cfg', [0, 1, 4, 5])
+def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
+    """The MFMA implicit-GEMM kernel against plain PyTorch fp32 conv2d on the CPU."""
+    from xfr_amd import _lib
+    lib = _lib.load()
+    cin, h, w, nb, cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((nb, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn((cout,), generator=g)
+    want = torch.nn.functional.conv2d(x, wt, b, stride=stride, padding=pad)
+    xg = x.to(gpu_device).permute(1, 0, 2, 3).contiguous()
+    out = torch.full((cout, nb) + tuple(want.shape[2:]), float('nan'), device=gpu_device)
+    ms = ctypes.c_float()
+    _lib.check(lib.xfr_debug_conv(xg.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), cin, h, w, nb, cout, k, k,
+                                  stride, pad, 0, cfg, 1, ctypes.byref(ms)))
+    got = out.permute(1, 0, 2, 3).cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_saliency_blur_matches_scipy(gpu_device):
+    from oracle.ebp_oracle import mwp_to_saliency
+    from xfr_amd.models import whitebox as WB
+    bb, _ = make_backbone('stresnet_mini')
+    wb = WB.Whitebox(WB.WhiteboxSTResnet(bb.to(gpu_device)))
+    rng = np.random.RandomState(1)
+    for shape in ((112, 112), (128, 128), (17, 9)):
+        P = (rng.rand(*shape) ** 4).astype(np.float32)
+        got = wb._mwp_to_saliency(P)
+        want = mwp_to_saliency(P)
+        assert got.dtype == np.float32 and abs(float(got.sum()) - 1.0) < 1e-5
+        assert np.abs(got - want).max() <= 2e-7 * want.max()
+    z = wb._mwp_to_saliency(np.zeros((112, 112), np.float32))     # max(sum, eps) guard: whitebox.py:459
+    assert np.all(z == 0)
+
+
+# ---- golden vectors from the real reference -------------------------------------------------------------------------
+@pytest.mark.parametrize('recipe', ['mild', 'harsh'])
+@pytest.mark.parametrize('mode', ['affineonly_with_prior', 'norelu', 'all', 'affineonly'])
+def test_mini_resnet_golden(gpu_device, recipe, mode):
+    gold = GC.golden('golden_mini')
+    bb, sd = make_backbone('stresnet_mini', seed=3, recipe=recipe, num_classes=5)
+    assert synth.state_checksum(sd) == str(gold['mini/%s/wsum' % recipe])
+    GC.replay(GC.engine_subject('stresnet_mini', bb, mode), GC.mini_cases(recipe, mode), gold, _check_factory(True))
+
+
+@pytest.mark.parametrize('mode', ['affineonly_with_prior', 'norelu'])
+def test_resnet101_demo_sequences_golden(gpu_device, mode):
+    """demo/test_whitebox.py:77-144 call sequences on the bundled JPEGs, seeded weights."""
+    gold = GC.golden('golden_r101')
+    bb, sd = make_backbone('stresnet101', seed=0, num_classes=65359)
+    assert synth.state_checksum(sd) == str(gold['r101/wsum'])
+    subj = GC.engine_subject('stresnet101', bb, mode)
+    x_demo, x_probe, x_non, x_mate = GC.net_inputs('stresnet101')
+    enc = subj.enc(x_mate).cpu().numpy()
+    assert np.abs(enc - gold['r101/%s/enc_mate' % mode]).max() <= 1e-4 * np.abs(enc).max()
+    GC.replay(subj, GC.r101_cases(mode), gold, _check_factory())
+
+
+@pytest.mark.parametrize('mode', ['affineonly_with_prior', 'norelu'])
+def test_resnet50_128_golden(gpu_device, mode):
+    gold = GC.golden('golden_r50')
+    bb, sd = make_backbone('resnet50_128', seed=0)
+    assert synth.state_checksum(sd) == str(gold['r50/wsum'])
+    GC.replay(GC.engine_subject('resnet50_128', bb, mode), GC.r50_cases(mode), gold, _check_factory(True))
+
+
+@pytest.mark.parametrize('mode', ['affineonly', 'affineonly_with_prior', 'all'])
+def test_lightcnn_golden(gpu_device, mode):
+    gold = GC.golden('golden_lcnn')
+    bb, sd = make_backbone('lightcnn29v2', seed=0, num_classes=80013)
+    assert synth.state_checksum(sd) == str(gold['lcnn/wsum'])
+    GC.replay(GC.engine_subject('lightcnn29v2', bb, mode), GC.lcnn_cases(mode), gold, _check_factory(True))
+
+
+# ---- oracle on fresh seeded inputs, batched ----------------------------------------------------------------------------
+@pytest.mark.parametrize('arch,mode', [('stresnet_mini', 'affineonly_with_prior'), ('stresnet_mini', 'norelu'),
+                                       ('lightcnn29v2', 'affineonly_with_prior'), ('resnet50_128', 'norelu')])
+def test_batched_engine_equals_per_sample_oracle(gpu_device, arch, mode):
+    """The reference is batch-1 for contrastive EBP (whitebox.py:512,524); the batched engine must equal it per sample."""
+    from oracle import ebp_oracle as O
+    from xfr_amd.models import whitebox as WB
+    n = 3
+    bb, sd = make_backbone(arch, seed=21, num_classes=None if arch == 'resnet50_128' else 9)
+    x = make_images(arch, n, seed=77, smooth=False)
+    D = emb_dim(arch)
+    xm = synth.unit_rows(n, D, seed=3) / 2500
+    xn = synth.unit_rows(n, D, seed=4) / 2500
+    subj = GC.engine_subject(arch, bb, mode)
+    # classifier rows are needed for the marks/engine to exist
+    subj.set_cls(xm[:1], xn[:1])
+    sal = subj.wb.contrastive_triplet_ebp_batch(x, xm, xn).cpu().numpy()
+    assert sal.shape[0] == n
+    for i in range(n):
+        ow = O.OracleWhitebox(arch, sd, ('hooked', None), mode)
+        ow.set_triplet_classifier(xm[i:i + 1], xn[i:i + 1])
+        want = ow.contrastive_ebp(x[i:i + 1], 0, 1)
+        assert_map_close_robust(sal[i], want, '%s %s sample %d' % (arch, mode, i))
+        assert abs(float(sal[i].sum()) - 1.0) < 1e-4
+
+
+def test_truncation_tail_equals_reference_formula_on_engine_P(gpu_device):
+    """whitebox.py:547-558 (sort, cumsum, percentile mask) applied on the CPU to the engine's own P[-2] must give the
+    engine's truncated map: isolates the radix-select tail from the (discontinuous) dependence on P."""
+    import torch.nn.functional as F
+    from oracle.ebp_oracle import mwp_to_saliency
+    bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=7)
+    x = make_images('stresnet_mini', 2)
+    subj = GC.engine_subject('stresnet_mini', bb, 'norelu')
+    subj.set_cls(synth.unit_rows(1, 512, seed=1) / 2500, synth.unit_rows(1, 512, seed=2) / 2500)
+    wb = subj.wb
+    eng = wb._engine(2)
+    st, seeds = wb._class_seeds(2, 0, 1)
+    mwp, _ = eng.ebp(x, st, seeds, want_mwp=True)
+    mwp = mwp.cpu()
+    for pct in (20.0, 50.0, 0.0):
+        sal = eng.contrastive(x, st, seeds, pct).cpu().numpy()
+        for i in range(2):
+            m = mwp[0, i:i + 1] / torch.sum(mwp[0, i:i + 1])
+            q = mwp[1, i:i + 1] / torch.sum(mwp[1, i:i + 1])
+            (s, idx) = torch.sort(torch.flatten(m.clone()))
+            cs = torch.cumsum(s, 0)
+            mask = torch.zeros(s.shape)
+            mask[idx] = (cs >= (pct / 100.0) * cs[-1]).type(torch.FloatTensor)
+            mask = mask.reshape(m.shape)
+            c = np.squeeze(np.sum(F.relu(mask * m - mask * q).numpy(), axis=1).astype(np.float32))
+            assert_map_close(sal[i], mwp_to_saliency(c), 'truncated tail pct=%g sample %d' % (pct, i))
+
+
+# ---- full BASELINE.json size: properties that do not need the (slow) CPU path --------------------------------------------
+def test_resnet101_batch32_properties(gpu_device):
+    """ResNet-101, 32 triplets (BASELINE.json configs[1]): every map is finite, non-negative and sums to 1; samples
+    are independent (a sample computed alone gives the same map); the batch is permutation-equivariant."""
+    bb, sd = make_backbone('stresnet101', seed=0, num_classes=2)
+    subj = GC.engine_subject('stresnet101', bb, 'affineonly_with_prior')
+    wb = subj.wb
+    B = 32
+    imgs = make_images('stresnet101', 3 * B, seed=1234, smooth=False).to(gpu_device)
+    em = subj.enc(imgs[0:B]) / 2500.0
+    en = subj.enc(imgs[B:2 * B]) / 2500.0
+    subj.set_cls(em[:1].cpu(), en[:1].cpu())
+    probes = imgs[2 * B:]
+    sal = wb.contrastive_triplet_ebp_batch(probes, em, en)
+    assert tuple(sal.shape) == (B, 112, 112)
+    assert bool(torch.isfinite(sal).all()) and float(sal.min()) >= 0.0
+    assert float((sal.sum(dim=(1, 2)) - 1.0).abs().max()) < 1e-4
+    for i in (0, 13, 31):
+        alone = wb.contrastive_triplet_ebp_batch(probes[i:i + 1], em[i:i + 1], en[i:i + 1])
+        rel, cos = map_metrics(alone[0].cpu().numpy(), sal[i].cpu().numpy())
+        assert rel <= 1e-5 and cos >= 0.9999999, (i, rel, cos)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(gpu_device)
+    sal_p = wb.contrastive_triplet_ebp_batch(probes[perm], em[perm], en[perm])
+    assert float((sal_p - sal[perm]).abs().max()) <= 1e-5 * float(sal.max())
+    # truncated variant at full size: same invariants
+    sal_t = wb.contrastive_triplet_ebp_batch(probes, em, en, percentile=20)
+    assert bool(torch.isfinite(sal_t).all()) and float((sal_t.sum(dim=(1, 2)) - 1.0).abs().max()) < 1e-4
+
+
+def test_engine_argument_errors(gpu_device):
+    bb, _ = make_backbone('stresnet_mini', num_classes=5)
+    subj = GC.engine_subject('stresnet_mini', bb, 'affineonly_with_prior')
+    wb = subj.wb
+    x = make_images('stresnet_mini', 1)
+    with pytest.raises(AssertionError):                # whitebox.py:508-509 channel range asserts
+        wb.contrastive_ebp(x, 0, 5)
+    with pytest.raises(ValueError):
+        subj.enc(torch.zeros(1, 3, 100, 100))
+    with pytest.raises(ValueError):
+        wb._engine(1).ebp(x, 2, torch.zeros(3, 1, 1))  # n_streams / seed shape
+    with pytest.raises(ValueError):
+        wb.net.engine().set_mode('nonsense')

@@ -1,0 +1,64 @@
+"""The CPU oracle against the golden vectors captured from the real reference (tests/golden/make_golden.py).
+
+On the machine that produced the vectors the oracle reproduces them bit-for-bit (it dispatches to the same ATen
+kernels); across machines / thread counts MKLDNN may re-associate the convolution sums, so the assertion is
+max|d|/max <= 1e-5 on maps and 1e-5 relative on every per-firing P sum."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as GC
+from parity_utils import make_backbone, map_metrics
+from xfr_amd import synth
+
+ORACLE_TOL = 1e-5
+
+
+def check(key, res, trace, gold):
+    want = gold[key + '/map']
+    rel, cos = map_metrics(res, want)
+    assert rel <= ORACLE_TOL, '%s: map max|d|/max = %.3e' % (key, rel)
+    sums, names = trace
+    gsum, gnames = gold[key + '/trace'], [str(n) for n in gold[key + '/names']]
+    assert names == gnames, '%s: firing order differs' % key
+    err = np.abs(sums - gsum) / np.maximum(np.abs(gsum), 1e-300)
+    assert err.max() <= ORACLE_TOL, '%s: trace rel err %.3e at firing %d (%s)' % (key, err.max(), int(err.argmax()), names[int(err.argmax())])
+
+
+@pytest.mark.parametrize('recipe', ['mild', 'harsh'])
+@pytest.mark.parametrize('mode', ['affineonly_with_prior', 'norelu', 'all', 'affineonly'])
+def test_mini_resnet_all_modes(recipe, mode):
+    torch.set_num_threads(8)
+    gold = GC.golden('golden_mini')
+    bb, sd = make_backbone('stresnet_mini', seed=3, recipe=recipe, num_classes=5)
+    assert synth.state_checksum(sd) == str(gold['mini/%s/wsum' % recipe]), 'synthetic weight generator drifted'
+    GC.replay(GC.oracle_subject('stresnet_mini', sd, mode), GC.mini_cases(recipe, mode), gold, check)
+
+
+def test_resnet101_triplet_contrastive_demo():
+    """demo/test_whitebox.py:124-133 on the bundled JPEGs + the bench-style synthetic triplet (default mode)."""
+    torch.set_num_threads(8)
+    gold = GC.golden('golden_r101')
+    bb, sd = make_backbone('stresnet101', seed=0, num_classes=65359)
+    assert synth.state_checksum(sd) == str(gold['r101/wsum'])
+    cases = GC.r101_cases('affineonly_with_prior', which=['triplet/contrastive', 'synthetic/contrastive', 'hooked/ebp'])
+    GC.replay(GC.oracle_subject('stresnet101', sd, 'affineonly_with_prior'), cases, gold, check)
+
+
+def test_resnet50_128_truncated_norelu():
+    torch.set_num_threads(8)
+    gold = GC.golden('golden_r50')
+    bb, sd = make_backbone('resnet50_128', seed=0)
+    assert synth.state_checksum(sd) == str(gold['r50/wsum'])
+    cases = GC.r50_cases('norelu', which=['triplet/truncated', 'triplet/ebp'])
+    GC.replay(GC.oracle_subject('resnet50_128', sd, 'norelu'), cases, gold, check)
+
+
+def test_lightcnn_ebp_affineonly():
+    torch.set_num_threads(8)
+    gold = GC.golden('golden_lcnn')
+    bb, sd = make_backbone('lightcnn29v2', seed=0, num_classes=80013)
+    assert synth.state_checksum(sd) == str(gold['lcnn/wsum'])
+    GC.replay(GC.oracle_subject('lightcnn29v2', sd, 'affineonly'), GC.lcnn_cases('affineonly'), gold, check)
+    cases = GC.lcnn_cases('affineonly_with_prior', which=['triplet/contrastive'])
+    GC.replay(GC.oracle_subject('lightcnn29v2', sd, 'affineonly_with_prior'), cases, gold, check)

@@ -1,0 +1,103 @@
+"""Host logic: layer programs, parameter specs, preprocessing -- pinned by structure captured from the reference."""
+import collections
+
+import numpy as np
+import PIL.Image
+import pytest
+import torch
+
+import golden_cases as GC
+from parity_utils import make_backbone
+from xfr_amd.program import OpKind
+
+
+@pytest.mark.parametrize('arch,nc', [('stresnet101', 65359), ('resnet50_128', None), ('lightcnn29v2', 80013)])
+def test_state_dict_keys_and_shapes_match_reference(arch, nc):
+    g = GC.golden('golden_structure')
+    bb, sd = make_backbone(arch, num_classes=nc)
+    ours = [(k, ','.join(str(s) for s in v.shape)) for k, v in sd.items()]
+    ref = list(zip([str(k) for k in g['%s/keys' % arch]], [str(s) for s in g['%s/shapes' % arch]]))
+    assert sorted(ours) == sorted(ref)
+
+
+def firing_kinds(prog, upto):
+    """Module class name per hook firing, reference order: descending producer, registration order, image last."""
+    names = {OpKind.CONV: 'Conv2d', OpKind.BATCHNORM: 'BatchNorm2d', OpKind.RELU: 'ReLU', OpKind.MAXPOOL: 'MaxPool2d',
+             OpKind.AVGPOOL: 'AvgPool2d', OpKind.ADD: 'Add', OpKind.CONCAT: 'ConcatChannels', OpKind.MULTIPLY: 'Multiply',
+             OpKind.LINEAR: 'Linear', OpKind.SPLIT: 'Split'}
+    hooks = collections.defaultdict(list)
+    for o in prog.ops:
+        if o.out > upto or o.kind >= OpKind.G_ADD:
+            continue
+        ins = [o.in0] + ([o.in1] if o.kind == OpKind.ADD else [])
+        for t in ins:
+            hooks[o.out if (o.kind == OpKind.RELU and o.inplace) else t].append(names[OpKind(o.kind)])
+    out = []
+    for t in range(upto, -1, -1):
+        out += hooks.get(t, [])
+    return out
+
+
+def test_firing_order_matches_reference_traces():
+    g = GC.golden('golden_r101')
+    bb, _ = make_backbone('stresnet101', num_classes=65359)
+    prog = bb.build_program()
+    assert firing_kinds(prog, prog.marks['classify']) == [str(n) for n in g['r101/affineonly_with_prior/hooked/ebp/names']]
+    assert firing_kinds(prog, prog.marks['encode']) == [str(n) for n in g['r101/affineonly_with_prior/triplet/ebp/names']]
+    g = GC.golden('golden_r50')
+    bb, _ = make_backbone('resnet50_128')
+    prog = bb.build_program()
+    assert firing_kinds(prog, prog.marks['encode']) == [str(n) for n in g['r50/norelu/triplet/ebp/names']]
+    g = GC.golden('golden_lcnn')
+    bb, _ = make_backbone('lightcnn29v2', num_classes=80013)
+    prog = bb.build_program()
+    assert firing_kinds(prog, prog.marks['classify']) == [str(n) for n in g['lcnn/affineonly/hooked/ebp/names']]
+
+
+def test_hooked_call_counts():
+    bb, _ = make_backbone('stresnet101', num_classes=65359)
+    c = collections.Counter(OpKind(o.kind) for o in bb.build_program().ops)
+    assert (c[OpKind.CONV], c[OpKind.BATCHNORM], c[OpKind.RELU], c[OpKind.ADD], c[OpKind.AVGPOOL], c[OpKind.CONCAT],
+            c[OpKind.MAXPOOL], c[OpKind.MULTIPLY], c[OpKind.LINEAR]) == (100, 100, 100, 33, 5, 4, 1, 1, 2)
+    bb, _ = make_backbone('resnet50_128')
+    c = collections.Counter(OpKind(o.kind) for o in bb.build_program().ops)
+    assert (c[OpKind.CONV], c[OpKind.BATCHNORM], c[OpKind.RELU], c[OpKind.MAXPOOL], c[OpKind.AVGPOOL], c[OpKind.G_ADD]) == (54, 53, 49, 1, 1, 16)
+    bb, _ = make_backbone('lightcnn29v2', num_classes=80013)
+    c = collections.Counter(OpKind(o.kind) for o in bb.build_program().ops)
+    assert (c[OpKind.CONV], c[OpKind.SPLIT], c[OpKind.ADD], c[OpKind.MAXPOOL], c[OpKind.AVGPOOL], c[OpKind.LINEAR]) == (29, 29, 10, 4, 4, 2)
+
+
+def test_preprocess_shapes_and_values():
+    from xfr_amd.models import resnet, whitebox as WB
+    from xfr_amd.models.lightcnn import lightcnn_preprocess
+    rng = np.random.RandomState(0)
+    im = PIL.Image.fromarray(rng.randint(0, 256, (300, 260, 3)).astype(np.uint8))
+    bb, _ = make_backbone('stresnet_mini')
+    x = WB.WhiteboxSTResnet(bb).preprocess(im)                      # whitebox.py:108-110
+    assert tuple(x.shape) == (1, 3, 224, 224) and x.dtype == torch.float32
+    want = np.moveaxis(np.array(im.resize((224, 224)).convert('RGB')) - resnet.MEAN_RGB, 2, 0)
+    assert np.allclose(x[0].numpy(), want.astype(np.float32))
+    bb50, _ = make_backbone('resnet50_128')
+    x = WB.Whitebox_resnet50_128(bb50).preprocess(im)                # whitebox.py:235-258
+    assert tuple(x.shape) == (1, 3, 224, 224)
+    x = lightcnn_preprocess()(im)                                    # lightcnn.py:27-31
+    assert tuple(x.shape) == (1, 1, 128, 128) and 0.0 <= float(x.min()) and float(x.max()) <= 1.0
+
+
+def test_unsupported_layer_kind_is_rejected_by_name():
+    """whitebox.py:402-403: Sigmoid / ELU / Tanh raise ValueError; the engine refuses unknown op kinds the same way."""
+    import ctypes
+    from xfr_amd import _lib
+    from xfr_amd.program import Program
+    p = Program((3, 32, 32))
+    t = p.conv(0, 'c', 8, 3, 1, 1)
+    p._op(99, t)     # not a kind the engine knows (e.g. Sigmoid)
+    h = ctypes.c_void_p()
+    lib = _lib.load()
+    st = lib.xfr_engine_create(p.op_array(), len(p.ops), len(p.weight_names), 3, 32, 32, 1, 0, ctypes.byref(h))
+    if torch.cuda.is_available():
+        assert st == _lib.XFR_UNSUPPORTED_LAYER
+        with pytest.raises(ValueError):
+            _lib.check(st)
+    else:
+        assert st == _lib.XFR_HIP_ERROR
