@@ -151,6 +151,8 @@ def main():
         imgs = synth.synth_images(3, (3, 224, 224), seed=1234, mean=xresnet.MEAN_RGB)
         em = wbn.encode(imgs[0:1]).detach()
         en = wbn.encode(imgs[1:2]).detach()
+        out['r101/%s/enc_synth_mate' % mode] = em.numpy()
+        out['r101/%s/enc_synth_nonmate' % mode] = en.numpy()
         wbn.set_triplet_classifier(em / 2500.0, en / 2500.0)
         run_case(out, 'r101/%s/synthetic/contrastive' % mode, wb, lambda w: w.contrastive_ebp(imgs[2:3], 0, 1))
     np.savez_compressed(os.path.join(HERE, 'golden_r101.npz'), **out)
@@ -168,6 +170,7 @@ def main():
         e_mate = wbn.encode(x_mate).detach()
         e_non = wbn.encode(x_non).detach()
         out['r50/%s/enc_mate' % mode] = e_mate.numpy()
+        out['r50/%s/enc_nonmate' % mode] = e_non.numpy()
         wbn.set_triplet_classifier(e_mate / 2500.0, e_non / 2500.0)
         P2 = torch.zeros((1, 2))
         P2[0][0] = 1.0
@@ -201,6 +204,7 @@ def main():
             e_mate = wbn.encode(x_mate).detach()
             e_non = wbn.encode(x_non).detach()
             out['lcnn/%s/enc_mate' % mode] = e_mate.numpy()
+            out['lcnn/%s/enc_nonmate' % mode] = e_non.numpy()
             wbn.set_triplet_classifier(e_mate / 2500.0, e_non / 2500.0)
             run_case(out, 'lcnn/%s/triplet/contrastive' % mode, wb, lambda w: w.contrastive_ebp(x_probe, 0, 1))
             run_case(out, 'lcnn/%s/triplet/truncated' % mode, wb,
