@@ -147,13 +147,11 @@ def main():
         run_case(out, 'r101/%s/triplet/contrastive' % mode, wb, lambda w: w.contrastive_ebp(x_probe, 0, 1))  # :124-133
         run_case(out, 'r101/%s/triplet/truncated' % mode, wb,
                  lambda w: w.truncated_contrastive_ebp(x_probe, 0, 1, 20))                                    # :135-144
-        # bench-style synthetic triplet (uniform-noise images, seed 1234)
+        # synthetic probe (uniform-noise image, seed 1234) against two well-separated random classifier rows.
+        # (Encodings of two NOISE images under random weights are nearly parallel: the contrastive map then is a
+        # rounding-noise residual on which the reference disagrees with itself across machines by 6 %.)
         imgs = synth.synth_images(3, (3, 224, 224), seed=1234, mean=xresnet.MEAN_RGB)
-        em = wbn.encode(imgs[0:1]).detach()
-        en = wbn.encode(imgs[1:2]).detach()
-        out['r101/%s/enc_synth_mate' % mode] = em.numpy()
-        out['r101/%s/enc_synth_nonmate' % mode] = en.numpy()
-        wbn.set_triplet_classifier(em / 2500.0, en / 2500.0)
+        wbn.set_triplet_classifier(synth.unit_rows(1, 512, seed=1) / 2500, synth.unit_rows(1, 512, seed=2) / 2500)
         run_case(out, 'r101/%s/synthetic/contrastive' % mode, wb, lambda w: w.contrastive_ebp(imgs[2:3], 0, 1))
     np.savez_compressed(os.path.join(HERE, 'golden_r101.npz'), **out)
 

@@ -3,6 +3,12 @@
 Tolerance (stated once, used everywhere).  The reference's own fp32-vs-fp64 self-consistency on these maps is
 max|d|/max ~ 1e-4, so a GPU map is accepted when
     max|gpu - ref| / max|ref| <= 1e-3   and   cosine(gpu, ref) >= 0.99999                    (assert_map_close)
+Contrastive maps are a DIFFERENCE of two normalised MWP tensors (whitebox.py:524-526).  With seeded random weights the
+mate and non-mate sweeps are nearly identical, so the subtraction cancels 2-3 digits and last-bit differences of P
+(1e-7) surface at 1e-4..1e-3 of the contrastive map (measured: a 1-ulp change of one classifier row moves the
+reference's own map by 5e-4).  Contrastive / truncated maps are therefore accepted at
+    max|d|/max <= 5e-3 (MAP_RTOL_CONTRAST)   and   cosine >= 0.99999,
+while the MWP tensors they are computed from are held to the 1e-3 / 1e-4 bars above.
 Two steps of the reference algorithm are DISCONTINUOUS in the activations and flip on last-bit differences between
 any two fp32 implementations (MKLDNN vs MFMA summation order), moving a whole gradient element:
   * max-pool argmax near-ties (two window elements equal to ~1e-7 relative: ~10 windows per 64x112x112 image),
@@ -19,6 +25,7 @@ from xfr_amd import synth
 from xfr_amd.models import lightcnn, resnet, resnet50_128
 
 MAP_RTOL = 1e-3
+MAP_RTOL_CONTRAST = 5e-3
 MAP_COS = 0.99999
 
 R50_MEAN = (131.0912, 103.8827, 91.4953)
@@ -61,24 +68,24 @@ def map_metrics(a, b):
     return rel, cos
 
 
-def assert_map_close(got, want, what=''):
+def assert_map_close(got, want, what='', rtol=MAP_RTOL):
     assert np.isfinite(np.asarray(got)).all(), 'non-finite values in %s' % what
     rel, cos = map_metrics(got, want)
-    assert rel <= MAP_RTOL and cos >= MAP_COS, '%s: max|d|/max = %.3e (tol %.0e), cosine = %.8f (tol %.5f)' % (
-        what, rel, MAP_RTOL, cos, MAP_COS)
+    assert rel <= rtol and cos >= MAP_COS, '%s: max|d|/max = %.3e (tol %.0e), cosine = %.8f (tol %.5f)' % (
+        what, rel, rtol, cos, MAP_COS)
     return rel, cos
 
 
-def assert_map_close_robust(got, want, what='', frac=2e-3, cap=5e-2):
+def assert_map_close_robust(got, want, what='', frac=2e-3, cap=5e-2, rtol=MAP_RTOL):
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert np.isfinite(got).all(), 'non-finite values in %s' % what
     mx = max(np.abs(want).max(), 1e-300)
     d = np.abs(got - want) / mx
     rel, cos = map_metrics(got, want)
-    bad = float((d > MAP_RTOL).mean())
+    bad = float((d > rtol).mean())
     assert cos >= MAP_COS and bad <= frac and d.max() <= cap, \
-        '%s: cosine %.8f, %.3f %% pixels beyond %.0e, max|d|/max %.3e' % (what, cos, 100 * bad, MAP_RTOL, d.max())
+        '%s: cosine %.8f, %.3f %% pixels beyond %.0e, max|d|/max %.3e' % (what, cos, 100 * bad, rtol, d.max())
     return rel, cos
 
 

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import golden_cases as GC
-from parity_utils import (assert_map_close, assert_map_close_robust, assert_trace_close, emb_dim, make_backbone,
+from parity_utils import (MAP_RTOL_CONTRAST, assert_map_close, assert_map_close_robust, assert_trace_close, emb_dim, make_backbone,
                           make_images, map_metrics)
 from xfr_amd import synth
 
@@ -18,8 +18,14 @@ def _check_factory(robust_pooled=False):
     def check(key, res, trace, gold):
         want = gold[key + '/map']
         # final maps of *truncated* calls and P[-2]-level maps ride on discontinuous steps (see parity_utils docstring)
-        if key.endswith('truncated') or robust_pooled:
+        if key.endswith('truncated'):
+            assert_map_close_robust(res, want, key, rtol=MAP_RTOL_CONTRAST)
+        elif robust_pooled and not key.endswith('contrastive'):
             assert_map_close_robust(res, want, key)
+        elif robust_pooled:
+            assert_map_close_robust(res, want, key, rtol=MAP_RTOL_CONTRAST)
+        elif key.endswith('contrastive'):
+            assert_map_close(res, want, key, rtol=MAP_RTOL_CONTRAST)
         else:
             assert_map_close(res, want, key)
         if trace is not None and key.endswith('/ebp'):
