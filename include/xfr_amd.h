@@ -166,6 +166,18 @@ xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n,
                            int32_t seed_tensor, const float* seed_dev, float percentile,
                            float* sal_dev, void* stream);
 
+/* One whole triplet step for N independent (mate, non-mate, probe) triplets -- demo/test_whitebox.py:124-133:
+ *     x_mate = encode(mate); x_nonmate = encode(nonmate)                         (:71-72)
+ *     set_triplet_classifier(scale * x_mate, scale * x_nonmate)                  (:129, scale = 1/2500)
+ *     contrastive_ebp(probe, 0, 1)  |  truncated_contrastive_ebp(probe, 0, 1, percentile)   (:130)
+ *   probes_dev   N  x in_c x in_h x in_w
+ *   gallery_dev  2N x in_c x in_h x in_w : the N mates followed by the N non-mates
+ *   encode_tensor  tensor id of encode()'s output; requires max_batch >= 2N
+ * The two encode forwards run as one 2N-image batch, concurrently (internal streams, joined before the backward
+ * sweep) with the probe forward.  sal_dev: N x H1 x W1. */
+xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const float* gallery_dev, int32_t n,
+                                   int32_t encode_tensor, float scale, float percentile, float* sal_dev, void* stream);
+
 /* _mwp_to_saliency (whitebox.py:448-460, ebp_ver 6) on N pooled maps: in N x H x W -> out N x H x W. */
 xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w,
                                float* sal_dev, void* stream);

@@ -205,6 +205,24 @@ def test_resnet101_batch32_properties(gpu_device):
     assert bool(torch.isfinite(sal_t).all()) and float((sal_t.sum(dim=(1, 2)) - 1.0).abs().max()) < 1e-4
 
 
+def test_triplet_step_equals_two_call_path(gpu_device):
+    """xfr_triplet_contrastive (fused + two-stream) == encode(), encode(), contrastive() done call by call."""
+    bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=5)
+    subj = GC.engine_subject('stresnet_mini', bb, 'affineonly_with_prior')
+    wb = subj.wb
+    n = 4
+    imgs = make_images('stresnet_mini', 3 * n, seed=9, smooth=False).to(gpu_device)
+    mates, nonmates, probes = imgs[:n], imgs[n:2 * n], imgs[2 * n:]
+    for pct in (None, 20):
+        got = wb.triplet_images_ebp_batch(probes, mates, nonmates, percentile=pct)
+        em = (1.0 / 2500.0) * subj.enc(mates)
+        en = (1.0 / 2500.0) * subj.enc(nonmates)
+        want = wb.contrastive_triplet_ebp_batch(probes, em, en, percentile=pct)
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.max())
+        again = wb.triplet_images_ebp_batch(probes, mates, nonmates, percentile=pct)
+        assert torch.equal(got, again)        # deterministic, and the stream join is race-free
+
+
 def test_engine_argument_errors(gpu_device):
     bb, _ = make_backbone('stresnet_mini', num_classes=5)
     subj = GC.engine_subject('stresnet_mini', bb, 'affineonly_with_prior')

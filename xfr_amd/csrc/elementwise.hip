@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const float* __restrict
             }
         }
         out[i] = best;
-        idx[i] = (uint8_t)bi;
+        if (idx) idx[i] = (uint8_t)bi;
     }
 }
 

@@ -148,7 +148,12 @@ struct xfr_engine {
     long last_gemm_launches = 0;
     double last_gemm_flops = 0.0;
 
-    float* T(int t) { const Tensor& x = tens[t]; return ws + tens[x.alias >= 0 ? root(t) : t].t_off; }
+    float* t_bank = nullptr;       // when set, true activations live in this bank (gallery forward of a triplet step)
+    float* ws_enc = nullptr;       // second bank of true activations (T region only), allocated on first use
+    size_t t_region_floats = 0;
+    hipStream_t s_a = nullptr, s_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b = nullptr;
+    float* T(int t) { const Tensor& x = tens[t]; return (t_bank ? t_bank : ws) + tens[x.alias >= 0 ? root(t) : t].t_off; }
     float* Pv(int t) { return ws + tens[t].pv_off; }
     float* G(int t) { return ws + tens[t].g_off; }
     int root(int t) const { while (tens[t].alias >= 0) t = tens[t].alias; return t; }
@@ -361,6 +366,7 @@ xfr_status allocate(xfr_engine* e)
         Tensor& x = e->tens[t];
         if (x.alias < 0) x.t_off = take(B * x.per_n());
     }
+    e->t_region_floats = off;
     for (size_t t = 0; t < e->tens.size(); ++t) {
         Tensor& x = e->tens[t];
         if (x.pstate == PS_OTHER) x.pv_off = take(B * x.per_n());
@@ -510,7 +516,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
             launch_relu(e->T(d.in0), e->T(d.out), n_in, s);
             return XFR_OK;
         case XFR_OP_MAXPOOL:
-            launch_maxpool_fwd(e->T(d.in0), e->T(d.out), e->idx_ws + o.idx_off, a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, d.pad, s);
+            launch_maxpool_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->idx_ws + o.idx_off, a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, d.pad, s);
             return XFR_OK;
         case XFR_OP_AVGPOOL:
             launch_avgpool_fwd(e->T(d.in0), e->T(d.out), a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, 0, s);
@@ -532,7 +538,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
             launch_maxhalves_fwd(e->T(d.in0), e->T(d.out), t.C, (long)B * t.HW(), 0, s);
             return XFR_OK;
         case XFR_OP_G_NORMALIZE:
-            launch_normalize_fwd(e->T(d.in0), e->T(d.out), e->ws + e->misc_off + o.norm_off, t.C, B, 0, s);
+            launch_normalize_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->ws + e->misc_off + o.norm_off, t.C, B, 0, s);
             return XFR_OK;
     }
     return fail(XFR_UNSUPPORTED_LAYER, "forward: unsupported kind %d", d.kind);
@@ -997,6 +1003,12 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->arena) (void)hipFree(e->arena);
     if (e->dbl_ws) (void)hipFree(e->dbl_ws);
     if (e->trunc_ws) (void)hipFree(e->trunc_ws);
+    if (e->ws_enc) (void)hipFree(e->ws_enc);
+    if (e->s_a) (void)hipStreamDestroy(e->s_a);
+    if (e->s_b) (void)hipStreamDestroy(e->s_b);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_a) (void)hipEventDestroy(e->ev_a);
+    if (e->ev_b) (void)hipEventDestroy(e->ev_b);
     for (auto& ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete e;
     return XFR_OK;
@@ -1143,17 +1155,8 @@ xfr_status xfr_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32_t n_strea
     return prof_end(e, s);
 }
 
-xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
-                           float percentile, float* sal_dev, void* stream)
+static xfr_status contrastive_tail(xfr_engine* e, int n, float percentile, float* sal_dev, hipStream_t s)
 {
-    xfr_status st = check_run(e, x_dev, n);
-    if (st != XFR_OK) return st;
-    if (!sal_dev) return fail(XFR_INVALID_ARG, "null output");
-    if (percentile > 100.f) return fail(XFR_INVALID_ARG, "percentile must be <= 100 (or < 0 for plain contrastive)");
-    hipStream_t s = (hipStream_t)stream;
-    prof_begin(e);
-    st = ebp_core(e, x_dev, n, 2, seed_tensor, seed_dev, s);
-    if (st != XFR_OK) return st;
     const Tensor& t1 = e->tens[1];
     const float* P = e->ws + e->tap_off;
     double* sums = e->dbl_ws;
@@ -1167,6 +1170,78 @@ xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n, int32_t
     launch_contrast(P, sums, thr, contrast, t1.C, n, t1.HW(), s);
     launch_saliency_blur(contrast, e->ws + e->blur_b_off, sal_dev, n, t1.H, t1.W, e->eps, s);
     HIP_TRY(hipGetLastError());
+    return XFR_OK;
+}
+
+xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                           float percentile, float* sal_dev, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, n);
+    if (st != XFR_OK) return st;
+    if (!sal_dev) return fail(XFR_INVALID_ARG, "null output");
+    if (percentile > 100.f) return fail(XFR_INVALID_ARG, "percentile must be <= 100 (or < 0 for plain contrastive)");
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(e);
+    st = ebp_core(e, x_dev, n, 2, seed_tensor, seed_dev, s);
+    if (st != XFR_OK) return st;
+    st = contrastive_tail(e, n, percentile, sal_dev, s);
+    if (st != XFR_OK) return st;
+    return prof_end(e, s);
+}
+
+xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const float* gallery_dev, int32_t n,
+                                   int32_t encode_tensor, float scale, float percentile, float* sal_dev, void* stream)
+{
+    xfr_status st = check_run(e, probes_dev, n);
+    if (st != XFR_OK) return st;
+    if (!gallery_dev || !sal_dev) return fail(XFR_INVALID_ARG, "null argument");
+    if (2 * n > e->max_batch) return fail(XFR_INVALID_ARG, "triplet batch %d needs max_batch >= %d (the gallery forward runs 2n images)", n, 2 * n);
+    if (percentile > 100.f) return fail(XFR_INVALID_ARG, "percentile must be <= 100 (or < 0 for plain contrastive)");
+    if (encode_tensor < 2 || encode_tensor >= (int)e->tens.size()) return fail(XFR_INVALID_ARG, "bad encode tensor %d", encode_tensor);
+    hipStream_t s = (hipStream_t)stream;
+    if (!e->ws_enc) {
+        HIP_TRY(hipMalloc(&e->ws_enc, (e->t_region_floats + 4096) * sizeof(float)));
+        HIP_TRY(hipStreamCreateWithFlags(&e->s_a, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&e->s_b, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
+    }
+    BwdPlan* plan = nullptr;
+    st = get_plan(e, encode_tensor, &plan);
+    if (st != XFR_OK) return st;
+    prof_begin(e);
+    // The gallery encodes (2n images, true weights only) and the probe forward (n images, W and relu(W)) are
+    // independent until the backward sweep needs its seeds: run them on two streams so their small layer-3/4 grids
+    // fill each other's idle CUs.  With profiling on, everything is serialised on the caller's stream instead.
+    const bool fork = !e->profile_on;
+    hipStream_t sa = fork ? e->s_a : s, sb = fork ? e->s_b : s;
+    if (fork) {
+        HIP_TRY(hipEventRecord(e->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(sa, e->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(sb, e->ev_fork, 0));
+    }
+    e->t_bank = e->ws_enc;
+    st = forward_all(e, gallery_dev, 2 * n, encode_tensor, false, sa);
+    const Tensor& sd = e->tens[encode_tensor];
+    // seeds: stream 0 = scale * encode(mate_i), stream 1 = scale * encode(nonmate_i)  (demo/test_whitebox.py:129 with the
+    // one-hot priors of whitebox.py:512,518 folded through the un-hooked 2-way classifier).  Layouts coincide:
+    // both are [D][2n][1].
+    if (st == XFR_OK) launch_scale(e->T(encode_tensor), e->G(encode_tensor), (long)sd.per_n() * 2 * n, scale, 0, sa);
+    e->t_bank = nullptr;
+    if (st != XFR_OK) return st;
+    st = forward_all(e, probes_dev, n, encode_tensor, true, sb);
+    if (st != XFR_OK) return st;
+    if (fork) {
+        HIP_TRY(hipEventRecord(e->ev_a, sa));
+        HIP_TRY(hipEventRecord(e->ev_b, sb));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_a, 0));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_b, 0));
+    }
+    st = run_backward(e, *plan, n, 2, s);
+    if (st != XFR_OK) return st;
+    st = contrastive_tail(e, n, percentile, sal_dev, s);
+    if (st != XFR_OK) return st;
     return prof_end(e, s);
 }
 

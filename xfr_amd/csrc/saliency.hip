@@ -219,8 +219,8 @@ void launch_channel_pool(const float* P, float* pooled, int C, int SB, int HW, h
 void launch_sample_sums(const float* P, double* sums, int C, int SB, int HW, hipStream_t s)
 {
     (void)hipMemsetAsync(sums, 0, sizeof(double) * SB, s);
-    long chunks = ((long)C * HW + NT * 8 - 1) / (NT * 8);
-    if (chunks > 512) chunks = 512;
+    long chunks = ((long)C * HW + NT * 4 - 1) / (NT * 4);
+    if (chunks > 64) chunks = 64;
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(sample_sums_kernel, dim3((int)chunks, SB), dim3(NT), 0, s, P, sums, C, SB, HW);
 }

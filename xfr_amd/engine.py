@@ -147,6 +147,21 @@ class Engine(object):
                                                 sal.data_ptr(), _stream_ptr(self.device)))
         return sal
 
+    def triplet_contrastive(self, probes, gallery, encode_tensor, scale=1.0 / 2500.0, percentile=None):
+        """probes N x C x H x W, gallery 2N x C x H x W (mates then non-mates) -> N x H1 x W1 saliency maps."""
+        probes = self._prep(probes)
+        n = probes.shape[0]
+        gallery = gallery.detach().to(self.device, torch.float32).contiguous()
+        if tuple(gallery.shape) != (2 * n,) + tuple(self.program.in_shape):
+            raise ValueError('gallery must be %d x %s, got %s' % (2 * n, self.program.in_shape, tuple(gallery.shape)))
+        c1, h1, w1 = self.tensor_shape(1)
+        sal = torch.empty((n, h1, w1), device=self.device)
+        pct = -1.0 if percentile is None else float(percentile)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_triplet_contrastive(self._h, probes.data_ptr(), gallery.data_ptr(), n, int(encode_tensor),
+                                                        float(scale), pct, sal.data_ptr(), _stream_ptr(self.device)))
+        return sal
+
     def mwp_to_saliency(self, pooled):
         pooled = pooled.detach().to(self.device, torch.float32).contiguous()
         n, h, w = pooled.shape
