@@ -10,7 +10,39 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define XFR_MAX_EW_STEPS 10
+#define XFR_MAX_EW_STEPS 14
+
+// ---- fused elementwise chain (micro-program) -------------------------------------------------------------------------
+// Executed per element either by the stand-alone ew_chain kernels or inside the conv_gemm epilogue.
+// Index spaces: "g-index" = position in the tensor being produced ([C][SB][HW]); "a-index" = the same (c, hw) in a
+// forward-side tensor with B images per channel row (sample b = sb % B).  For forward launches SB == B.
+enum {
+    EW_HOOK = 0,      // tensor hook (whitebox.py:388-428): a = relu(p0[a]), x = relu(p1[a]) or a; p = a*relu(g); action
+    EW_MASK = 1,      // g = p0[a] > 0 ? g : 0                      (in-place ReLU VJP)
+    EW_SCALE_C = 2,   // g *= p0[c]                                 (BatchNorm VJP with relu(gamma)*invstd)
+    EW_SCALE = 3,     // g *= f                                     (Multiply VJP)
+    EW_STORE = 4,     // pstore[g] = g
+    EW_ADDP = 5,      // g += p0[g]                                 (gradient fan-in / residual add)
+    EW_AFFINE_C = 6,  // g = g*p0[c] + p1[c]                        (eval BatchNorm forward)
+    EW_RELU = 7,      // g = max(g, 0)
+    EW_FORK_POSBN = 8 // pstore[g] = max(g,0)*p0[c] + p1[c]         (positive-pass BatchNorm output, g unchanged)
+};
+enum { HOOK_DIV = 0, HOOK_RELU = 1, HOOK_PASS = 2 };
+
+struct EwStep {
+    int type;
+    int action;        // HOOK_*
+    const float* p0;
+    const float* p1;
+    float* pstore;     // HOOK: if non-null, p is stored here (g-index);  STORE / FORK_POSBN: destination
+    double* trace;     // HOOK: if non-null, sum(p) per (stream,sample) is accumulated at trace[sb] (stand-alone kernels only)
+    float f;           // SCALE: factor
+};
+
+struct EwChain {
+    int n;
+    EwStep s[XFR_MAX_EW_STEPS];
+};
 
 // ---- implicit-GEMM convolution -------------------------------------------------------------------------------
 struct ConvParams {
@@ -33,29 +65,13 @@ struct ConvParams {
     int relu_in;        // clamp the gathered input at 0 (A = relu(input))
     int accumulate;     // out += result
     int out_H, out_W, out_stride;  // out_stride > 1: scatter the (OH,OW) grid into an (out_H,out_W) tensor
+    int chain_B;        // forward batch for the a-index of the epilogue chain
+    float chain_eps;    // eps of the hook divide
+    EwChain chain;      // epilogue micro-program applied to half 0 before the final store (n == 0: none)
 };
 
 void launch_conv_gemm(const ConvParams& p, hipStream_t s);
 int conv_gemm_pick_cfg(const ConvParams& p);
-
-// ---- fused elementwise backward chain ------------------------------------------------------------------------
-enum { EW_HOOK = 0, EW_MASK = 1, EW_SCALE_C = 2, EW_SCALE = 3 };
-enum { HOOK_DIV = 0, HOOK_RELU = 1, HOOK_PASS = 2 };
-
-struct EwStep {
-    int type;
-    int action;        // HOOK_*
-    const float* p0;   // HOOK: a source (relu applied on load);  MASK: tensor whose sign gates;  SCALE_C: per-channel vector
-    const float* p1;   // HOOK: x source (relu applied on load), nullptr => x = a
-    float* pstore;     // HOOK: if non-null, p is stored here (same indexing as the gradient)
-    double* trace;     // HOOK: if non-null, sum(p) per (stream,sample) is accumulated at trace[sb]
-    float f;           // SCALE: factor
-};
-
-struct EwChain {
-    int n;
-    EwStep s[XFR_MAX_EW_STEPS];
-};
 
 // g = src[idx]; run chain; dst[idx] = (accumulate ? dst[idx] : 0) + g.   Tensors are [C][SB][HW] for the gradient
 // and [C][B][HW] for the forward-side sources (sample b = sb % B).

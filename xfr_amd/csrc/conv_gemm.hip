@@ -272,17 +272,20 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     wait_vmcnt<0>();   // drain the tail loads before the LDS is released
 
     // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
+    // Optional fused micro-program (half 0 only): forward = bias -> [store raw] -> BatchNorm -> [+residual] -> ReLU;
+    // backward = [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP -> next GEMM's input.
+    const bool use_chain = (p.chain.n > 0) && (half == 0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
         if (m >= p.M) continue;
         long col;
         long row_stride;
+        const int ohw = p.OH * p.OW;
         if (p.out_stride == 1) {
             col = m;
-            row_stride = (long)p.out_nb * p.OH * p.OW;
+            row_stride = (long)p.out_nb * ohw;
         } else {
-            const int ohw = p.OH * p.OW;
             const int n = m / ohw;
             const int r = m - n * ohw;
             const int oh = r / p.OW;
@@ -290,18 +293,97 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
             col = ((long)n * p.out_H + (long)oh * p.out_stride) * p.out_W + (long)ow * p.out_stride;
             row_stride = (long)p.out_nb * p.out_H * p.out_W;
         }
+        long acol = 0, arow = 0;
+        if (use_chain) {
+            const int sb = m / ohw;
+            const int hw = m - sb * ohw;
+            acol = (long)(sb % p.chain_B) * ohw + hw;
+            arow = (long)p.chain_B * ohw;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            // the 16 accumulator registers of a 32x32 tile are 4 groups of 4 consecutive output channels
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wrow * (TCO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (co < p.CoutTot) {
-                    float v = acc[i][j][r];
-                    if (bsel) v += bsel[co];
-                    float* o = osel + (long)co * row_stride;
-                    if (p.accumulate) v += o[col];
-                    o[col] = v;
+            for (int rg = 0; rg < 4; ++rg) {
+                const int co4 = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg;   // channels co4 .. co4+3
+                float g[4];
+                int gi[4];          // g-index (elements; every tensor is < 2^31 bytes)
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = co4 + q;
+                    ok[q] = co < p.CoutTot;
+                    gi[q] = (int)((long)co * row_stride + col);
+                    float v = acc[i][j][rg * 4 + q];
+                    if (ok[q]) {
+                        if (bsel) v += bsel[co];
+                        if (p.accumulate) v += osel[gi[q]];
+                    }
+                    g[q] = v;
                 }
+                if (use_chain) {
+                    int ai[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ai[q] = (int)((long)(co4 + q) * arow + acol);
+#pragma unroll 1
+                    for (int sidx = 0; sidx < p.chain.n; ++sidx) {
+                        const EwStep& st = p.chain.s[sidx];
+                        const int type = st.type;
+                        if (type == EW_HOOK) {
+                            const float* __restrict__ pa = st.p0;
+                            const float* __restrict__ px = st.p1;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (ok[q]) {
+                                    const float a = fmaxf(pa[ai[q]], 0.f);
+                                    const float zh = fmaxf(g[q], 0.f);
+                                    const float pp = a * zh;
+                                    if (st.pstore) st.pstore[gi[q]] = pp;
+                                    if (st.action == HOOK_DIV) {
+                                        const float x = px ? fmaxf(px[ai[q]], 0.f) : a;
+                                        g[q] = __fdiv_rn(pp, x + p.chain_eps);
+                                    } else if (st.action == HOOK_RELU) {
+                                        g[q] = zh;
+                                    }
+                                }
+                            }
+                        } else if (type == EW_MASK) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (ok[q]) g[q] = (st.p0[ai[q]] > 0.f) ? g[q] : 0.f;
+                        } else if (type == EW_SCALE_C) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (ok[q]) g[q] *= st.p0[co4 + q];
+                        } else if (type == EW_SCALE) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) g[q] *= st.f;
+                        } else if (type == EW_STORE) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (ok[q]) st.pstore[gi[q]] = g[q];
+                        } else if (type == EW_ADDP) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (ok[q]) g[q] += st.p0[gi[q]];
+                        } else if (type == EW_AFFINE_C) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (ok[q]) g[q] = __fadd_rn(__fmul_rn(g[q], st.p0[co4 + q]), st.p1[co4 + q]);
+                        } else if (type == EW_RELU) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
+                        } else {   // EW_FORK_POSBN
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (ok[q])
+                                    st.pstore[gi[q]] = __fadd_rn(__fmul_rn(fmaxf(g[q], 0.f), st.p0[co4 + q]), st.p1[co4 + q]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ok[q]) osel[gi[q]] = g[q];
             }
         }
     }

@@ -84,7 +84,12 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
             } else if (ok) {
                 if (st.type == EW_MASK) g = (st.p0[aidx] > 0.f) ? g : 0.f;
                 else if (st.type == EW_SCALE_C) g = g * st.p0[c];
-                else g = g * st.f;
+                else if (st.type == EW_SCALE) g = g * st.f;
+                else if (st.type == EW_STORE) st.pstore[idx] = g;
+                else if (st.type == EW_ADDP) g += st.p0[idx];
+                else if (st.type == EW_AFFINE_C) g = __fadd_rn(__fmul_rn(g, st.p0[c]), st.p1[c]);
+                else if (st.type == EW_RELU) g = fmaxf(g, 0.f);
+                else st.pstore[idx] = __fadd_rn(__fmul_rn(fmaxf(g, 0.f), st.p0[c]), st.p1[c]);
             }
         }
         if (ok) {
@@ -143,9 +148,26 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
                 const float sc = st.p0[c];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) g[q] *= sc;
-            } else {
+            } else if (st.type == EW_SCALE) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) g[q] *= st.f;
+            } else if (st.type == EW_STORE) {
+                reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(g[0], g[1], g[2], g[3]);
+            } else if (st.type == EW_ADDP) {
+                const float4 d = reinterpret_cast<const float4*>(st.p0)[idx];
+                g[0] += d.x; g[1] += d.y; g[2] += d.z; g[3] += d.w;
+            } else if (st.type == EW_AFFINE_C) {
+                const float al = st.p0[c], be = st.p1[c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(__fmul_rn(g[q], al), be);
+            } else if (st.type == EW_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
+            } else {
+                const float al = st.p0[c], be = st.p1[c];
+                reinterpret_cast<float4*>(st.pstore)[idx] =
+                    make_float4(__fadd_rn(__fmul_rn(fmaxf(g[0], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[1], 0.f), al), be),
+                                __fadd_rn(__fmul_rn(fmaxf(g[2], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[3], 0.f), al), be));
             }
         }
         float4 o = make_float4(g[0], g[1], g[2], g[3]);

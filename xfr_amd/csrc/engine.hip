@@ -94,14 +94,15 @@ struct BwdStep {
     long copy_elems_per_sb = 0;   // ST_COPY: channels to copy (prefix), dst/src channel counts differ for concat
     // ST_EW: symbolic chain (resolved to pointers at run time)
     struct Sym { int type; int action; int t0; int x_t; float f; int op; int slot; bool tap; };
-    std::vector<Sym> chain;
+    std::vector<Sym> chain;   // ST_EW: the chain; ST_CONV_BWD: epilogue chain fused into the GEMM (may be empty)
     int ew_t = -1;     // tensor whose shape the chain runs over
 };
 
 struct BwdPlan {
     int seed_tensor = -1;
     int mode = -1;
-    std::vector<BwdStep> steps;
+    std::vector<BwdStep> steps;      // one launch per step, no cross-kernel fusion (used when tracing)
+    std::vector<BwdStep> fused;      // after copy forwarding and chain -> GEMM-epilogue fusion
     std::vector<int> firing_kinds;   // xfr_op_kind per firing, reference order
     int n_firings = 0;
 };
@@ -137,6 +138,8 @@ struct xfr_engine {
     std::vector<BwdPlan> plans;
     // trace / profile
     int trace_on = 0;
+    bool fuse_gemm_epilogue = false;   // XFR_FUSE_GEMM=1: also run hook chains inside the backward GEMM epilogue (measured slower)
+    bool no_fuse = false;          // XFR_NO_FUSE=1: one launch per schedule step (A/B and debugging)
     int last_trace_firings = 0, last_trace_sb = 0;
     std::vector<int> last_trace_kinds;
     int profile_on = 0;
@@ -787,6 +790,132 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan)
     return fail(XFR_STATE_ERROR, "backward schedule never reached the first layer's output");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-kernel fusion of the backward schedule.
+//   1. copy forwarding: a full-tensor gradient copy (Add / functional-add VJP) becomes an alias; the first later
+//      writer that accumulated into the copy's destination instead adds the alias source in its chain (EW_ADDP).
+//   2. chain -> chain: EW(a->b) followed by EW(b->c) becomes one launch (with an EW_STORE of b if b has other readers).
+//   3. GEMM -> chain: a non-scattering backward-data GEMM whose output only feeds a chain runs that chain in its
+//      epilogue, so the gradient between two GEMMs is never written to HBM un-hooked.
+void fuse_plan(xfr_engine* e, BwdPlan& plan)
+{
+    typedef BwdStep::Sym Sym;
+    std::vector<BwdStep> st = plan.steps;
+    const int nt = (int)e->tens.size();
+    auto mk = [](int type, int t0) { Sym s; s.type = type; s.action = 0; s.t0 = t0; s.x_t = -1; s.f = 0.f; s.op = -1; s.slot = -1; s.tap = false; return s; };
+    auto scatter_conv = [&](const BwdStep& b) { return b.kind == ST_CONV_BWD && e->ops[b.op].d.stride != 1; };
+    auto reads = [&](const BwdStep& b, int t) {
+        if (b.kind != ST_ZERO && b.src_t == t) return true;
+        for (const Sym& y : b.chain) if (y.type == EW_ADDP && y.t0 == t) return true;
+        if (b.accumulate && b.dst_t == t) return true;
+        return false;
+    };
+    auto writes = [&](const BwdStep& b, int t) {
+        if (b.dst_t == t) return true;
+        for (const Sym& y : b.chain) if (y.type == EW_STORE && y.t0 == t) return true;
+        return false;
+    };
+    // ---- 1. copy forwarding
+    {
+        std::vector<BwdStep> out;
+        std::vector<int> alias(nt, -1);
+        for (size_t i = 0; i < st.size(); ++i) {
+            BwdStep b = st[i];
+            // readers use the alias
+            if (b.kind != ST_ZERO && b.src_t >= 0 && alias[b.src_t] >= 0) b.src_t = alias[b.src_t];
+            const int d = b.dst_t;
+            if (b.kind == ST_COPY && !b.accumulate && d >= 0 && e->tens[d].C == e->tens[b.src_t].C &&
+                b.copy_elems_per_sb == e->tens[d].C) {
+                // forward only if every later accumulating writer of d can take an addend in its chain
+                bool ok = true;
+                bool later_writer = false, later_reader = false;
+                for (size_t j = i + 1; j < st.size() && ok; ++j) {
+                    const BwdStep& c = st[j];
+                    if (c.dst_t == d) {
+                        later_writer = true;
+                        if (!c.accumulate) { ok = false; break; }
+                        if (!(c.kind == ST_EW || (c.kind == ST_CONV_BWD && !scatter_conv(c)))) ok = false;
+                        break;   // after the first physical writer the tensor is real again
+                    }
+                    if (c.kind != ST_ZERO && c.src_t == d) later_reader = true;
+                }
+                (void)later_writer; (void)later_reader;
+                if (ok) { alias[d] = b.src_t; continue; }
+            }
+            if (d >= 0 && alias[d] >= 0) {
+                // first physical writer of an aliased tensor: it was an accumulate; turn it into "+ alias source"
+                if (b.accumulate) {
+                    b.accumulate = 0;
+                    b.chain.insert(b.chain.begin(), mk(EW_ADDP, alias[d]));
+                    if (b.kind == ST_CONV_BWD) b.ew_t = d;
+                }
+                alias[d] = -1;
+            }
+            out.push_back(b);
+        }
+        st.swap(out);
+    }
+    // ---- 2 + 3, to a fixed point
+    bool changed = true;
+    while (changed) {
+        changed = false;
+        for (size_t i = 0; i < st.size() && !changed; ++i) {
+            BwdStep& a = st[i];
+            const bool a_ew = a.kind == ST_EW;
+            const bool a_conv = e->fuse_gemm_epilogue && a.kind == ST_CONV_BWD && !scatter_conv(a);
+            if (!a_ew && !a_conv) continue;
+            const int b_t = a.dst_t;
+            if (b_t < 0) continue;
+            bool tap_inside = false;
+            for (const Sym& y : a.chain) if (y.tap) tap_inside = true;
+            if (tap_inside) continue;                       // the tap launch is the last one
+            // next step that touches b_t
+            size_t j = i + 1;
+            for (; j < st.size(); ++j)
+                if (reads(st[j], b_t) || writes(st[j], b_t)) break;
+            if (j >= st.size()) continue;
+            BwdStep& c = st[j];
+            if (c.kind != ST_EW || c.src_t != b_t || writes(c, b_t)) continue;
+            if (e->tens[c.ew_t].C != e->tens[b_t].C || e->tens[c.ew_t].HW() != e->tens[b_t].HW()) continue;
+            // does anything after j still read b_t?
+            bool other_readers = false;
+            for (size_t k = j + 1; k < st.size(); ++k) {
+                if (reads(st[k], b_t)) { other_readers = true; break; }
+                if (writes(st[k], b_t)) break;
+            }
+            // the merged launch runs at position i: nothing in (i, j) may write c's destination or read/write what the
+            // merged chain stores
+            const int u = c.dst_t;
+            bool blocked = false;
+            for (size_t k = i + 1; k < j; ++k)
+                if (writes(st[k], u) || reads(st[k], u)) blocked = true;
+            // ADDP sources of c must be final before position i
+            for (const Sym& y : c.chain)
+                if (y.type == EW_ADDP)
+                    for (size_t k = i; k < j; ++k)
+                        if (writes(st[k], y.t0)) blocked = true;
+            if (blocked) continue;
+            std::vector<Sym> merged = a.chain;
+            if (a.accumulate) {
+                // a accumulates into b_t (partial sums already there): fold as an addend, then continue
+                merged.push_back(mk(EW_ADDP, b_t));
+            }
+            if (other_readers || a.accumulate) merged.push_back(mk(EW_STORE, b_t));
+            merged.insert(merged.end(), c.chain.begin(), c.chain.end());
+            if (c.accumulate) merged.push_back(mk(EW_ADDP, u));
+            if ((int)merged.size() > XFR_MAX_EW_STEPS) continue;
+            a.chain = merged;
+            a.dst_t = u;
+            a.accumulate = 0;
+            if (a.kind == ST_CONV_BWD) a.ew_t = b_t;
+            st.erase(st.begin() + j);
+            changed = true;
+        }
+    }
+    plan.fused.swap(st);
+}
+
 xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out)
 {
     for (auto& p : e->plans)
@@ -794,8 +923,34 @@ xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out)
     e->plans.emplace_back();
     xfr_status st = make_plan(e, seed_tensor, e->plans.back());
     if (st != XFR_OK) { e->plans.pop_back(); return st; }
+    fuse_plan(e, e->plans.back());
     *out = &e->plans.back();
     return XFR_OK;
+}
+
+void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain& ch, double* trace, int SB)
+{
+    ch.n = 0;
+    for (const auto& sy : syms) {
+        EwStep& q = ch.s[ch.n++];
+        memset(&q, 0, sizeof(q));
+        q.type = sy.type;
+        q.action = sy.action;
+        q.f = sy.f;
+        switch (sy.type) {
+            case EW_HOOK:
+                q.p0 = e->T(sy.t0);
+                q.p1 = sy.x_t >= 0 ? e->Pv(sy.x_t) : nullptr;
+                if (sy.tap) q.pstore = e->ws + e->tap_off;
+                if (e->trace_on && sy.slot >= 0 && trace) q.trace = trace + (size_t)sy.slot * SB;
+                break;
+            case EW_MASK: q.p0 = e->T(sy.t0); break;
+            case EW_SCALE_C: q.p0 = e->arena + e->ops[sy.op].bn_alpha_p; break;
+            case EW_STORE: q.pstore = e->G(sy.t0); break;
+            case EW_ADDP: q.p0 = e->G(sy.t0); break;
+            default: break;
+        }
+    }
 }
 
 xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t s)
@@ -808,28 +963,12 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
         e->last_trace_sb = SB;
         e->last_trace_kinds = plan.firing_kinds;
     }
-    for (const BwdStep& st : plan.steps) {
+    const bool use_fused = !e->trace_on && !e->no_fuse && !plan.fused.empty();
+    for (const BwdStep& st : (use_fused ? plan.fused : plan.steps)) {
         switch (st.kind) {
             case ST_EW: {
                 EwChain ch;
-                ch.n = 0;
-                for (const auto& sy : st.chain) {
-                    EwStep& q = ch.s[ch.n++];
-                    memset(&q, 0, sizeof(q));
-                    q.type = sy.type;
-                    q.action = sy.action;
-                    q.f = sy.f;
-                    if (sy.type == EW_HOOK) {
-                        q.p0 = e->T(sy.t0);
-                        q.p1 = sy.x_t >= 0 ? e->Pv(sy.x_t) : nullptr;
-                        if (sy.tap) q.pstore = e->ws + e->tap_off;
-                        if (e->trace_on && sy.slot >= 0) q.trace = trace + (size_t)sy.slot * SB;
-                    } else if (sy.type == EW_MASK) {
-                        q.p0 = e->T(sy.t0);
-                    } else if (sy.type == EW_SCALE_C) {
-                        q.p0 = e->arena + e->ops[sy.op].bn_alpha_p;
-                    }
-                }
+                resolve_chain(e, st.chain, ch, trace, SB);
                 const Tensor& x = e->tens[st.ew_t];
                 launch_ew_chain(e->G(st.src_t), e->G(st.dst_t), st.accumulate, ch, x.C, SB, B, x.HW(), e->eps, s);
                 break;
@@ -867,6 +1006,12 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                     p.accumulate = 1;   // the target was zero-filled or already holds other contributions
                 }
                 p.M = SB * p.OH * p.OW;
+                if (!st.chain.empty()) {
+                    resolve_chain(e, st.chain, p.chain, nullptr, SB);
+                    p.chain_B = B;
+                    p.chain_eps = e->eps;
+                    p.accumulate = 0;
+                }
                 xfr_status rs = run_conv(e, p, s);
                 if (rs != XFR_OK) return rs;
                 break;
@@ -985,6 +1130,8 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     if (ops[0].kind != XFR_OP_CONV || ops[0].in0 != 0)
         return fail(XFR_UNSUPPORTED_LAYER, "the first layer must be a convolution on the input image");
     xfr_engine* e = new xfr_engine();
+    e->no_fuse = getenv("XFR_NO_FUSE") != nullptr;
+    e->fuse_gemm_epilogue = getenv("XFR_FUSE_GEMM") != nullptr;
     e->device = device; e->max_batch = max_batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
     xfr_status st = build(e, ops, n_ops);
     if (st == XFR_OK) st = layout_arena(e);
