@@ -176,7 +176,15 @@ xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n,
  * The two encode forwards run as one 2N-image batch, concurrently (internal streams, joined before the backward
  * sweep) with the probe forward.  sal_dev: N x H1 x W1. */
 xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const float* gallery_dev, int32_t n,
-                                   int32_t encode_tensor, float scale, float percentile, float* sal_dev, void* stream);
+                                   int32_t encode_tensor, float scale, float percentile, float* sal_dev, void* stream,
+                                   int32_t inputs_ready);
+
+/* Cross-call pipelining of xfr_triplet_contrastive (off by default).  When enabled, the engine keeps two forward slots
+ * and the forwards of call i+1 start as soon as the slot they overwrite is free, i.e. they overlap the backward
+ * sweep of call i (for calls made with inputs_ready = 1); results still appear in order on `stream`.  This is the steady state of the reference's job loop
+ * (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:200-215: independent jobs, inputs loaded ahead).
+ * Costs one extra copy of the forward workspace.  Synchronises the device. */
+xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
 
 /* _mwp_to_saliency (whitebox.py:448-460, ebp_ver 6) on N pooled maps: in N x H x W -> out N x H x W. */
 xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w,

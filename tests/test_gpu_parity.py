@@ -221,6 +221,19 @@ def test_triplet_step_equals_two_call_path(gpu_device):
         assert float((got - want).abs().max()) <= 1e-6 * float(want.max())
         again = wb.triplet_images_ebp_batch(probes, mates, nonmates, percentile=pct)
         assert torch.equal(got, again)        # deterministic, and the stream join is race-free
+    # cross-call pipelining: a stream of different batches gives the same maps as one-by-one execution
+    eng = wb._engine(2 * n)
+    batches = [(probes, mates, nonmates), (mates, nonmates, probes), (nonmates, probes, mates), (probes, nonmates, mates)]
+    ref = [wb.triplet_images_ebp_batch(*b).clone() for b in batches]
+    gal = [torch.cat((b[1], b[2]), dim=0) for b in batches]
+    torch.cuda.synchronize()                       # inputs_ready contract: inputs valid before the calls
+    eng.set_pipeline(True)
+    outs = [wb.triplet_images_ebp_batch(b[0], None, None, gallery=g, inputs_ready=True) for b, g in list(zip(batches, gal)) * 2]
+    outs += [wb.triplet_images_ebp_batch(*b) for b in batches]      # inputs produced on the stream: still correct
+    torch.cuda.synchronize()
+    eng.set_pipeline(False)
+    for i, o in enumerate(outs):
+        assert torch.equal(o, ref[i % len(batches)]), 'pipelined call %d differs' % i
 
 
 def test_engine_argument_errors(gpu_device):

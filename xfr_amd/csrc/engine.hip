@@ -164,8 +164,22 @@ struct xfr_engine {
     size_t t_region_floats = 0;
     hipStream_t s_a = nullptr, s_b = nullptr;
     hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b = nullptr;
-    float* T(int t) { const Tensor& x = tens[t]; return (t_bank ? t_bank : ws) + tens[x.alias >= 0 ? root(t) : t].t_off; }
-    float* Pv(int t) { return ws + tens[t].pv_off; }
+    // cross-step pipelining (xfr_engine_set_pipeline): two forward slots (T, Pv, norms, argmax) so that the forward of
+    // triplet call i+1 may run while the backward sweep of call i still reads slot i%2
+    bool pipeline = false;
+    int cur_slot = 0;
+    long seq = 0;
+    float* ws2 = nullptr;
+    uint8_t* idx_ws2 = nullptr;
+    size_t fwd_region_floats = 0;
+    float* seedbuf[2] = {nullptr, nullptr};
+    hipEvent_t ev_slot_done[2] = {nullptr, nullptr};
+    bool slot_pending[2] = {false, false};
+    float* fwd_base() { return cur_slot ? ws2 : ws; }
+    uint8_t* idx_base() { return cur_slot ? idx_ws2 : idx_ws; }
+    float* T(int t) { const Tensor& x = tens[t]; return (t_bank ? t_bank : fwd_base()) + tens[x.alias >= 0 ? root(t) : t].t_off; }
+    float* Pv(int t) { return fwd_base() + tens[t].pv_off; }
+    float* misc() { return fwd_base() + misc_off; }
     float* G(int t) { return ws + tens[t].g_off; }
     int root(int t) const { while (tens[t].alias >= 0) t = tens[t].alias; return t; }
 };
@@ -382,6 +396,16 @@ xfr_status allocate(xfr_engine* e)
         Tensor& x = e->tens[t];
         if (x.pstate == PS_OTHER) x.pv_off = take(B * x.per_n());
     }
+    // normalize norms live in the forward region too (written by the forward, read by the backward)
+    size_t misc = 0;
+    size_t idxb = 0;
+    for (auto& o : e->ops) {
+        if (o.d.kind == XFR_OP_G_NORMALIZE) { o.norm_off = misc; misc += align_up(B, 64); }
+        if (o.d.kind == XFR_OP_MAXPOOL) { o.idx_off = idxb; idxb += align_up(B * e->tens[o.d.out].per_n(), 256); }
+    }
+    e->misc_off = take(std::max<size_t>(misc, 64));
+    take(4096);
+    e->fwd_region_floats = off;
     for (size_t t = 1; t < e->tens.size(); ++t) e->tens[t].g_off = take(2 * B * e->tens[t].per_n());
     size_t max_per_n = 0;
     for (auto& x : e->tens) max_per_n = std::max(max_per_n, (size_t)x.per_n());
@@ -392,14 +416,6 @@ xfr_status allocate(xfr_engine* e)
     e->blur_a_off = take(2 * B * std::max(t1.HW(), 1));
     e->blur_b_off = take(2 * B * std::max(t1.HW(), 1));
     e->thr_off = take(B);
-    // misc: normalize norms
-    size_t misc = 0;
-    size_t idxb = 0;
-    for (auto& o : e->ops) {
-        if (o.d.kind == XFR_OP_G_NORMALIZE) { o.norm_off = misc; misc += align_up(B, 64); }
-        if (o.d.kind == XFR_OP_MAXPOOL) { o.idx_off = idxb; idxb += align_up(B * e->tens[o.d.out].per_n(), 256); }
-    }
-    e->misc_off = take(std::max<size_t>(misc, 64));
     take(4096);   // slack: vector loads of a tile's dead columns may run past the last tensor
     e->ws_floats = off;
     e->idx_bytes = std::max<size_t>(idxb, 256);
@@ -586,7 +602,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
             launch_relu(e->T(d.in0), e->T(d.out), n_in, s);
             return XFR_OK;
         case XFR_OP_MAXPOOL:
-            launch_maxpool_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->idx_ws + o.idx_off, a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, d.pad, s);
+            launch_maxpool_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->idx_base() + o.idx_off, a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, d.pad, s);
             return XFR_OK;
         case XFR_OP_AVGPOOL:
             launch_avgpool_fwd(e->T(d.in0), e->T(d.out), a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, 0, s);
@@ -608,7 +624,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
             launch_maxhalves_fwd(e->T(d.in0), e->T(d.out), t.C, (long)B * t.HW(), 0, s);
             return XFR_OK;
         case XFR_OP_G_NORMALIZE:
-            launch_normalize_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->ws + e->misc_off + o.norm_off, t.C, B, 0, s);
+            launch_normalize_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->misc() + o.norm_off, t.C, B, 0, s);
             return XFR_OK;
     }
     return fail(XFR_UNSUPPORTED_LAYER, "forward: unsupported kind %d", d.kind);
@@ -1092,7 +1108,7 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                 const xfr_op_desc& d = o.d;
                 const Tensor& a = e->tens[d.in0];
                 const Tensor& t = e->tens[d.out];
-                launch_maxpool_bwd(e->G(st.src_t), e->idx_ws + o.idx_off, e->G(st.dst_t), st.accumulate, a.C, SB, B, a.H, a.W, t.H,
+                launch_maxpool_bwd(e->G(st.src_t), e->idx_base() + o.idx_off, e->G(st.dst_t), st.accumulate, a.C, SB, B, a.H, a.W, t.H,
                                    t.W, d.kh, d.stride, d.pad, s);
                 break;
             }
@@ -1118,7 +1134,7 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                 const OpRec& o = e->ops[st.op];
                 const xfr_op_desc& d = o.d;
                 const Tensor& t = e->tens[d.out];
-                launch_normalize_bwd(e->G(st.src_t), e->T(d.in0), e->ws + e->misc_off + o.norm_off, e->G(st.dst_t), st.accumulate,
+                launch_normalize_bwd(e->G(st.src_t), e->T(d.in0), e->misc() + o.norm_off, e->G(st.dst_t), st.accumulate,
                                      t.C, SB, B, s);
                 break;
             }
@@ -1224,6 +1240,9 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->dbl_ws) (void)hipFree(e->dbl_ws);
     if (e->trunc_ws) (void)hipFree(e->trunc_ws);
     if (e->ws_enc) (void)hipFree(e->ws_enc);
+    if (e->ws2) (void)hipFree(e->ws2);
+    if (e->idx_ws2) (void)hipFree(e->idx_ws2);
+    for (int i = 0; i < 2; ++i) { if (e->seedbuf[i]) (void)hipFree(e->seedbuf[i]); if (e->ev_slot_done[i]) (void)hipEventDestroy(e->ev_slot_done[i]); }
     if (e->s_a) (void)hipStreamDestroy(e->s_a);
     if (e->s_b) (void)hipStreamDestroy(e->s_b);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -1410,7 +1429,8 @@ xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n, int32_t
 }
 
 xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const float* gallery_dev, int32_t n,
-                                   int32_t encode_tensor, float scale, float percentile, float* sal_dev, void* stream)
+                                   int32_t encode_tensor, float scale, float percentile, float* sal_dev, void* stream,
+                                   int32_t inputs_ready)
 {
     xfr_status st = check_run(e, probes_dev, n);
     if (st != XFR_OK) return st;
@@ -1434,20 +1454,33 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     // The gallery encodes (2n images, true weights only) and the probe forward (n images, W and relu(W)) are
     // independent until the backward sweep needs its seeds: run them on two streams so their small layer-3/4 grids
     // fill each other's idle CUs.  With profiling on, everything is serialised on the caller's stream instead.
+    // In pipeline mode the forwards do not wait for the caller's stream at all (only for the slot they overwrite), so
+    // the forward of call i+1 overlaps the backward sweep of call i.
     const bool fork = !e->profile_on;
+    const bool pipe = fork && e->pipeline;
     hipStream_t sa = fork ? e->s_a : s, sb = fork ? e->s_b : s;
+    e->cur_slot = pipe ? (int)(e->seq++ & 1) : 0;
+    const int slot = e->cur_slot;
     if (fork) {
-        HIP_TRY(hipEventRecord(e->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(sa, e->ev_fork, 0));
-        HIP_TRY(hipStreamWaitEvent(sb, e->ev_fork, 0));
+        if (pipe && inputs_ready) {
+            if (e->slot_pending[slot]) {       // the backward that last read this slot must be done
+                HIP_TRY(hipStreamWaitEvent(sa, e->ev_slot_done[slot], 0));
+                HIP_TRY(hipStreamWaitEvent(sb, e->ev_slot_done[slot], 0));
+            }
+        } else {                               // order the forwards after everything already on the caller's stream
+            HIP_TRY(hipEventRecord(e->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(sa, e->ev_fork, 0));
+            HIP_TRY(hipStreamWaitEvent(sb, e->ev_fork, 0));
+        }
     }
+    const Tensor& sd = e->tens[encode_tensor];
+    float* seed_dst = pipe ? e->seedbuf[slot] : e->G(encode_tensor);
     e->t_bank = e->ws_enc;
     st = forward_all(e, gallery_dev, 2 * n, encode_tensor, false, sa);
-    const Tensor& sd = e->tens[encode_tensor];
     // seeds: stream 0 = scale * encode(mate_i), stream 1 = scale * encode(nonmate_i)  (demo/test_whitebox.py:129 with the
     // one-hot priors of whitebox.py:512,518 folded through the un-hooked 2-way classifier).  Layouts coincide:
     // both are [D][2n][1].
-    if (st == XFR_OK) launch_scale(e->T(encode_tensor), e->G(encode_tensor), (long)sd.per_n() * 2 * n, scale, 0, sa);
+    if (st == XFR_OK) launch_scale(e->T(encode_tensor), seed_dst, (long)sd.per_n() * 2 * n, scale, 0, sa);
     e->t_bank = nullptr;
     if (st != XFR_OK) return st;
     st = forward_all(e, probes_dev, n, encode_tensor, true, sb);
@@ -1458,11 +1491,38 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
         HIP_TRY(hipStreamWaitEvent(s, e->ev_a, 0));
         HIP_TRY(hipStreamWaitEvent(s, e->ev_b, 0));
     }
+    if (pipe) launch_copy_acc(seed_dst, e->G(encode_tensor), (long)sd.per_n() * 2 * n, 0, s);
     st = run_backward(e, *plan, n, 2, s);
     if (st != XFR_OK) return st;
     st = contrastive_tail(e, n, percentile, sal_dev, s);
     if (st != XFR_OK) return st;
+    if (pipe) {
+        HIP_TRY(hipEventRecord(e->ev_slot_done[slot], s));
+        e->slot_pending[slot] = true;
+    }
+    e->cur_slot = 0;
     return prof_end(e, s);
+}
+
+xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (enable && !e->ws2) {
+        HIP_TRY(hipMalloc(&e->ws2, e->fwd_region_floats * sizeof(float)));
+        HIP_TRY(hipMalloc(&e->idx_ws2, e->idx_bytes));
+        size_t max_per_n = 0;
+        for (auto& x : e->tens) max_per_n = std::max(max_per_n, (size_t)x.per_n());
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipMalloc(&e->seedbuf[i], 2 * (size_t)e->max_batch * max_per_n * sizeof(float)));
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_slot_done[i], hipEventDisableTiming));
+        }
+    }
+    e->pipeline = enable != 0;
+    e->slot_pending[0] = e->slot_pending[1] = false;
+    e->seq = 0;
+    return XFR_OK;
 }
 
 xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w, float* sal_dev, void* stream)

@@ -147,8 +147,10 @@ class Engine(object):
                                                 sal.data_ptr(), _stream_ptr(self.device)))
         return sal
 
-    def triplet_contrastive(self, probes, gallery, encode_tensor, scale=1.0 / 2500.0, percentile=None):
-        """probes N x C x H x W, gallery 2N x C x H x W (mates then non-mates) -> N x H1 x W1 saliency maps."""
+    def triplet_contrastive(self, probes, gallery, encode_tensor, scale=1.0 / 2500.0, percentile=None, inputs_ready=False):
+        """probes N x C x H x W, gallery 2N x C x H x W (mates then non-mates) -> N x H1 x W1 saliency maps.
+        inputs_ready=True: both tensors are already valid on the device (not pending on the current stream) and will not be
+        modified or freed until the result has been consumed -- required for cross-call pipelining (set_pipeline)."""
         probes = self._prep(probes)
         n = probes.shape[0]
         gallery = gallery.detach().to(self.device, torch.float32).contiguous()
@@ -159,8 +161,13 @@ class Engine(object):
         pct = -1.0 if percentile is None else float(percentile)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.xfr_triplet_contrastive(self._h, probes.data_ptr(), gallery.data_ptr(), n, int(encode_tensor),
-                                                        float(scale), pct, sal.data_ptr(), _stream_ptr(self.device)))
+                                                        float(scale), pct, sal.data_ptr(), _stream_ptr(self.device),
+                                                        1 if inputs_ready else 0))
         return sal
+
+    def set_pipeline(self, on):
+        """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
+        _lib.check(self.lib.xfr_engine_set_pipeline(self._h, 1 if on else 0))
 
     def mwp_to_saliency(self, pooled):
         pooled = pooled.detach().to(self.device, torch.float32).contiguous()

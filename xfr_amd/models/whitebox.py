@@ -344,15 +344,17 @@ class Whitebox(object):
                              torch.as_tensor(x_nonmates, dtype=torch.float32).reshape(n, -1)), dim=0)
         return eng.contrastive(img_probes, prog_marks['encode'], seeds, percentile)
 
-    def triplet_images_ebp_batch(self, img_probes, img_mates, img_nonmates, scale=1.0 / 2500.0, percentile=None):
+    def triplet_images_ebp_batch(self, img_probes, img_mates, img_nonmates, scale=1.0 / 2500.0, percentile=None,
+                                 gallery=None, inputs_ready=False):
         """The whole triplet step of demo/test_whitebox.py:124-133 for N triplets given as images: encode the mates and
         non-mates, install scale*encoding as the per-triplet 2-way classifier, (truncated) contrastive EBP of the probes.
         Returns N x H x W float32 (torch, on the engine device)."""
         n = img_probes.shape[0]
         self.net.default_max_batch = max(self.net.default_max_batch, 2 * n)
         eng = self._engine(2 * n)
-        gallery = torch.cat((img_mates.to(eng.device), img_nonmates.to(eng.device)), dim=0)
-        return eng.triplet_contrastive(img_probes, gallery, self.net._program.marks['encode'], scale, percentile)
+        if gallery is None:       # [mates; non-mates] as one 2N-image batch (pass `gallery` to avoid the copy)
+            gallery = torch.cat((img_mates.to(eng.device), img_nonmates.to(eng.device)), dim=0)
+        return eng.triplet_contrastive(img_probes, gallery, self.net._program.marks['encode'], scale, percentile, inputs_ready)
 
     def layerwise_ebp(self, *args, **kwargs):
         raise NotImplementedError('layerwise_ebp (whitebox.py:561-581) is a "next" row of the scope table')
