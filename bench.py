@@ -50,15 +50,84 @@ def cpu_baseline(sd, probes, mates, nonmates, mode, budget_s=25.0):
             'sample': '%d ResNet-101 triplet(s) (2 encodes + contrastive_ebp each), batch 1, %.1f s' % (n, dt)}
 
 
+def secondary(args, dev, rank, world):
+    """BASELINE.json configs[2] (VGGFace2 ResNet-50-128d truncated contrastive EBP, batch 64, mode norelu) and configs[3]
+    (Light-CNN-29v2 plain EBP, batch 128, 80013-way hooked classifier, mode affineonly).  Same timing contract."""
+    import torch
+    from xfr_amd import synth
+    from xfr_amd.engine import Engine
+    from xfr_amd.models import lightcnn, resnet50_128
+    if args.model == 'resnet50_128':
+        B = args.batch if args.batch != 32 else 64
+        mode = args.mode or 'norelu'
+        bb = resnet50_128.Resnet50_128()
+        flops = 6 * 7.712e9
+        prog = bb.build_program()
+        eng = Engine(prog, 2 * B, dev)
+        eng.load_weights(synth.synth_state_dict(bb, seed=0))
+        eng.set_mode(mode)
+        eng.set_pipeline(True)
+        imgs = synth.synth_images(3 * B, (3, 224, 224), seed=1234 + rank, mean=(131.0912, 103.8827, 91.4953)).to(dev)
+        gallery, probes = imgs[:2 * B].contiguous(), imgs[2 * B:].contiguous()
+        enc_t = prog.marks['encode']
+        step = lambda: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, 20.0, inputs_ready=True)   # noqa: E731
+        metric = 'triplet truncated-contrastive-EBP (20 %) saliency maps/sec, VGGFace2 ResNet-50-128d 224x224'
+        work = 'ResNet-50-128d truncated contrastive EBP, batch=%d synthetic triplets per GPU, mode %s' % (B, mode)
+    else:
+        B = args.batch if args.batch != 32 else 128
+        mode = args.mode or 'affineonly'
+        bb = lightcnn.LightCNN_29Layers_v2(num_classes=80013)
+        flops = 3 * 7.234e9
+        prog = bb.build_program()
+        eng = Engine(prog, B, dev)
+        eng.load_weights(synth.synth_state_dict(bb, seed=0))
+        eng.set_mode(mode)
+        x = synth.synth_images(B, (1, 128, 128), seed=1234 + rank, scale255=False).to(dev)
+        seed = torch.zeros((1, B, 80013), device=dev)
+        seed[0, :, 0] = 1.0
+        cls_t = prog.marks['classify']
+
+        def step():
+            _, pooled = eng.ebp(x, cls_t, seed, want_mwp=False, want_pooled=True)
+            return eng.mwp_to_saliency(pooled[0])
+        metric = 'EBP saliency maps/sec, Light-CNN-29v2 128x128 (80013-way hooked classifier)'
+        work = 'Light-CNN-29v2 excitation backprop, batch=%d synthetic images per GPU, mode %s' % (B, mode)
+    for _ in range(args.warmup):
+        sal = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sal = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.isfinite(sal).all().item()) and abs(float(sal[0].sum().item()) - 1.0) < 1e-3
+    eng.set_profile(True)
+    step()
+    ms, nl, fl = eng.get_profile()
+    eng.set_profile(False)
+    if rank == 0:
+        ach = flops * B / (ms * 1e-3) / 1e12
+        print(json.dumps({'metric': metric, 'value': world * B * args.steps / dt, 'unit': 'maps/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': work}, 'outputs_ok': ok,
+                          'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA / 1e12, 'unit': 'TFLOP/s',
+                                       'frac': ach / (PEAK_F32_MFMA / 1e12), 'traffic': None, 'launches_per_step': nl,
+                                       'gemm_ms_per_step': ms}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=32, help='triplets per GPU per step')
-    ap.add_argument('--mode', default='affineonly_with_prior')
+    ap.add_argument('--mode', default=None)
+    ap.add_argument('--model', default='resnet101', choices=['resnet101', 'resnet50_128', 'lightcnn'],
+                    help='resnet101 = the BASELINE.json headline; the other two are its secondary configurations')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--serial', action='store_true', help='run every step on ONE stream with per-GEMM HIP events (what the roofline figure is measured on); use under rocprofv3 so that kernel durations are not inflated by concurrent streams')
     ap.add_argument('--no-pipeline', action='store_true', help='do not overlap step i+1 forwards with step i backward')
     args = ap.parse_args()
 
@@ -75,6 +144,10 @@ def main():
             sys.exit(2)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    if args.model != 'resnet101':
+        return secondary(args, dev, rank, world)
+    if args.mode is None:
+        args.mode = 'affineonly_with_prior'
     B = args.batch
 
     bb = resnet.ResNet([3, 4, 23, 3], num_classes=2)   # fc2 is replaced by the per-triplet classifier anyway
@@ -114,6 +187,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.serial:
+        eng.set_profile(True)
     for _ in range(args.warmup):
         sal = step()
     barrier()
@@ -128,6 +203,8 @@ def main():
         dt = float(t.item())
     ok = bool(torch.isfinite(sal).all().item()) and abs(float(sal[0].sum().item()) - 1.0) < 1e-3
 
+    if args.serial:
+        eng.set_profile(False)
     roof = None
     if not args.no_profile:
         # live GEMM timing: HIP events around every conv_gemm launch on the launch stream, separate steps after the
