@@ -236,6 +236,28 @@ def test_triplet_step_equals_two_call_path(gpu_device):
         assert torch.equal(o, ref[i % len(batches)]), 'pipelined call %d differs' % i
 
 
+def test_weight_arena_is_a_zero_copy_view(gpu_device):
+    """The multi-GPU path broadcasts INTO the arena tensor: it must alias the engine's memory, not copy it."""
+    import ctypes
+    from xfr_amd import _lib
+    bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=5)
+    subj = GC.engine_subject('stresnet_mini', bb, 'affineonly_with_prior')
+    eng = subj.wb._engine(1)
+    arena = eng.weight_arena()
+    p, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
+    _lib.check(eng.lib.xfr_engine_weight_arena(eng._h, ctypes.byref(p), ctypes.byref(nbytes)))
+    assert arena.data_ptr() == p.value and arena.numel() == nbytes.value and arena.dtype == torch.uint8
+    # a second engine that only RECEIVES the arena (rank != 0) computes the same maps
+    from xfr_amd.engine import Engine
+    x = make_images('stresnet_mini', 2).to(gpu_device)
+    want = eng.forward(x, subj.wb.net._program.marks['encode'])
+    e2 = Engine(subj.wb.net._program, 32, gpu_device)
+    e2.weight_arena().copy_(arena)
+    e2.mark_weights_loaded()
+    got = e2.forward(x, subj.wb.net._program.marks['encode'])
+    assert torch.equal(got, want)
+
+
 def test_engine_argument_errors(gpu_device):
     bb, _ = make_backbone('stresnet_mini', num_classes=5)
     subj = GC.engine_subject('stresnet_mini', bb, 'affineonly_with_prior')

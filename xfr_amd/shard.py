@@ -16,6 +16,8 @@ def dist_env():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if 'XFR_FORCE_DEVICE' in os.environ:      # test hook: several ranks on one GPU (gloo)
+        local = int(os.environ['XFR_FORCE_DEVICE'])
     return rank, world, local
 
 
@@ -25,7 +27,7 @@ def init_process_group(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('XFR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
