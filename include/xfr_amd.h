@@ -166,6 +166,12 @@ xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n,
                            int32_t seed_tensor, const float* seed_dev, float percentile,
                            float* sal_dev, void* stream);
 
+/* As xfr_contrastive, but stops before _mwp_to_saliency: contrast_dev (N x H1 x W1) receives `mwp_contrastive` /
+ * `mwp_truncated_contrastive` (whitebox.py:526 / :557), for callers that apply the uint8 + PIL blur of ebp_version != 6
+ * (whitebox.py:451-454) on the host. */
+xfr_status xfr_contrastive_raw(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                               float percentile, float* contrast_dev, void* stream);
+
 /* One whole triplet step for N independent (mate, non-mate, probe) triplets -- demo/test_whitebox.py:124-133:
  *     x_mate = encode(mate); x_nonmate = encode(nonmate)                         (:71-72)
  *     set_triplet_classifier(scale * x_mate, scale * x_nonmate)                  (:129, scale = 1/2500)

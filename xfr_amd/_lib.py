@@ -38,6 +38,7 @@ SYMBOLS = [
     ('xfr_forward', _I, [_P, _P, _I, _I, _P, _P]),
     ('xfr_ebp', _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     ('xfr_contrastive', _I, [_P, _P, _I, _I, _P, _F, _P, _P]),
+    ('xfr_contrastive_raw', _I, [_P, _P, _I, _I, _P, _F, _P, _P]),
     ('xfr_triplet_contrastive', _I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I]),
     ('xfr_engine_set_pipeline', _I, [_P, _I]),
     ('xfr_mwp_to_saliency', _I, [_P, _P, _I, _I, _I, _P, _P]),

@@ -1394,7 +1394,7 @@ xfr_status xfr_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32_t n_strea
     return prof_end(e, s);
 }
 
-static xfr_status contrastive_tail(xfr_engine* e, int n, float percentile, float* sal_dev, hipStream_t s)
+static xfr_status contrastive_tail(xfr_engine* e, int n, float percentile, float* sal_dev, hipStream_t s, bool raw = false)
 {
     const Tensor& t1 = e->tens[1];
     const float* P = e->ws + e->tap_off;
@@ -1405,9 +1405,9 @@ static xfr_status contrastive_tail(xfr_engine* e, int n, float percentile, float
         thr = e->ws + e->thr_off;
         launch_truncation_threshold(P, sums, percentile, thr, e->trunc_ws, t1.C, n, t1.HW(), s);
     }
-    float* contrast = e->ws + e->blur_a_off;
+    float* contrast = raw ? sal_dev : e->ws + e->blur_a_off;
     launch_contrast(P, sums, thr, contrast, t1.C, n, t1.HW(), s);
-    launch_saliency_blur(contrast, e->ws + e->blur_b_off, sal_dev, n, t1.H, t1.W, e->eps, s);
+    if (!raw) launch_saliency_blur(contrast, e->ws + e->blur_b_off, sal_dev, n, t1.H, t1.W, e->eps, s);
     HIP_TRY(hipGetLastError());
     return XFR_OK;
 }
@@ -1424,6 +1424,22 @@ xfr_status xfr_contrastive(xfr_engine* e, const float* x_dev, int32_t n, int32_t
     st = ebp_core(e, x_dev, n, 2, seed_tensor, seed_dev, s);
     if (st != XFR_OK) return st;
     st = contrastive_tail(e, n, percentile, sal_dev, s);
+    if (st != XFR_OK) return st;
+    return prof_end(e, s);
+}
+
+xfr_status xfr_contrastive_raw(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                               float percentile, float* contrast_dev, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, n);
+    if (st != XFR_OK) return st;
+    if (!contrast_dev) return fail(XFR_INVALID_ARG, "null output");
+    if (percentile > 100.f) return fail(XFR_INVALID_ARG, "percentile must be <= 100 (or < 0 for plain contrastive)");
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(e);
+    st = ebp_core(e, x_dev, n, 2, seed_tensor, seed_dev, s);
+    if (st != XFR_OK) return st;
+    st = contrastive_tail(e, n, percentile, contrast_dev, s, true);
     if (st != XFR_OK) return st;
     return prof_end(e, s);
 }

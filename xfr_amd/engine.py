@@ -131,8 +131,9 @@ class Engine(object):
                                         pooled.data_ptr() if want_pooled else None, _stream_ptr(self.device)))
         return mwp, pooled
 
-    def contrastive(self, x, seed_tensor, seed, percentile=None):
-        """seed: 2 x N x D (mate, non-mate).  Returns N x H1 x W1 saliency maps."""
+    def contrastive(self, x, seed_tensor, seed, percentile=None, raw=False):
+        """seed: 2 x N x D (mate, non-mate).  Returns N x H1 x W1 saliency maps (raw=True: the contrastive MWP before
+        _mwp_to_saliency)."""
         x = self._prep(x)
         n = x.shape[0]
         seed = seed.detach().to(self.device, torch.float32).contiguous()
@@ -143,8 +144,8 @@ class Engine(object):
         sal = torch.empty((n, h1, w1), device=self.device)
         pct = -1.0 if percentile is None else float(percentile)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.xfr_contrastive(self._h, x.data_ptr(), n, int(seed_tensor), seed.data_ptr(), pct,
-                                                sal.data_ptr(), _stream_ptr(self.device)))
+            fn = self.lib.xfr_contrastive_raw if raw else self.lib.xfr_contrastive
+            _lib.check(fn(self._h, x.data_ptr(), n, int(seed_tensor), seed.data_ptr(), pct, sal.data_ptr(), _stream_ptr(self.device)))
         return sal
 
     def triplet_contrastive(self, probes, gallery, encode_tensor, scale=1.0 / 2500.0, percentile=None, inputs_ready=False):

@@ -315,20 +315,24 @@ class Whitebox(object):
 
     def contrastive_ebp(self, img_probe, k_poschannel, k_negchannel):
         """Contrastive excitation backprop (whitebox.py:506-527); per sample when N > 1."""
-        if self.convert_saliency_uint8:
-            raise NotImplementedError('xfr_amd implements ebp_version 6 saliency for contrastive EBP')
         n = img_probe.shape[0]
         eng = self._engine(n)
         seed_tensor, seeds = self._class_seeds(n, k_poschannel, k_negchannel)
+        if self.convert_saliency_uint8:      # ebp_version != 6: uint8 + PIL blur on the host (whitebox.py:451-454)
+            raw = eng.contrastive(img_probe, seed_tensor, seeds, None, raw=True).cpu().numpy()
+            out = np.stack([self._mwp_to_saliency(r) for r in raw])
+            return out[0] if n == 1 else out
         return self._squeeze(eng.contrastive(img_probe, seed_tensor, seeds, None))
 
     def truncated_contrastive_ebp(self, img_probe, k_poschannel, k_negchannel, percentile=20):
         """Truncated contrastive excitation backprop (whitebox.py:529-558)."""
-        if self.convert_saliency_uint8:
-            raise NotImplementedError('xfr_amd implements ebp_version 6 saliency for contrastive EBP')
         n = img_probe.shape[0]
         eng = self._engine(n)
         seed_tensor, seeds = self._class_seeds(n, k_poschannel, k_negchannel)
+        if self.convert_saliency_uint8:
+            raw = eng.contrastive(img_probe, seed_tensor, seeds, float(percentile), raw=True).cpu().numpy()
+            out = np.stack([self._mwp_to_saliency(r) for r in raw])
+            return out[0] if n == 1 else out
         return self._squeeze(eng.contrastive(img_probe, seed_tensor, seeds, float(percentile)))
 
     # -- additive batched API --------------------------------------------------------------------------------
