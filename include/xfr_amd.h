@@ -196,6 +196,38 @@ xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
 xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w,
                                float* sal_dev, void* stream);
 
+/* ---- "next" row: layerwise_ebp / weighted_subtree_ebp (whitebox.py:561-581, 647-737) ------------------------------------
+ * Firing indices are positions in Whitebox.P (reference order); the last one computed here is P[-2]. */
+
+/* Number of hook firings of a sweep seeded at `seed_tensor` (= len(Whitebox.P) - 1: the image hook is not computed). */
+xfr_status xfr_firing_count(xfr_engine* e, int32_t seed_tensor, int32_t* n_firings);
+
+/* whitebox.py:652-697: true-weight gradients of the two classifier outputs at every hooked module input (the `dA`
+ * lists of the 'activation'-mode `_savegrad` hooks, :355-358), reduced per firing k to
+ *     w[k] = max((g0[k] >= 0) * (-g1[k])),  idx[k] = argmax (flattened c,h,w index)          (gate_ge0 = 1, :689-690)
+ *     w[k] = max((g0[k] <  0) * (-g1[k]))   with g0 = gradient of the cross-entropy loss          (gate_ge0 = 0, :693-694)
+ * seed_dev: 2 x N x D gradient seeds at seed_tensor (stream 0 -> g0, stream 1 -> g1 = y[0][1]); w_host / idx_host:
+ * n_firings x N host arrays.  Synchronises `stream`. */
+xfr_status xfr_subtree_weights(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                               int32_t gate_ge0, float* w_host, int32_t* idx_host, int32_t capacity, void* stream);
+
+/* One standard EBP sweep (whitebox.py:567) of ONE image that returns P[k].flatten()[elem[k]] for every firing k
+ * (elem_host[k] < 0: skip) -- the values layerwise_ebp(mode='elementwise') turns into priors (:575-577).  Synchronises. */
+xfr_status xfr_ebp_capture(xfr_engine* e, const float* x_dev, int32_t seed_tensor, const float* seed_dev, const int32_t* elem_host,
+                           float* p_host, int32_t n_firings, void* stream);
+
+/* whitebox.py:570-581 for a BATCH of layers of one image: sweep j re-runs ebp(img, 0*P0) with P_prior[firing[j]] set to a
+ * tensor that is zero except element elem[j] = val[j] (mode 'elementwise'), or to dense_prior_dev (n_sweeps == 1; mode
+ * 'argmax').  The forward is shared; the sweeps form the gradient batch.  pooled_dev: n_sweeps x H1 x W1 channel-pooled P[-2]. */
+xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n_sweeps, int32_t seed_tensor, const int32_t* firing_host,
+                             const int32_t* elem_host, const float* val_host, const float* dense_prior_dev, float* pooled_dev,
+                             void* stream);
+
+/* Whitebox.P[firing] of a standard EBP sweep (whitebox.py:394): out_dev receives N x C x H x W; (c,h,w) receive its shape
+ * (out_dev == NULL: shape query only, nothing is run). */
+xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                                int32_t firing, float* out_dev, int32_t* c, int32_t* h, int32_t* w, void* stream);
+
 /* Debug / parity: after an xfr_ebp call made while tracing is enabled, the per-firing trace
  * sum(P[i]) (what the golden fixtures store for every entry of Whitebox.P, whitebox.py:394).
  * xfr_engine_set_trace(e, 1) makes xfr_ebp record it (slower).  `sums` receives n_firings x S x N doubles

@@ -280,6 +280,32 @@ class Tape(object):
         return P, names
 
 
+    def true_gradients(self, seed_tensor, seed):
+        """The `dA` list of whitebox.py:355-358: in 'activation' mode every hooked module input carries a plain tensor hook
+        `_savegrad` that records its (true-weight) gradient; one entry per hook firing, same order as Whitebox.P."""
+        hooks = self.hooks_by_tensor()
+        G = {seed_tensor: seed.detach().clone().float()}
+        dA = []
+        for k in range(len(self.calls) - 1, -1, -1):
+            c = self.calls[k]
+            if c.out not in G:
+                continue
+            for _ in hooks.get(c.out, []):
+                dA.append(G[c.out])
+            g_out = G.pop(c.out)
+            ins = [self.T[i].detach().clone().requires_grad_(True) for i in c.ins]
+            with torch.enable_grad():
+                out = c.fn(ins, False)
+                gins = torch.autograd.grad(out, ins, g_out, allow_unused=True)
+            for i, gi in zip(c.ins, gins):
+                if gi is None:
+                    continue
+                G[i] = G[i] + gi if i in G else gi
+        for _ in hooks.get(0, []):
+            dA.append(G[0])
+        return dA
+
+
 # ---------------------------------------------------------------------------------------------
 # Backbones (forward functions restated from the reference definitions)
 # ---------------------------------------------------------------------------------------------
@@ -515,3 +541,65 @@ class OracleWhitebox(object):
         t = F.relu(mask * mwp_mate - mask * mwp_nonmate)
         c = np.squeeze(np.sum(t.numpy(), axis=1).astype(np.float32))
         return mwp_to_saliency(c, self.eps)
+
+    def _scale_normalized(self, img):
+        img = np.float32(img)
+        return (img - np.min(img)) / (self.eps + (np.max(img) - np.min(img)))
+
+    def layerwise_ebp(self, x, k_layer, mode='argmax', k_element=None, k_poschannel=0, mwp=True):
+        """whitebox.py:561-581"""
+        P0 = self._onehot(x, k_poschannel)
+        self.ebp(x, P0)
+        P_mate = self.P
+        if mode == 'argmax':
+            prior = P_mate[k_layer] * (1.0 - torch.ne(P_mate[k_layer], torch.max(P_mate[k_layer])).float())
+        elif mode == 'elementwise':
+            assert k_element is not None
+            Pf = (0 * (P_mate[k_layer].detach().clone())).flatten()
+            Pf[k_element] = P_mate[k_layer].flatten()[k_element]
+            prior = Pf.reshape(P_mate[k_layer].shape)
+        else:
+            raise ValueError('invalid layerwise EBP mode "%s"' % mode)
+        return self.ebp(x, 0.0 * P0, mwp=mwp, priors={int(k_layer): prior})
+
+    def weighted_subtree_ebp(self, x, k_poschannel, k_negchannel, topk=1, do_max_subtree=False,
+                             do_mated_similarity_gating=True, subtree_mode='norelu', do_mwp_to_saliency=True):
+        """whitebox.py:647-737 (ebp_ver 6 branches)."""
+        self.mode = subtree_mode
+        tape, out = self._run(x, 'classify')
+        C = tape.T[out].shape[1]
+        y = tape.T[out]
+        if not do_mated_similarity_gating:
+            g = torch.softmax(y, dim=1).clone()
+            g[0, 0] -= 1.0                                  # d cross_entropy(y, [0]) / dy
+            gradlist_ce = tape.true_gradients(out, g)
+        e0 = torch.zeros((1, C)); e0[0, 0] = 1.0
+        e1 = torch.zeros((1, C)); e1[0, 1] = 1.0
+        gradlist_mated = tape.true_gradients(out, e0)
+        gradlist_nonmated = tape.true_gradients(out, e1)
+        P_img, P_subtree, P_subtree_idx = [], [], []
+        n_layers = len(gradlist_mated)
+        for k in range(0, n_layers - 1):
+            if do_mated_similarity_gating:
+                v = torch.mul(gradlist_mated[k] >= 0, -gradlist_nonmated[k])
+            else:
+                v = torch.mul(gradlist_ce[k] < 0, -gradlist_nonmated[k])
+            P_subtree.append(float(torch.max(v)))
+            P_subtree_idx.append(torch.argmax(v))
+        k_subtree = np.argsort(np.array(P_subtree))
+        for k in k_subtree:
+            P_img.append(self.layerwise_ebp(x, k_layer=k, k_poschannel=k_poschannel, k_element=P_subtree_idx[k], mode='elementwise'))
+        k_valid = [np.max(P) > 0 for P in P_img]
+        k_subtree_valid = [k for (k, v) in zip(k_subtree, k_valid) if v == True and k != 1][-topk:]   # noqa: E712
+        if len(k_subtree_valid) == 0:
+            raise RuntimeError('Failed to calculate valid subtrees.')
+        P_img_valid = [p for (p, k, v) in zip(P_img, k_subtree, k_valid) if v == True and k != 1][-topk:]  # noqa: E712
+        P_subtree_valid = [P_subtree[k] for k in k_subtree_valid]
+        sn = self._scale_normalized(P_subtree_valid)
+        P_subtree_valid_norm = sn if not np.sum(sn) == 0 else np.ones_like(P_subtree_valid)
+        stack = np.dstack([float(w) * np.array(P) * (1.0 / (np.max(P) + 1E-12)) for (w, P) in zip(P_subtree_valid_norm, P_img_valid)])
+        smap = np.max(stack, axis=2) if do_max_subtree else np.sum(stack, axis=2)
+        smap /= max(smap.sum(), self.eps)
+        return (mwp_to_saliency(smap, self.eps) if do_mwp_to_saliency else smap,
+                [mwp_to_saliency(P, self.eps) if do_mwp_to_saliency else P for P in P_img_valid],
+                P_subtree_valid, k_subtree_valid)

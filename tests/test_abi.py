@@ -71,5 +71,3 @@ def test_whitebox_constructor_errors_match_reference():
     wb = WB.Whitebox(net, ebp_version=11)
     assert wb._ebp_with_bias is True and wb.convert_saliency_uint8 is True      # whitebox.py:285-289
     assert WB.Whitebox(net).ebp_subtree_mode() == 'affineonly_with_prior' and WB.Whitebox(net).eps == 1e-16
-    with pytest.raises(NotImplementedError):
-        wb.weighted_subtree_ebp(None, 0, 1)

@@ -62,3 +62,24 @@ def test_lightcnn_ebp_affineonly():
     GC.replay(GC.oracle_subject('lightcnn29v2', sd, 'affineonly'), GC.lcnn_cases('affineonly'), gold, check)
     cases = GC.lcnn_cases('affineonly_with_prior', which=['triplet/contrastive'])
     GC.replay(GC.oracle_subject('lightcnn29v2', sd, 'affineonly_with_prior'), cases, gold, check)
+
+
+def test_weighted_subtree_and_layerwise_mini():
+    """"next" row (whitebox.py:561-581, 647-737): the oracle's restatement against the reference's own outputs."""
+    torch.set_num_threads(8)
+    from oracle import ebp_oracle as O
+    from parity_utils import make_images
+    g = GC.golden('golden_subtree_mini')
+    bb, sd = make_backbone('stresnet_mini', seed=3, recipe='mild', num_classes=5)
+    x = make_images('stresnet_mini', 1, seed=5)
+    ow = O.OracleWhitebox('stresnet_mini', sd, ('hooked', None), 'norelu')
+    ow.set_triplet_classifier(synth.unit_rows(1, 512, seed=1) / 2500, synth.unit_rows(1, 512, seed=2) / 2500)
+    smap, P_valid, w_valid, k_valid = ow.weighted_subtree_ebp(x, 0, 1, topk=8, subtree_mode='norelu')
+    key = 'mini/norelu/top8'
+    assert [int(k) for k in k_valid] == [int(k) for k in g[key + '/k_valid']]
+    assert np.allclose(np.array(w_valid), g[key + '/w_valid'], rtol=ORACLE_TOL)
+    assert map_metrics(smap, g[key + '/map'])[0] <= ORACLE_TOL
+    for k in (5, 20, 40):
+        got = ow.layerwise_ebp(x, k_layer=k, mode='argmax', k_poschannel=0, mwp=True)
+        want = g['mini/norelu/layerwise_argmax_%d' % k]
+        assert np.abs(got - want).max() <= ORACLE_TOL * max(np.abs(want).max(), 1e-30)

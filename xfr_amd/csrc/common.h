@@ -28,6 +28,7 @@ enum {
     EW_FORK_POSBN = 8 // pstore[g] = max(g,0)*p0[c] + p1[c]         (positive-pass BatchNorm output, g unchanged)
 };
 enum { HOOK_DIV = 0, HOOK_RELU = 1, HOOK_PASS = 2 };
+enum { PRIOR_DIV = 0, PRIOR_PASS = 1, PRIOR_GATEZ = 2 };   // p/(x+eps) | gradient unchanged | (prior>0)*z
 
 struct EwStep {
     int type;
@@ -37,6 +38,16 @@ struct EwStep {
     float* pstore;     // HOOK: if non-null, p is stored here (g-index);  STORE / FORK_POSBN: destination
     double* trace;     // HOOK: if non-null, sum(p) per (stream,sample) is accumulated at trace[sb] (stand-alone kernels only)
     float f;           // SCALE: factor
+    // HOOK extras for layerwise EBP (whitebox.py:390-392,406-419): sample `prior_sb` has its p OVERRIDDEN by a prior at
+    // this firing -- a single element (prior_elem, prior_val; c*HW+hw within the sample) or a dense tensor prior_dense
+    int prior_sb;      // -1: no prior at this firing
+    int prior_action;  // PRIOR_* : what the hook returns for that sample
+    int prior_elem;
+    float prior_val;
+    const float* prior_dense;
+    // HOOK: capture p of one element (g-index) into *cap_dst (stand-alone kernels only)
+    long cap_idx;
+    float* cap_dst;
 };
 
 struct EwChain {
@@ -111,6 +122,10 @@ void launch_normalize_bwd(const float* gout, const float* tin, const float* norm
 // seed [S][N][D] (D = C*HW, NCHW order inside a sample) -> gradient tensor [C][S*N][HW]
 void launch_seed_to_cnhw(const float* seed, float* g, int SB, int C, int HW, hipStream_t s);
 void launch_fill(float* p, long n, float v, hipStream_t s);
+// per sample n: v = (gate_ge0 ? gm >= 0 : gm < 0) * (-gn) over the C*HW elements of gm = G[:, n], gn = G[:, N+n] (two gradient streams);
+// vmax[n] = max v, vidx[n] = smallest c*HW+hw attaining it   (whitebox.py:689-690)
+void launch_subtree_stats(const float* G, float* vmax, int* vidx, void* scratch, int C, int N, int HW, int gate_ge0, hipStream_t s);
+size_t subtree_stats_scratch_bytes(int N);
 
 // ---- saliency post-processing --------------------------------------------------------------------------------
 // pooled[sb][hw] = sum_c P[c][sb][hw]

@@ -60,13 +60,29 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                     const float a = fmaxf(st.p0[aidx], 0.f);
                     const float zh = fmaxf(g, 0.f);
                     p = a * zh;
-                    if (st.pstore) st.pstore[idx] = p;
-                    if (st.action == HOOK_DIV) {
-                        const float x = st.p1 ? fmaxf(st.p1[aidx], 0.f) : a;
-                        g = __fdiv_rn(p, x + eps);
-                    } else if (st.action == HOOK_RELU) {
-                        g = zh;
+                    if (st.prior_sb >= 0 && sb == st.prior_sb) {
+                        // layerwise EBP: p is overridden by the prior (whitebox.py:390-392)
+                        const int hw_ = (int)((idx - (long)c * per_c) - (long)sb * HW);
+                        const int el = c * HW + hw_;
+                        const float pr = st.prior_dense ? st.prior_dense[el] : (el == st.prior_elem ? st.prior_val : 0.f);
+                        p = pr;
+                        if (st.pstore) st.pstore[idx] = p;
+                        if (st.prior_action == PRIOR_DIV) {
+                            const float x = st.p1 ? fmaxf(st.p1[aidx], 0.f) : a;
+                            g = __fdiv_rn(p, x + eps);
+                        } else if (st.prior_action == PRIOR_GATEZ) {
+                            g = pr > 0.f ? g : 0.f;
+                        }
+                    } else {
+                        if (st.pstore) st.pstore[idx] = p;
+                        if (st.action == HOOK_DIV) {
+                            const float x = st.p1 ? fmaxf(st.p1[aidx], 0.f) : a;
+                            g = __fdiv_rn(p, x + eps);
+                        } else if (st.action == HOOK_RELU) {
+                            g = zh;
+                        }
                     }
+                    if (st.cap_dst && idx == st.cap_idx) *st.cap_dst = p;
                 }
                 if (TRACE && st.trace) {
                     // per-(stream,sample) sum of p; a block may straddle samples when HW < NT, so reduce per lane
@@ -496,15 +512,79 @@ __global__ __launch_bounds__(NT) void seed_to_cnhw_kernel(const float* __restric
     }
 }
 
+// weighted-subtree layer weights (whitebox.py:689-690): max / first argmax of (gm >= 0) * (-gn) per sample
+struct StatPartial { float v; int i; };
+
+__global__ __launch_bounds__(NT) void subtree_stats_kernel(const float* __restrict__ G, StatPartial* __restrict__ part, int C,
+                                                          int N, int HW, int chunks, int gate_ge0)
+{
+    const int n = blockIdx.y;
+    const long total = (long)C * HW;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)chunks * NT) {
+        const int c = (int)(e / HW);
+        const int hw = (int)(e - (long)c * HW);
+        const float gm = G[((long)c * 2 * N + n) * HW + hw];
+        const float gn = G[((long)c * 2 * N + N + n) * HW + hw];
+        const float v = ((gate_ge0 ? gm >= 0.f : gm < 0.f) ? 1.f : 0.f) * (-gn);
+        if (v > best || (v == best && (int)e < bi)) { best = v; bi = (int)e; }
+    }
+    __shared__ float sv[NT];
+    __shared__ int si[NT];
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float v2 = sv[threadIdx.x + o];
+            const int i2 = si[threadIdx.x + o];
+            if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v2; si[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[(long)n * chunks + blockIdx.x].v = sv[0]; part[(long)n * chunks + blockIdx.x].i = si[0]; }
+}
+
+__global__ void subtree_stats_final_kernel(const StatPartial* __restrict__ part, float* __restrict__ vmax, int* __restrict__ vidx,
+                                           int chunks)
+{
+    const int n = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = 0; k < chunks; ++k) {
+        const StatPartial q = part[(long)n * chunks + k];
+        if (q.v > best || (q.v == best && q.i < bi)) { best = q.v; bi = q.i; }
+    }
+    vmax[n] = best;
+    vidx[n] = bi;
+}
+
+constexpr int STAT_CHUNKS = 64;
+
 }  // namespace
+
+size_t subtree_stats_scratch_bytes(int N) { return sizeof(StatPartial) * (size_t)N * STAT_CHUNKS; }
+
+void launch_subtree_stats(const float* G, float* vmax, int* vidx, void* scratch, int C, int N, int HW, int gate_ge0, hipStream_t s)
+{
+    StatPartial* part = reinterpret_cast<StatPartial*>(scratch);
+    hipLaunchKernelGGL(subtree_stats_kernel, dim3(STAT_CHUNKS, N), dim3(NT), 0, s, G, part, C, N, HW, STAT_CHUNKS, gate_ge0);
+    hipLaunchKernelGGL(subtree_stats_final_kernel, dim3(N), dim3(64), 0, s, part, vmax, vidx, STAT_CHUNKS);
+}
 
 void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain& chain, int C, int SB, int B, int HW,
                      float eps, hipStream_t s)
 {
-    bool trace = false;
-    for (int i = 0; i < chain.n; ++i) if (chain.s[i].type == EW_HOOK && chain.s[i].trace) trace = true;
+    bool trace = false, special = false;
+    for (int i = 0; i < chain.n; ++i) {
+        if (chain.s[i].type != EW_HOOK) continue;
+        if (chain.s[i].trace) trace = true;
+        if (chain.s[i].prior_sb >= 0 || chain.s[i].cap_dst) special = true;
+    }
     const long total = (long)C * SB * HW;
-    if (!trace && (HW % 4) == 0) {
+    if (!trace && !special && (HW % 4) == 0) {
         hipLaunchKernelGGL(ew_chain_kernel_v4, dim3(grid_for(total / 4)), dim3(NT), 0, s,
                            reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), accumulate, chain, C, SB, B,
                            HW / 4, eps);

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -70,7 +71,7 @@ struct Tensor {
 struct OpRec {
     xfr_op_desc d;
     // packed parameter offsets (floats) into the arena; -1 if absent
-    long w_true = -1, w_pos = -1, w_bwd = -1;
+    long w_true = -1, w_pos = -1, w_bwd = -1, w_bwd_true = -1;   // w_bwd_true: true-weight backward pack (plain gradients)
     long b_true = -1, b_pos = -1;            // conv/linear bias and relu(bias)
     long bn_alpha_t = -1, bn_beta_t = -1, bn_alpha_p = -1, bn_beta_p = -1, bn_beta_pb = -1;
     int ldw = 0, ldb = 0;
@@ -101,6 +102,8 @@ struct BwdStep {
 struct BwdPlan {
     int seed_tensor = -1;
     int mode = -1;
+    bool plain = false;              // true-weight gradients without hooks (whitebox.py:652-676 dA lists)
+    std::vector<int> firing_tensor;  // tensor whose gradient each firing sees
     std::vector<BwdStep> steps;      // one launch per step, no cross-kernel fusion (used when tracing)
     std::vector<BwdStep> fused;      // after copy forwarding and chain -> GEMM-epilogue fusion
     std::vector<int> firing_kinds;   // xfr_op_kind per firing, reference order
@@ -135,9 +138,21 @@ struct xfr_engine {
     int with_bias = 0;
     bool need_dirty = true;
     // plans
-    std::vector<BwdPlan> plans;
+    std::deque<BwdPlan> plans;         // deque: get_plan() hands out pointers that must survive later insertions
     // trace / profile
     int trace_on = 0;
+    // per-call context of the backward sweep ("next" rows: layerwise / weighted-subtree EBP)
+    std::vector<int> rc_prior_sb, rc_prior_elem;      // per firing slot: sample with a prior (-1 none), its element
+    std::vector<float> rc_prior_val;
+    const float* rc_prior_dense = nullptr;            // dense prior tensor (single sweep) instead of (elem, val)
+    std::vector<long> rc_cap_idx;                     // per firing slot: g-index whose p is captured (-1 none)
+    float* cap_dev = nullptr;                         // [n_firings] captured values
+    float* stat_v = nullptr;                          // [n_firings][max_batch]
+    int* stat_i = nullptr;
+    void* stat_scratch = nullptr;
+    int store_slot = -1;                              // firing whose full P tensor is kept in store_dev
+    float* store_dev = nullptr;
+    int store_tensor = -1, store_sb = 0;
     std::vector<char> fwd_done;        // per forward pass: ops whose work was folded into an earlier GEMM epilogue
     std::vector<char> pos_done;        // ... and whose positive-pass output was produced there too
     int fwd_last_op = 0;
@@ -446,6 +461,7 @@ xfr_status layout_arena(xfr_engine* e)
             if (k != 0) {
                 o.ldb = (int)align_up(o.Cin, 128);
                 o.w_bwd = take(align_up(o.Kb, 32) * o.ldb);
+                o.w_bwd_true = take(align_up(o.Kb, 32) * o.ldb);
             }
             if (d.w_bias >= 0) { o.b_true = take(d.cout); o.b_pos = take(d.cout); }
         } else if (d.kind == XFR_OP_BATCHNORM) {
@@ -713,8 +729,9 @@ bool unary_elementwise(int kind)
     return kind == XFR_OP_RELU || kind == XFR_OP_BATCHNORM || kind == XFR_OP_MULTIPLY || kind == XFR_OP_SPLIT;
 }
 
-xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan)
+xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan, bool plain)
 {
+    plan.plain = plain;
     const int nt = (int)e->tens.size();
     plan.seed_tensor = seed_tensor;
     plan.mode = e->mode;
@@ -739,6 +756,7 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan)
     // firing order (reference): descending producer index, registration order within a tensor; image last
     std::vector<std::vector<int>> slot(nt);
     plan.firing_kinds.clear();
+    plan.firing_tensor.clear();
     for (int k = e->tens[seed_tensor].producer; k >= 0; --k) {
         const int t = e->ops[k].d.out;
         if (!reach[t]) continue;
@@ -746,6 +764,7 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan)
             if (e->ops[h.op].d.out > seed_tensor) { slot[t].push_back(-1); continue; }   // call beyond the seed
             slot[t].push_back((int)plan.firing_kinds.size());
             plan.firing_kinds.push_back(e->ops[h.op].d.kind);
+            plan.firing_tensor.push_back(t);
         }
     }
     plan.n_firings = (int)plan.firing_kinds.size();   // (+1 for the image hook of op 0, which is not computed)
@@ -758,6 +777,7 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan)
         for (size_t i = 0; i < x.hooks.size(); ++i) {
             const Hook& h = x.hooks[i];
             if (slot[t][i] < 0) continue;   // hook of a call that lies beyond the seed tensor
+            if (plain) continue;            // plain gradients: the _savegrad hooks only record
             const xfr_op_desc& hd = e->ops[h.op].d;
             BwdStep::Sym sy;
             sy.type = EW_HOOK;
@@ -1003,19 +1023,29 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
     plan.fused.swap(st);
 }
 
-xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out)
+xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out, bool plain = false)
 {
     for (auto& p : e->plans)
-        if (p.seed_tensor == seed_tensor && p.mode == e->mode) { *out = &p; return XFR_OK; }
+        if (p.seed_tensor == seed_tensor && p.mode == e->mode && p.plain == plain) { *out = &p; return XFR_OK; }
     e->plans.emplace_back();
-    xfr_status st = make_plan(e, seed_tensor, e->plans.back());
+    xfr_status st = make_plan(e, seed_tensor, e->plans.back(), plain);
     if (st != XFR_OK) { e->plans.pop_back(); return st; }
-    fuse_plan(e, e->plans.back());
+    if (!plain) fuse_plan(e, e->plans.back());
     *out = &e->plans.back();
     return XFR_OK;
 }
 
-void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain& ch, double* trace, int SB)
+int prior_action_for(int mode, int kind)
+{   // what the hook returns for a sample whose p was overridden by a prior (whitebox.py:396-428 with p_prior set)
+    switch (mode) {
+        case XFR_MODE_AFFINEONLY: return is_affine_name(kind) ? PRIOR_DIV : PRIOR_PASS;
+        case XFR_MODE_AFFINEONLY_WITH_PRIOR: return is_affine_name(kind) ? PRIOR_DIV : PRIOR_GATEZ;
+        case XFR_MODE_NORELU: return (kind == XFR_OP_MAXPOOL || kind == XFR_OP_RELU) ? PRIOR_PASS : PRIOR_DIV;
+        default: return PRIOR_DIV;
+    }
+}
+
+void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain& ch, double* trace, int SB, bool plain = false)
 {
     ch.n = 0;
     for (const auto& sy : syms) {
@@ -1024,15 +1054,31 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
         q.type = sy.type;
         q.action = sy.action;
         q.f = sy.f;
+        q.prior_sb = -1;
+        q.cap_idx = -1;
         switch (sy.type) {
             case EW_HOOK:
                 q.p0 = e->T(sy.t0);
                 q.p1 = sy.x_t >= 0 ? e->Pv(sy.x_t) : nullptr;
                 if (sy.tap) q.pstore = e->ws + e->tap_off;
                 if (e->trace_on && sy.slot >= 0 && trace) q.trace = trace + (size_t)sy.slot * SB;
+                if (sy.slot >= 0) {
+                    if (sy.slot == e->store_slot && !sy.tap) q.pstore = e->store_dev;
+                    if (sy.slot < (int)e->rc_prior_sb.size() && e->rc_prior_sb[sy.slot] >= 0) {
+                        q.prior_sb = e->rc_prior_sb[sy.slot];
+                        q.prior_elem = e->rc_prior_elem[sy.slot];
+                        q.prior_val = e->rc_prior_val[sy.slot];
+                        q.prior_dense = e->rc_prior_dense;
+                        q.prior_action = prior_action_for(e->mode, e->ops[sy.op].d.kind);
+                    }
+                    if (sy.slot < (int)e->rc_cap_idx.size() && e->rc_cap_idx[sy.slot] >= 0) {
+                        q.cap_idx = e->rc_cap_idx[sy.slot];
+                        q.cap_dst = e->cap_dev + sy.slot;
+                    }
+                }
                 break;
             case EW_MASK: q.p0 = e->T(sy.t0); break;
-            case EW_SCALE_C: q.p0 = e->arena + e->ops[sy.op].bn_alpha_p; break;
+            case EW_SCALE_C: q.p0 = e->arena + (plain ? e->ops[sy.op].bn_alpha_t : e->ops[sy.op].bn_alpha_p); break;
             case EW_STORE: q.pstore = e->G(sy.t0); break;
             case EW_ADDP: q.p0 = e->G(sy.t0); break;
             default: break;
@@ -1050,12 +1096,13 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
         e->last_trace_sb = SB;
         e->last_trace_kinds = plan.firing_kinds;
     }
-    const bool use_fused = !e->trace_on && !e->no_fuse && !plan.fused.empty();
+    const bool special = !e->rc_prior_sb.empty() || !e->rc_cap_idx.empty() || e->store_slot >= 0;
+    const bool use_fused = !e->trace_on && !e->no_fuse && !plan.fused.empty() && !plan.plain && !special;
     for (const BwdStep& st : (use_fused ? plan.fused : plan.steps)) {
         switch (st.kind) {
             case ST_EW: {
                 EwChain ch;
-                resolve_chain(e, st.chain, ch, trace, SB);
+                resolve_chain(e, st.chain, ch, trace, SB, plan.plain);
                 const Tensor& x = e->tens[st.ew_t];
                 launch_ew_chain(e->G(st.src_t), e->G(st.dst_t), st.accumulate, ch, x.C, SB, B, x.HW(), e->eps, s);
                 break;
@@ -1071,7 +1118,7 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                 ConvParams p;
                 memset(&p, 0, sizeof(p));
                 p.in = e->G(st.src_t);
-                p.w = e->arena + o.w_bwd;
+                p.w = e->arena + (plan.plain ? o.w_bwd_true : o.w_bwd);
                 p.out0 = e->G(st.dst_t);
                 p.Cin = t.C; p.H = t.H; p.W = t.W; p.NB = SB; p.in_nb = SB; p.out_nb = SB;
                 p.tap_major = (d.stride == 1 && o.tap_bwd) ? 1 : 0;
@@ -1241,6 +1288,11 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->trunc_ws) (void)hipFree(e->trunc_ws);
     if (e->ws_enc) (void)hipFree(e->ws_enc);
     if (e->ws2) (void)hipFree(e->ws2);
+    if (e->cap_dev) (void)hipFree(e->cap_dev);
+    if (e->stat_v) (void)hipFree(e->stat_v);
+    if (e->stat_i) (void)hipFree(e->stat_i);
+    if (e->stat_scratch) (void)hipFree(e->stat_scratch);
+    if (e->store_dev) (void)hipFree(e->store_dev);
     if (e->idx_ws2) (void)hipFree(e->idx_ws2);
     for (int i = 0; i < 2; ++i) { if (e->seedbuf[i]) (void)hipFree(e->seedbuf[i]); if (e->ev_slot_done[i]) (void)hipEventDestroy(e->ev_slot_done[i]); }
     if (e->s_a) (void)hipStreamDestroy(e->s_a);
@@ -1284,6 +1336,7 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
             if (o.w_bwd >= 0) {
                 // backward-data pack of relu(W): [k' = (co, kh', kw')][ci] with the kernel flipped
                 float* wb = host.data() + o.w_bwd;
+                float* wbt = host.data() + o.w_bwd_true;
                 for (int co = 0; co < d.cout; ++co)
                     for (int ci = 0; ci < o.Cin; ++ci)
                         for (int a = 0; a < d.kh; ++a)
@@ -1293,6 +1346,7 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
                                 const size_t kk = (o.tap_bwd && d.stride == 1) ? (size_t)(a2 * d.kw + b2) * d.cout + co
                                                                                : (size_t)(co * d.kh + a2) * d.kw + b2;
                                 wb[kk * o.ldb + ci] = v > 0.f ? v : 0.f;
+                                wbt[kk * o.ldb + ci] = v;
                             }
             }
             if (d.w_bias >= 0) {
@@ -1549,6 +1603,172 @@ xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     launch_saliency_blur(pooled_dev, e->ws + e->blur_b_off, sal_dev, n, h, w, e->eps, s);
+    HIP_TRY(hipGetLastError());
+    return XFR_OK;
+}
+
+// ---- "next" rows: layerwise / weighted-subtree EBP -----------------------------------------------------------------------
+static xfr_status ensure_subtree_scratch(xfr_engine* e)
+{
+    if (e->cap_dev) return XFR_OK;
+    const size_t nf = e->trace_cap + 1;
+    size_t max_per_n = 0;
+    for (auto& x : e->tens) max_per_n = std::max(max_per_n, (size_t)x.per_n());
+    HIP_TRY(hipMalloc(&e->cap_dev, nf * sizeof(float)));
+    HIP_TRY(hipMalloc(&e->stat_v, nf * e->max_batch * sizeof(float)));
+    HIP_TRY(hipMalloc(&e->stat_i, nf * e->max_batch * sizeof(int)));
+    HIP_TRY(hipMalloc(&e->stat_scratch, subtree_stats_scratch_bytes(e->max_batch)));
+    HIP_TRY(hipMalloc(&e->store_dev, 2 * (size_t)e->max_batch * max_per_n * sizeof(float)));
+    return XFR_OK;
+}
+
+xfr_status xfr_firing_count(xfr_engine* e, int32_t seed_tensor, int32_t* n_firings)
+{
+    if (!e || !n_firings) return fail(XFR_INVALID_ARG, "null argument");
+    if (e->need_dirty) compute_need(e);
+    BwdPlan* plan = nullptr;
+    xfr_status st = get_plan(e, seed_tensor, &plan);
+    if (st != XFR_OK) return st;
+    *n_firings = plan->n_firings;
+    return XFR_OK;
+}
+
+xfr_status xfr_subtree_weights(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                               int32_t gate_ge0, float* w_host, int32_t* idx_host, int32_t capacity, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, n);
+    if (st != XFR_OK) return st;
+    if (!seed_dev || !w_host || !idx_host) return fail(XFR_INVALID_ARG, "null argument");
+    st = ensure_subtree_scratch(e);
+    if (st != XFR_OK) return st;
+    hipStream_t s = (hipStream_t)stream;
+    BwdPlan* plan = nullptr;
+    st = get_plan(e, seed_tensor, &plan, true);
+    if (st != XFR_OK) return st;
+    const int nf = plan->n_firings;
+    if (capacity < nf * n) return fail(XFR_INVALID_ARG, "need room for %d x %d values", nf, n);
+    st = forward_all(e, x_dev, n, seed_tensor, false, s);
+    if (st != XFR_OK) return st;
+    const Tensor& sd = e->tens[seed_tensor];
+    launch_seed_to_cnhw(seed_dev, e->G(seed_tensor), 2 * n, sd.C, sd.HW(), s);
+    e->rc_prior_sb.clear(); e->rc_cap_idx.clear(); e->store_slot = -1;
+    st = run_backward(e, *plan, n, 2, s);
+    if (st != XFR_OK) return st;
+    int last_t = -1;
+    for (int f = 0; f < nf; ++f) {
+        const int t = plan->firing_tensor[f];
+        if (t == last_t) {          // several hooks on one tensor see the same gradient
+            HIP_TRY(hipMemcpyAsync(e->stat_v + (size_t)f * n, e->stat_v + (size_t)(f - 1) * n, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(e->stat_i + (size_t)f * n, e->stat_i + (size_t)(f - 1) * n, n * sizeof(int), hipMemcpyDeviceToDevice, s));
+        } else {
+            const Tensor& x = e->tens[t];
+            launch_subtree_stats(e->G(t), e->stat_v + (size_t)f * n, e->stat_i + (size_t)f * n, e->stat_scratch, x.C, n, x.HW(), gate_ge0, s);
+        }
+        last_t = t;
+    }
+    HIP_TRY(hipMemcpyAsync(w_host, e->stat_v, (size_t)nf * n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(idx_host, e->stat_i, (size_t)nf * n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return XFR_OK;
+}
+
+xfr_status xfr_ebp_capture(xfr_engine* e, const float* x_dev, int32_t seed_tensor, const float* seed_dev, const int32_t* elem_host,
+                           float* p_host, int32_t n_firings, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, 1);
+    if (st != XFR_OK) return st;
+    if (!seed_dev || !elem_host || !p_host) return fail(XFR_INVALID_ARG, "null argument");
+    st = ensure_subtree_scratch(e);
+    if (st != XFR_OK) return st;
+    hipStream_t s = (hipStream_t)stream;
+    BwdPlan* plan = nullptr;
+    st = get_plan(e, seed_tensor, &plan);
+    if (st != XFR_OK) return st;
+    if (n_firings != plan->n_firings) return fail(XFR_INVALID_ARG, "expected %d firings, got %d", plan->n_firings, n_firings);
+    e->rc_prior_sb.clear(); e->store_slot = -1;
+    e->rc_cap_idx.assign(n_firings, -1);
+    for (int f = 0; f < n_firings; ++f) {
+        const Tensor& x = e->tens[plan->firing_tensor[f]];
+        if (elem_host[f] >= 0 && elem_host[f] < x.per_n()) e->rc_cap_idx[f] = elem_host[f];   // SB == 1: g-index == c*HW+hw
+    }
+    HIP_TRY(hipMemsetAsync(e->cap_dev, 0, n_firings * sizeof(float), s));
+    st = ebp_core(e, x_dev, 1, 1, seed_tensor, seed_dev, s);
+    e->rc_cap_idx.clear();
+    if (st != XFR_OK) return st;
+    HIP_TRY(hipMemcpyAsync(p_host, e->cap_dev, n_firings * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return XFR_OK;
+}
+
+xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n_sweeps, int32_t seed_tensor, const int32_t* firing_host,
+                             const int32_t* elem_host, const float* val_host, const float* dense_prior_dev, float* pooled_dev,
+                             void* stream)
+{
+    xfr_status st = check_run(e, x_dev, 1);
+    if (st != XFR_OK) return st;
+    if (!firing_host || !pooled_dev) return fail(XFR_INVALID_ARG, "null argument");
+    if (n_sweeps < 1 || n_sweeps > 2 * e->max_batch) return fail(XFR_INVALID_ARG, "n_sweeps %d outside [1, %d]", n_sweeps, 2 * e->max_batch);
+    if (dense_prior_dev && n_sweeps != 1) return fail(XFR_INVALID_ARG, "a dense prior needs n_sweeps == 1");
+    if (!dense_prior_dev && (!elem_host || !val_host)) return fail(XFR_INVALID_ARG, "null prior arrays");
+    hipStream_t s = (hipStream_t)stream;
+    BwdPlan* plan = nullptr;
+    st = get_plan(e, seed_tensor, &plan);
+    if (st != XFR_OK) return st;
+    const int nf = plan->n_firings;
+    e->rc_cap_idx.clear(); e->store_slot = -1;
+    e->rc_prior_sb.assign(nf, -1);
+    e->rc_prior_elem.assign(nf, -1);
+    e->rc_prior_val.assign(nf, 0.f);
+    e->rc_prior_dense = dense_prior_dev;
+    for (int j = 0; j < n_sweeps; ++j) {
+        const int f = firing_host[j];
+        if (f < 0 || f >= nf) { e->rc_prior_sb.clear(); return fail(XFR_INVALID_ARG, "firing %d outside [0, %d)", f, nf); }
+        if (e->rc_prior_sb[f] >= 0) { e->rc_prior_sb.clear(); return fail(XFR_INVALID_ARG, "firing %d requested twice in one batch", f); }
+        e->rc_prior_sb[f] = j;
+        if (!dense_prior_dev) { e->rc_prior_elem[f] = elem_host[j]; e->rc_prior_val[f] = val_host[j]; }
+    }
+    // one forward for all sweeps (whitebox.py:581 runs ebp(img, 0*P0) again for every layer); zero seeds: all the
+    // gradient enters through the priors
+    st = forward_all(e, x_dev, 1, seed_tensor, true, s);
+    if (st == XFR_OK) {
+        const Tensor& sd = e->tens[seed_tensor];
+        launch_fill(e->G(seed_tensor), (long)sd.per_n() * n_sweeps, 0.f, s);
+        st = run_backward(e, *plan, 1, n_sweeps, s);
+    }
+    e->rc_prior_sb.clear();
+    e->rc_prior_dense = nullptr;
+    if (st != XFR_OK) return st;
+    const Tensor& t1 = e->tens[1];
+    launch_channel_pool(e->ws + e->tap_off, pooled_dev, t1.C, n_sweeps, t1.HW(), s);
+    HIP_TRY(hipGetLastError());
+    return XFR_OK;
+}
+
+xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                                int32_t firing, float* out_dev, int32_t* c, int32_t* h, int32_t* w, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, n);
+    if (st != XFR_OK) return st;
+    if (!seed_dev) return fail(XFR_INVALID_ARG, "null seed");
+    st = ensure_subtree_scratch(e);
+    if (st != XFR_OK) return st;
+    hipStream_t s = (hipStream_t)stream;
+    BwdPlan* plan = nullptr;
+    st = get_plan(e, seed_tensor, &plan);
+    if (st != XFR_OK) return st;
+    if (firing < 0 || firing >= plan->n_firings) return fail(XFR_INVALID_ARG, "firing %d outside [0, %d)", firing, plan->n_firings);
+    const Tensor& x = e->tens[plan->firing_tensor[firing]];
+    if (c) *c = x.C;
+    if (h) *h = x.H;
+    if (w) *w = x.W;
+    if (!out_dev) return XFR_OK;          // shape query
+    e->rc_prior_sb.clear(); e->rc_cap_idx.clear();
+    const bool is_tap = (firing == plan->n_firings - 1);
+    e->store_slot = is_tap ? -1 : firing;
+    st = ebp_core(e, x_dev, n, 1, seed_tensor, seed_dev, s);
+    e->store_slot = -1;
+    if (st != XFR_OK) return st;
+    launch_cnhw_to_nchw(is_tap ? e->ws + e->tap_off : e->store_dev, out_dev, n, x.C, x.HW(), s);
     HIP_TRY(hipGetLastError());
     return XFR_OK;
 }

@@ -179,6 +179,68 @@ class Engine(object):
                                                     _stream_ptr(self.device)))
         return out
 
+    # -- "next" row: layerwise / weighted-subtree EBP ---------------------------------------------------
+    def firing_count(self, seed_tensor):
+        n = ctypes.c_int32()
+        _lib.check(self.lib.xfr_firing_count(self._h, int(seed_tensor), ctypes.byref(n)))
+        return n.value
+
+    def subtree_weights(self, x, seed_tensor, seed, gate_ge0=True):
+        """seed 2 x N x D -> (w [n_firings, N] float32, idx [n_firings, N] int32)."""
+        x = self._prep(x)
+        n = x.shape[0]
+        seed = seed.detach().to(self.device, torch.float32).contiguous()
+        nf = self.firing_count(seed_tensor)
+        w = (ctypes.c_float * (nf * n))()
+        idx = (ctypes.c_int32 * (nf * n))()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_subtree_weights(self._h, x.data_ptr(), n, int(seed_tensor), seed.data_ptr(), 1 if gate_ge0 else 0,
+                                                    w, idx, nf * n, _stream_ptr(self.device)))
+        return (np.frombuffer(w, dtype=np.float32).reshape(nf, n).copy(), np.frombuffer(idx, dtype=np.int32).reshape(nf, n).copy())
+
+    def ebp_capture(self, x, seed_tensor, seed, elems):
+        """One image, seed 1 x 1 x D; elems[k] = flattened (c,h,w) element of firing k -> P[k].flatten()[elems[k]]."""
+        x = self._prep(x)
+        seed = seed.detach().to(self.device, torch.float32).contiguous()
+        nf = self.firing_count(seed_tensor)
+        el = (ctypes.c_int32 * nf)(*[int(v) for v in elems])
+        out = (ctypes.c_float * nf)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_ebp_capture(self._h, x.data_ptr(), int(seed_tensor), seed.data_ptr(), el, out, nf,
+                                                _stream_ptr(self.device)))
+        return np.frombuffer(out, dtype=np.float32).copy()
+
+    def layerwise(self, x, seed_tensor, firings, elems=None, vals=None, dense_prior=None):
+        """Batch of layerwise sweeps of one image -> J x H1 x W1 pooled P[-2]."""
+        x = self._prep(x)
+        J = len(firings)
+        fi = (ctypes.c_int32 * J)(*[int(v) for v in firings])
+        el = (ctypes.c_int32 * J)(*[int(v) for v in elems]) if elems is not None else None
+        va = (ctypes.c_float * J)(*[float(v) for v in vals]) if vals is not None else None
+        if dense_prior is not None:
+            dense_prior = dense_prior.detach().to(self.device, torch.float32).contiguous()
+        c1, h1, w1 = self.tensor_shape(1)
+        out = torch.empty((J, h1, w1), device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_layerwise_ebp(self._h, x.data_ptr(), J, int(seed_tensor), fi, el, va,
+                                                  dense_prior.data_ptr() if dense_prior is not None else None, out.data_ptr(),
+                                                  _stream_ptr(self.device)))
+        return out
+
+    def ebp_firing(self, x, seed_tensor, seed, firing):
+        """Whitebox.P[firing] of a standard sweep: N x C x H x W."""
+        x = self._prep(x)
+        n = x.shape[0]
+        seed = seed.detach().to(self.device, torch.float32).contiguous()
+        c, h, w = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_ebp_store_firing(self._h, x.data_ptr(), n, int(seed_tensor), seed.data_ptr(), int(firing), None,
+                                                     ctypes.byref(c), ctypes.byref(h), ctypes.byref(w), _stream_ptr(self.device)))
+            out = torch.empty((n, c.value, h.value, w.value), device=self.device)
+            _lib.check(self.lib.xfr_ebp_store_firing(self._h, x.data_ptr(), n, int(seed_tensor), seed.data_ptr(), int(firing),
+                                                     out.data_ptr(), None, None, None, _stream_ptr(self.device)))
+        return out
+
     # ------------------------------------------------------------------------------------------------
     def set_trace(self, on):
         _lib.check(self.lib.xfr_engine_set_trace(self._h, 1 if on else 0))

@@ -6,8 +6,9 @@ hooks and no autograd: every call is a few launches of the HIP engine (xfr_amd/c
 include/xfr_amd.h.  Additive API: `*_batch` methods that run many independent probes in one engine call
 (the reference is batch-1 only for contrastive EBP: whitebox.py:512,524).
 
-Not provided (outside the hot path): layerwise_ebp / weighted_subtree_ebp
-(whitebox.py:561-737, "next" row), Whitebox_senet50_256 (unsupported by the reference itself:
+Also provided ("next" row of the scope table): layerwise_ebp / weighted_subtree_ebp (whitebox.py:561-581, 647-737).
+Not provided (outside the hot path): layerwise_contrastive_ebp (deprecated by the reference itself,
+whitebox.py:587-588), Whitebox_senet50_256 (unsupported by the reference itself:
 whitebox.py:402-403), DataFrame / image_loader inputs of `embeddings`.
 """
 import numpy as np
@@ -360,11 +361,95 @@ class Whitebox(object):
             gallery = torch.cat((img_mates.to(eng.device), img_nonmates.to(eng.device)), dim=0)
         return eng.triplet_contrastive(img_probes, gallery, self.net._program.marks['encode'], scale, percentile, inputs_ready)
 
-    def layerwise_ebp(self, *args, **kwargs):
-        raise NotImplementedError('layerwise_ebp (whitebox.py:561-581) is a "next" row of the scope table')
+    def layerwise_ebp(self, img_probe, k_layer, mode='argmax', k_element=None, k_poschannel=0, mwp=True):
+        """Layerwise excitation backprop (whitebox.py:561-581): a standard EBP sweep picks the starting node of layer
+        `k_layer` (index into Whitebox.P), a second sweep with a zero seed propagates only that prior."""
+        assert (k_poschannel >= 0 and k_poschannel < self.net.num_classes())
+        assert img_probe.shape[0] == 1
+        eng = self._engine(1)
+        P0 = torch.zeros((1, self.net.num_classes()))
+        P0[0][k_poschannel] = 1.0
+        seed_tensor, seed = self.net.seed_for(P0, 1)
+        nf = eng.firing_count(seed_tensor)
+        if not (0 <= int(k_layer) < nf):
+            raise IndexError('k_layer %d outside the %d computed firings' % (k_layer, nf))
+        if mode == 'argmax':
+            Pk = eng.ebp_firing(img_probe, seed_tensor, seed.unsqueeze(0), int(k_layer))
+            prior = Pk * (1.0 - torch.ne(Pk, torch.max(Pk)).float())          # whitebox.py:572
+            pooled = eng.layerwise(img_probe, seed_tensor, [int(k_layer)], dense_prior=prior[0])
+        elif mode == 'elementwise':
+            assert (k_element is not None)
+            elems = [-1] * nf
+            elems[int(k_layer)] = int(k_element)
+            val = eng.ebp_capture(img_probe, seed_tensor, seed.unsqueeze(0), elems)[int(k_layer)]   # whitebox.py:575-577
+            pooled = eng.layerwise(img_probe, seed_tensor, [int(k_layer)], [int(k_element)], [float(val)])
+        else:
+            raise ValueError('invalid layerwise EBP mode "%s"' % mode)
+        P = np.squeeze(pooled[0].cpu().numpy()).astype(np.float32)
+        return self._mwp_to_saliency(P) if not mwp else P
 
-    def weighted_subtree_ebp(self, *args, **kwargs):
-        raise NotImplementedError('weighted_subtree_ebp (whitebox.py:647-737) is a "next" row of the scope table')
+    def weighted_subtree_ebp(self, img_probe, k_poschannel, k_negchannel, topk=1, verbose=True, do_max_subtree=False,
+                             do_mated_similarity_gating=True, subtree_mode='norelu', do_mwp_to_saliency=True, sweep_batch=None):
+        """Weighted subtree EBP (whitebox.py:647-737).  Same result as the reference, computed with: one true-weight
+        gradient pass for the layer weights (:652-697), ONE standard EBP sweep for all prior values (the reference repeats
+        it for every layer, :567), and layerwise sweeps batched on the GPU and evaluated lazily from the heaviest layer
+        downwards until `topk` valid subtrees exist (the reference sweeps all ~377 layers and keeps the last topk, :700-716)."""
+        assert img_probe.shape[0] == 1
+        self._ebp_subtree_mode = subtree_mode                                   # whitebox.py:651
+        eng = self._engine(1)
+        C = self.net.num_classes()
+        e0 = torch.zeros((1, C))
+        e0[0][0] = 1.0
+        e1 = torch.zeros((1, C))
+        e1[0][1] = 1.0
+        seed_tensor, s1 = self.net.seed_for(e1, 1)
+        if do_mated_similarity_gating:
+            _, s0 = self.net.seed_for(e0, 1)                                    # y[0][0].backward  (:668)
+        else:
+            y = self.net.classify(img_probe).detach().cpu().float()
+            g = torch.softmax(y, dim=1)
+            g[0, 0] -= 1.0                                                      # d cross_entropy(y,[0])/dy  (:657,:664)
+            _, s0 = self.net.seed_for(g, 1)
+        w, idx = eng.subtree_weights(img_probe, seed_tensor, torch.stack((s0, s1), dim=0), gate_ge0=do_mated_similarity_gating)
+        P_subtree = [float(v) for v in w[:, 0]]
+        P_subtree_idx = [int(v) for v in idx[:, 0]]
+        k_subtree = np.argsort(np.array(P_subtree))                             # ascending (:697)
+        Pk = torch.zeros((1, C))
+        Pk[0][k_poschannel] = 1.0
+        _, sk = self.net.seed_for(Pk, 1)
+        vals = eng.ebp_capture(img_probe, seed_tensor, sk.unsqueeze(0), P_subtree_idx)
+        J = int(sweep_batch or min(2 * eng.max_batch, max(8, 2 * topk)))
+        valid = []                                                              # (k, P) heaviest first
+        pos = len(k_subtree)
+        while pos > 0 and len(valid) < topk:
+            ks = [int(k) for k in k_subtree[max(0, pos - J):pos]][::-1]
+            pos -= len(ks)
+            maps = eng.layerwise(img_probe, seed_tensor, ks, [P_subtree_idx[k] for k in ks], [vals[k] for k in ks]).cpu().numpy()
+            for k, P in zip(ks, maps):
+                if verbose:
+                    print('[weighted_subtree_ebp][%d]: grad=%f' % (k, P_subtree[k]))
+                if np.max(P) > 0 and k != 1 and len(valid) < topk:             # :706-707 (k==1: STR-Janus Multiply layer)
+                    valid.append((k, P.astype(np.float32)))
+        if len(valid) == 0:
+            raise RuntimeError(
+                'Failed to calculate valid subtrees. The ebp subtree mode '
+                '(%s) may not support by this type of network. You may want '
+                'to try the "affineonly_with_prior" ebp subtree mode.' % self._ebp_subtree_mode)
+        valid = valid[::-1]                                                     # ascending weight, like [-topk:]
+        k_subtree_valid = [k for k, _ in valid]
+        P_img_valid = [P for _, P in valid]
+        P_subtree_valid = [P_subtree[k] for k in k_subtree_valid]
+        sn = self._scale_normalized(P_subtree_valid)
+        P_subtree_valid_norm = sn if not np.sum(sn) == 0 else np.ones_like(P_subtree_valid)
+        stack = np.dstack([float(wn) * np.array(P) * (1.0 / (np.max(P) + 1E-12)) for (wn, P) in zip(P_subtree_valid_norm, P_img_valid)])
+        smap = np.max(stack, axis=2) if do_max_subtree else np.sum(stack, axis=2)
+        if self.convert_saliency_uint8:
+            smap = self._float32_to_uint8(smap)
+        else:
+            smap /= max(smap.sum(), self.eps)
+        return (self._mwp_to_saliency(smap) if do_mwp_to_saliency else smap,
+                [self._mwp_to_saliency(P) if do_mwp_to_saliency else P for P in P_img_valid],
+                P_subtree_valid, k_subtree_valid)
 
     def ebp_subtree_mode(self):
         return self._ebp_subtree_mode
