@@ -148,6 +148,29 @@ def test_batched_engine_equals_per_sample_oracle(gpu_device, arch, mode):
         assert abs(float(sal[i].sum()) - 1.0) < 1e-4
 
 
+def test_with_bias_mode_vs_oracle(gpu_device):
+    """Whitebox(with_bias=True) (ebp_version 11, whitebox.py:286-289,321-324): positive pass uses relu(bias), relu(beta)."""
+    from oracle import ebp_oracle as O
+    from xfr_amd.models import whitebox as WB
+    bb, sd = make_backbone('stresnet_mini', seed=9, num_classes=5)
+    x = make_images('stresnet_mini', 1, seed=11)
+    bb.to(gpu_device)
+    wb = WB.Whitebox(WB.WhiteboxSTResnet(bb), ebp_subtree_mode='all', with_bias=True)
+    wb.debug_trace = True
+    ow = O.OracleWhitebox('stresnet_mini', sd, ('hooked', None), 'all', with_bias=True)
+    Pn = torch.zeros(1, 5)
+    Pn[0, 3] = 1
+    got = wb.ebp(x, Pn, mwp=True)
+    want = ow.ebp(x, Pn, mwp=True)
+    assert_map_close_robust(got, want, 'with_bias ebp')
+    sums = np.array([float(p.double().sum()) for p in ow.P])
+    assert_trace_close(np.asarray(wb.P_trace)[:, 0], wb.P_layername, sums, np.array(ow.P_layername), 'with_bias trace')
+    # and it differs from with_bias=False (the flag is live)
+    wb2 = WB.Whitebox(wb.net, ebp_subtree_mode='all', with_bias=False)
+    other = wb2.ebp(x, Pn, mwp=True)
+    assert np.abs(other - got).max() > 1e-6 * np.abs(got).max()
+
+
 def test_truncation_tail_equals_reference_formula_on_engine_P(gpu_device):
     """whitebox.py:547-558 (sort, cumsum, percentile mask) applied on the CPU to the engine's own P[-2] must give the
     engine's truncated map: isolates the radix-select tail from the (discontinuous) dependence on P."""

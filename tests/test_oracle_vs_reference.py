@@ -43,3 +43,25 @@ def test_every_P_tensor_matches_reference(mode):
         assert names == ow.P_layername
         for i, (a, b) in enumerate(zip(Pref, ow.P)):
             assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), (i, names[i])
+
+
+def test_with_bias_matches_reference():
+    """ebp_version 11 / with_bias=True: biases (and BatchNorm beta) are rectified in the positive pass (whitebox.py:321-324)."""
+    from oracle import ebp_oracle as O
+    ns = ref_import.load()
+    torch.set_num_threads(8)
+    bb, sd = make_backbone('stresnet_mini', seed=9, recipe='mild', num_classes=5)
+    net = ns.resnet.ResNet(ns.resnet.Bottleneck, [1, 1, 1, 1], mode='encode', num_classes=5)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    wb = ns.whitebox.Whitebox(ns.whitebox.WhiteboxSTResnet(net), ebp_subtree_mode='all', with_bias=True)
+    ow = O.OracleWhitebox('stresnet_mini', sd, ('hooked', None), 'all', with_bias=True)
+    x = make_images('stresnet_mini', 1, seed=11)
+    Pn = torch.zeros(1, 5)
+    Pn[0, 3] = 1
+    wb.ebp(x, Pn, mwp=True)
+    Pref = [p.detach().clone() for p in wb.P]
+    wb._ebp_mode = 'disable'
+    ow.ebp(x, Pn, mwp=True)
+    for i, (a, b) in enumerate(zip(Pref, ow.P)):
+        assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), i
