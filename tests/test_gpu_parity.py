@@ -46,7 +46,7 @@ def _check_factory(robust_pooled=False):
     (64, 16, 16, 2, 32, 1, 2, 0),      # strided 1x1
     (128, 8, 8, 2, 40, 8, 1, 0),       # Linear on a flattened 8x8 map (64 taps)
 ])
-@pytest.mark.parametrize('cfg', [0, 1, 4, 5])
+@pytest.mark.parametrize('cfg', [0, 1, 4, 5, 204, 305])      # 2xx / 3xx: split-K into 2 / 3 parts + reduce kernel
 def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
     """The MFMA implicit-GEMM kernel against plain PyTorch fp32 conv2d on the CPU."""
     from xfr_amd import _lib
@@ -65,6 +65,27 @@ def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
     got = out.permute(1, 0, 2, 3).cpu()
     assert torch.isfinite(got).all()
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_embeddings_and_mean_ebp(gpu_device):
+    """Whitebox.embeddings (whitebox.py:747-785) and the mean-EBP prior call of generate_whitebox_saliency.py:207-214
+    (P = ones over the hooked classifier)."""
+    from oracle import ebp_oracle as O
+    from xfr_amd.models import whitebox as WB
+    bb, sd = make_backbone('stresnet_mini', seed=4, num_classes=11)
+    x = make_images('stresnet_mini', 5, seed=2)
+    wb = WB.Whitebox(WB.WhiteboxSTResnet(bb.to(gpu_device)))
+    wb.batch_size = 2                                   # exercises the split into batches (:771)
+    emb = wb.embeddings([xi for xi in x], norm=True)
+    ow = O.OracleWhitebox('stresnet_mini', sd, ('hooked', None), 'affineonly_with_prior')
+    want = ow.encode(x).numpy()
+    want = want / np.linalg.norm(want, axis=1, keepdims=True)
+    assert emb.shape == (5, 512) and np.abs(emb - want).max() <= 1e-5
+    emb2 = wb.embeddings([xi.numpy() for xi in x], norm=False)
+    assert np.abs(emb2 - ow.encode(x).numpy()).max() <= 1e-4 * np.abs(emb2).max()
+    ones = torch.ones((1, 11))
+    got = wb.ebp(x[:1], ones)                            # mean EBP saliency
+    assert_map_close_robust(got, ow.ebp(x[:1], ones), 'mean_ebp')
 
 
 def test_saliency_blur_matches_scipy(gpu_device):

@@ -68,6 +68,9 @@ struct ConvParams {
     int in_nb, out_nb;  // images per channel row of the input / output tensors (>= NB: a launch may cover a batch prefix)
     unsigned in_bytes;  // byte size of the input tensor (buffer descriptor range; < 2^31)
     int force_cfg;      // 0 = heuristic tile choice, else a configuration id (tuning / tests)
+    int ksplit;         // 0 = heuristic, 1 = no split, P > 1 = split K into P parts (partials via splitk_ws + reduce kernel)
+    float* splitk_ws;   // scratch for split-K partial sums (nullptr: never split)
+    size_t splitk_ws_bytes;
     int tap_major;      // K ordered (kh, kw, ci) instead of (ci, kh, kw); requires Cin % 16 == 0
     int kh, kw, stride, pad;
     int OH, OW;

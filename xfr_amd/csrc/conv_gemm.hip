@@ -94,7 +94,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     const int l31 = lane & 31, lhi = lane >> 5;
 
     // n_co_tiles counts the tiles of BOTH halves of a dual launch (half 1 = relu(W) -> positive activations)
-    const int lid = xcd_remap(blockIdx.x, n_co_tiles * n_m_tiles);
+    // split-K: blocks [part * n_tiles, (part+1) * n_tiles) reduce K-steps [kt_lo, kt_hi) of every tile into a scratch slab
+    const int n_tiles_all = n_co_tiles * n_m_tiles;
+    const int lid_all = xcd_remap(blockIdx.x, n_tiles_all * p.ksplit);
+    const int part = lid_all / n_tiles_all;
+    const int lid = lid_all - part * n_tiles_all;
     const int tile_m = lid / n_co_tiles;
     const int tile_co_all = lid - tile_m * n_co_tiles;
     const int n_co_half = n_co_tiles / p.nhalves;
@@ -106,10 +110,13 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
     float* __restrict__ osel = half ? p.out1 : p.out0;
 
-    const int nk = (p.K + BK - 1) / BK;   // the packed weights are zero-padded to a multiple of 32 rows
+    const int nk_all = (p.K + BK - 1) / BK;   // the packed weights are zero-padded to a multiple of 32 rows
+    const int kt_lo = (int)((long)nk_all * part / p.ksplit);
+    const int kt_hi = (int)((long)nk_all * (part + 1) / p.ksplit);
+    const int nk = kt_hi;                     // K-steps are numbered globally; this block runs [kt_lo, kt_hi)
     const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
     // weights are packed with K padded to a multiple of BK (zero rows): no K tail on the A side
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, nk * BK * p.ldw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, nk_all * BK * p.ldw * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
 
     // ---- A side: per-lane byte offsets inside a K-step are constant; soffset walks k0
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         }
     }
     int iss_tap = 0, iss_ci0 = 0;     // (tap, first input channel) of the next K-step to be issued
+    if (MODE == MODE_TAP && kt_lo > 0) { iss_tap = (kt_lo * BK) / p.Cin; iss_ci0 = kt_lo * BK - iss_tap * p.Cin; }
     bool tap_dirty = true;
 
     // ---- issue the loads of one K-step into LDS stage `st`
@@ -222,13 +230,13 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
 
     // prologue: fill NST-1 stages
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s) issue(s, s);
+    for (int s = 0; s < NST - 1; ++s) issue(kt_lo + s, s);
 
     const int a_off = wrow * (TCO / 2) + l31;
     const int b_off = wcol * (TM / 2) + l31;
 
     int st = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt_lo; kt < nk; ++kt) {
         // stage kt has landed once at most (NST-2) younger stages are still in flight; the barrier then also
         // guarantees every wave is done reading the stage we are about to refill.
         wait_vmcnt<(NST - 2) * L>();
@@ -274,6 +282,23 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
     // Optional fused micro-program (half 0 only): forward = bias -> [store raw] -> BatchNorm -> [+residual] -> ReLU;
     // backward = [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP -> next GEMM's input.
+    if (p.ksplit > 1) {
+        // raw partial sums -> scratch[part][co][m]; bias / accumulate / layout are applied by splitk_reduce_kernel
+        float* __restrict__ slab = p.splitk_ws + (long)part * p.CoutTot * p.M;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wrow * (TCO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co < p.CoutTot) slab[(long)co * p.M + m] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     const bool use_chain = (p.chain.n > 0) && (half == 0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -389,6 +414,24 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     }
 }
 
+// out[co][m] = sum_part slab[part][co][m] + bias[co] (+ out[co][m])
+__global__ __launch_bounds__(NT) void splitk_reduce_kernel(const float4* __restrict__ ws, float4* __restrict__ out,
+                                                          const float* __restrict__ bias, int parts, int Cout, long M4,
+                                                          int accumulate)
+{
+    const long total = (long)Cout * M4;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        float4 a = ws[i];
+        for (int q = 1; q < parts; ++q) {
+            const float4 b = ws[(long)q * total + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (bias) { const float bb = bias[(int)(i / M4)]; a.x += bb; a.y += bb; a.z += bb; a.w += bb; }
+        if (accumulate) { const float4 o = out[i]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+        out[i] = a;
+    }
+}
+
 template <int TCO, int TM, int BK, int NST, int MODE>
 void launch_one(const ConvParams& p, hipStream_t s)
 {
@@ -396,9 +439,9 @@ void launch_one(const ConvParams& p, hipStream_t s)
     const int n_m = (p.M + TM - 1) / TM;
     const size_t lds = (size_t)NST * BK * (TCO + TM) * sizeof(float);
     if (p.relu_in)
-        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, true>), dim3(n_co * n_m), dim3(NT), lds, s, p, n_co, n_m);
+        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, true>), dim3(n_co * n_m * p.ksplit), dim3(NT), lds, s, p, n_co, n_m);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false>), dim3(n_co * n_m), dim3(NT), lds, s, p, n_co, n_m);
+        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false>), dim3(n_co * n_m * p.ksplit), dim3(NT), lds, s, p, n_co, n_m);
 }
 
 template <int TCO, int TM, int BK, int NST>
@@ -423,9 +466,59 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     return 4;
 }
 
+void launch_cfg_switch(const ConvParams& p, int cfg, hipStream_t s);
+
+int conv_gemm_pick_ksplit(const ConvParams& p, int cfg)
+{
+    // Few-tile grids (layer 3/4 of a 32-image batch) leave CUs idle in the last wave of workgroups: splitting K puts
+    // P x as many, P x shorter workgroups on the chip.  P minimises the makespan ceil(tiles*P / (256 CUs)) / P; the
+    // partial sums go through a scratch slab and one small reduce kernel (deterministic, no atomics).
+    if (p.nhalves != 1 || p.out_stride != 1 || p.chain.n > 0 || !p.splitk_ws || p.out_nb != p.NB || (p.M & 3)) return 1;
+    const int tile = 64;
+    (void)cfg;
+    const long tiles = (long)((p.CoutTot + tile - 1) / tile) * ((p.M + tile - 1) / tile);
+    const int bk = (cfg >= 5) ? 32 : 16;
+    const int nk = (p.K + bk - 1) / bk;
+    if (tiles >= 1536) return 1;
+    int best = 1;
+    double best_cost = 1e30;
+    const int cand[6] = {1, 2, 3, 4, 6, 8};
+    for (int ci = 0; ci < 6; ++ci) {
+        const int P = cand[ci];
+        if (P > 1 && nk / P < 12) break;
+        if ((size_t)P * p.CoutTot * p.M * sizeof(float) > p.splitk_ws_bytes) break;
+        const double rounds = (double)((tiles * P + 255) / 256) / P;              // in units of one full tile
+        const double cost = rounds * (1.0 + 0.04 * (P - 1)) + (P > 1 ? 0.08 : 0.0);  // pipeline refill + reduce pass
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = P; }
+    }
+    return best;
+}
+
 void launch_conv_gemm(const ConvParams& p, hipStream_t s)
 {
     const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
+    ConvParams q = p;
+    q.ksplit = p.ksplit > 0 ? p.ksplit : conv_gemm_pick_ksplit(p, cfg);
+    {   // a requested split is honoured only where the slab layout and the float4 reduce apply
+        const int bk = (cfg >= 5) ? 32 : 16;
+        const int nk = (p.K + bk - 1) / bk;
+        const bool can = p.nhalves == 1 && p.out_stride == 1 && p.chain.n == 0 && p.splitk_ws && p.out_nb == p.NB &&
+                         (p.M & 3) == 0 && (size_t)q.ksplit * p.CoutTot * p.M * sizeof(float) <= p.splitk_ws_bytes;
+        if (q.ksplit < 1 || !can) q.ksplit = 1;
+        if (q.ksplit > nk) q.ksplit = nk;
+    }
+    launch_cfg_switch(q, cfg, s);
+    if (q.ksplit > 1) {
+        const long M4 = q.M / 4;
+        long blocks = ((long)q.CoutTot * M4 + NT - 1) / NT;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(NT), 0, s, reinterpret_cast<const float4*>(q.splitk_ws),
+                           reinterpret_cast<float4*>(q.out0), q.bias, q.ksplit, q.CoutTot, M4, q.accumulate);
+    }
+}
+
+void launch_cfg_switch(const ConvParams& p, int cfg, hipStream_t s)
+{
     switch (cfg) {
         case 1: launch_cfg<128, 128, 16, 3>(p, s); break;
         case 2: launch_cfg<64, 128, 16, 4>(p, s); break;

@@ -1831,7 +1831,12 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     p.K = K; p.M = nb * p.OH * p.OW; p.CoutTot = cout; p.nhalves = 1; p.ldw = ldw;
     p.relu_in = relu_in; p.out_H = p.OH; p.out_W = p.OW; p.out_stride = 1;
     p.in_bytes = (unsigned)((size_t)cin * nb * h * w * sizeof(float));
-    p.tap_major = tap ? 1 : 0; p.force_cfg = cfg;
+    p.tap_major = tap ? 1 : 0; p.force_cfg = cfg % 100; p.ksplit = (cfg >= 100) ? cfg / 100 : 1;
+    float* skws = nullptr;
+    const size_t skbytes = (size_t)8 * cout * p.M * sizeof(float);
+    HIP_TRY(hipMalloc(&skws, skbytes));
+    p.splitk_ws = skws; p.splitk_ws_bytes = skbytes;
+    if (cfg >= 9900) p.ksplit = 0;   // heuristic
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
@@ -1845,6 +1850,7 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     if (ms_out) *ms_out = ms / reps;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     (void)hipFree(wd);
+    (void)hipFree(skws);
     if (bd) (void)hipFree(bd);
     HIP_TRY(hipGetLastError());
     return XFR_OK;
