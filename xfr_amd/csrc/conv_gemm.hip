@@ -83,7 +83,6 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
                                                   : B_FLOATS / 64 / 4;    // 4-byte wave-loads (one k row x 64 m)
     constexpr int L = A_PER_WAVE + B_PER_WAVE;
     constexpr int MSLOTS = TM / 64;                                       // m columns owned by a lane in the dword modes
-    constexpr int ROWS_PER_WAVE = (MODE == MODE_VEC) ? 1 : B_PER_WAVE / MSLOTS;   // k rows a wave loads per stage
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 

@@ -475,11 +475,6 @@ xfr_status layout_arena(xfr_engine* e)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct Prof {
-    xfr_engine* e;
-    hipStream_t s;
-};
-
 xfr_status run_conv(xfr_engine* e, const ConvParams& p, hipStream_t s)
 {
     if (e->profile_on) {
