@@ -465,11 +465,23 @@ def mwp_to_saliency(P, eps=1e-16, blur_radius=2):
     return img
 
 
+def mwp_to_saliency_uint8(P, eps=1e-16, blur_radius=2):
+    """whitebox.py:451-454, ebp_ver != 6: uint8 min-max -> PIL GaussianBlur(radius) -> uint8 min-max."""
+    import PIL.Image
+    import PIL.ImageFilter
+    img = np.asarray(P)
+    img = np.uint8(255 * ((img - np.min(img)) / (eps + (np.max(img) - np.min(img)))))
+    img = np.array(PIL.Image.fromarray(img).filter(PIL.ImageFilter.GaussianBlur(radius=blur_radius)))
+    img = np.uint8(255 * ((img - np.min(img)) / (eps + (np.max(img) - np.min(img)))))
+    return img
+
+
 class OracleWhitebox(object):
     """The method surface of whitebox.Whitebox that is on the hot path, evaluated by the tape."""
 
     def __init__(self, arch, params, classifier=('hooked', None), ebp_subtree_mode='affineonly_with_prior',
-                 eps=1e-16, with_bias=False):
+                 eps=1e-16, with_bias=False, ebp_version=6):
+        self.ebp_ver = ebp_version
         self.arch = arch
         self.params = {k: v.detach().clone().float() for k, v in params.items()}
         self.classifier = classifier
@@ -500,7 +512,10 @@ class OracleWhitebox(object):
         tape, out = self._run(x, 'classify')
         self.P, self.P_layername = tape.backward(out, Pn, self.mode, self.eps, priors)
         P = np.squeeze(np.sum(self.P[-2].detach().cpu().numpy(), axis=1)).astype(np.float32)
-        return mwp_to_saliency(P, self.eps) if not mwp else P
+        return self._sal(P) if not mwp else P
+
+    def _sal(self, P):
+        return mwp_to_saliency(P, self.eps) if self.ebp_ver == 6 else mwp_to_saliency_uint8(P, self.eps)
 
     def num_classes(self):
         if self.classifier is not None and self.classifier[1] is not None:
@@ -523,7 +538,7 @@ class OracleWhitebox(object):
         mwp_mate = P_mate[-2] / torch.sum(P_mate[-2])
         mwp_nonmate = P_nonmate[-2] / torch.sum(P_nonmate[-2])
         c = np.squeeze(np.sum(F.relu(mwp_mate - mwp_nonmate).numpy(), axis=1).astype(np.float32))
-        return mwp_to_saliency(c, self.eps)
+        return self._sal(c)
 
     def truncated_contrastive_ebp(self, x, k_pos, k_neg, percentile=20):
         """whitebox.py:529-558"""
@@ -540,7 +555,7 @@ class OracleWhitebox(object):
         mask = mask.reshape(mwp_mate.shape)
         t = F.relu(mask * mwp_mate - mask * mwp_nonmate)
         c = np.squeeze(np.sum(t.numpy(), axis=1).astype(np.float32))
-        return mwp_to_saliency(c, self.eps)
+        return self._sal(c)
 
     def _scale_normalized(self, img):
         img = np.float32(img)

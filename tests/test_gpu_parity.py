@@ -169,6 +169,28 @@ def test_batched_engine_equals_per_sample_oracle(gpu_device, arch, mode):
         assert abs(float(sal[i].sum()) - 1.0) < 1e-4
 
 
+def test_uint8_saliency_versions(gpu_device):
+    """ebp_version 5 / 7-12 convert through uint8 + PIL blur on the host (whitebox.py:285,451-454)."""
+    from oracle import ebp_oracle as O
+    from xfr_amd.models import whitebox as WB
+    bb, sd = make_backbone('stresnet_mini', seed=9, num_classes=5)
+    x = make_images('stresnet_mini', 1, seed=11)
+    wbn = WB.WhiteboxSTResnet(bb.to(gpu_device))
+    wb = WB.Whitebox(wbn, ebp_version=5)
+    ow = O.OracleWhitebox('stresnet_mini', sd, ('hooked', None), 'affineonly_with_prior', ebp_version=5)
+    xm, xn = synth.unit_rows(1, 512, seed=1) / 2500, synth.unit_rows(1, 512, seed=2) / 2500
+    wbn.set_triplet_classifier(xm, xn)
+    ow.set_triplet_classifier(xm, xn)
+    for got, want in ((wb.contrastive_ebp(x, 0, 1), ow.contrastive_ebp(x, 0, 1)),
+                      (wb.truncated_contrastive_ebp(x, 0, 1, 20), ow.truncated_contrastive_ebp(x, 0, 1, 20)),
+                      (wb.ebp(x, torch.tensor([[1.0, 0.0]])), ow.ebp(x, torch.tensor([[1.0, 0.0]])))):
+        assert got.dtype == np.uint8 and got.shape == (112, 112)
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        # two uint8 quantisations with a min-max stretch in between: a +-1 level flip before the blur is stretched to a few
+        # levels after it; the maps still agree on average to a fraction of a level
+        assert d.max() <= 10 and d.mean() < 0.5 and (d > 2).mean() < 0.02, (d.max(), d.mean())
+
+
 def test_with_bias_mode_vs_oracle(gpu_device):
     """Whitebox(with_bias=True) (ebp_version 11, whitebox.py:286-289,321-324): positive pass uses relu(bias), relu(beta)."""
     from oracle import ebp_oracle as O

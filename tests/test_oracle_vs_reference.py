@@ -3,6 +3,7 @@ exists (the build container); on the GPU box the committed golden vectors stand 
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -65,3 +66,25 @@ def test_with_bias_matches_reference():
     ow.ebp(x, Pn, mwp=True)
     for i, (a, b) in enumerate(zip(Pref, ow.P)):
         assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), i
+
+
+def test_uint8_saliency_path_matches_reference():
+    """ebp_version != 6: _mwp_to_saliency goes through uint8 + PIL GaussianBlur (whitebox.py:451-454)."""
+    from oracle import ebp_oracle as O
+    ns = ref_import.load()
+    torch.set_num_threads(8)
+    bb, sd = make_backbone('stresnet_mini', seed=9, recipe='mild', num_classes=5)
+    net = ns.resnet.ResNet(ns.resnet.Bottleneck, [1, 1, 1, 1], mode='encode', num_classes=5)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    wbn = ns.whitebox.WhiteboxSTResnet(net)
+    wb = ns.whitebox.Whitebox(wbn, ebp_version=5)
+    ow = O.OracleWhitebox('stresnet_mini', sd, ('hooked', None), 'affineonly_with_prior', ebp_version=5)
+    xm, xn = synth.unit_rows(1, 512, seed=1) / 2500, synth.unit_rows(1, 512, seed=2) / 2500
+    wbn.set_triplet_classifier(xm, xn)
+    ow.set_triplet_classifier(xm, xn)
+    x = make_images('stresnet_mini', 1, seed=11)
+    a = wb.contrastive_ebp(x, 0, 1)
+    wb._ebp_mode = 'disable'
+    b = ow.contrastive_ebp(x, 0, 1)
+    assert a.dtype == np.uint8 and b.dtype == np.uint8 and np.array_equal(a, b)

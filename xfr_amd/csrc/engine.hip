@@ -161,6 +161,9 @@ struct xfr_engine {
     // the other for free, while extra epilogue stores stretch every workgroup of a lock-step grid.  Kept for experiments.
     bool fuse_fwd = false;             // XFR_FWD_FUSE=1 enables it
     bool fuse_fwd_add = true;          // XFR_NO_FWD_ADD=1 keeps the residual add as its own kernel
+    float* splitk_buf[3] = {nullptr, nullptr, nullptr};   // split-K partial-sum slabs: caller stream, internal stream a, b
+    size_t splitk_bytes = 0;
+    bool use_splitk = false;            // XFR_SPLITK=1
     bool fuse_gemm_epilogue = false;   // XFR_FUSE_GEMM=1: also run hook chains inside the backward GEMM epilogue (measured slower)
     bool no_fuse = false;          // XFR_NO_FUSE=1: one launch per schedule step (A/B and debugging)
     int last_trace_firings = 0, last_trace_sb = 0;
@@ -475,8 +478,20 @@ xfr_status layout_arena(xfr_engine* e)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-xfr_status run_conv(xfr_engine* e, const ConvParams& p, hipStream_t s)
+xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
+    ConvParams p = p_in;
+    p.ksplit = 1;
+    if (e->use_splitk && p.kh * p.kw > 1) {      // only the deep-K KxK convolutions profit
+        const int which = (s == e->s_a && e->s_a) ? 1 : ((s == e->s_b && e->s_b) ? 2 : 0);
+        if (!e->splitk_buf[which]) {
+            e->splitk_bytes = (size_t)96 << 20;
+            HIP_TRY(hipMalloc(&e->splitk_buf[which], e->splitk_bytes));
+        }
+        p.splitk_ws = e->splitk_buf[which];
+        p.splitk_ws_bytes = e->splitk_bytes;
+        p.ksplit = 0;                           // heuristic
+    }
     if (e->profile_on) {
         if (e->ev_used == e->ev_pool.size()) {
             hipEvent_t a, b;
@@ -1261,6 +1276,7 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     xfr_engine* e = new xfr_engine();
     e->no_fuse = getenv("XFR_NO_FUSE") != nullptr;
     e->fuse_gemm_epilogue = getenv("XFR_FUSE_GEMM") != nullptr;
+    e->use_splitk = getenv("XFR_SPLITK") != nullptr;
     e->fuse_fwd = getenv("XFR_FWD_FUSE") != nullptr;
     e->fuse_fwd_add = getenv("XFR_NO_FWD_ADD") == nullptr;
     e->device = device; e->max_batch = max_batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
@@ -1282,6 +1298,7 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->dbl_ws) (void)hipFree(e->dbl_ws);
     if (e->trunc_ws) (void)hipFree(e->trunc_ws);
     if (e->ws_enc) (void)hipFree(e->ws_enc);
+    for (int i = 0; i < 3; ++i) if (e->splitk_buf[i]) (void)hipFree(e->splitk_buf[i]);
     if (e->ws2) (void)hipFree(e->ws2);
     if (e->cap_dev) (void)hipFree(e->cap_dev);
     if (e->stat_v) (void)hipFree(e->stat_v);
