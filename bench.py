@@ -82,6 +82,7 @@ def secondary(args, dev, rank, world):
         eng = Engine(prog, B, dev)
         eng.load_weights(synth.synth_state_dict(bb, seed=0))
         eng.set_mode(mode)
+        eng.set_pipeline(2)          # forward of step i+1 under the backward of step i; x is resident
         x = synth.synth_images(B, (1, 128, 128), seed=1234 + rank, scale255=False).to(dev)
         seed = torch.zeros((1, B, 80013), device=dev)
         seed[0, :, 0] = 1.0

@@ -189,6 +189,8 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
  * and the forwards of call i+1 start as soon as the slot they overwrite is free, i.e. they overlap the backward
  * sweep of call i (for calls made with inputs_ready = 1); results still appear in order on `stream`.  This is the steady state of the reference's job loop
  * (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:200-215: independent jobs, inputs loaded ahead).
+ * enable = 2 additionally pipelines xfr_ebp / xfr_contrastive / xfr_contrastive_raw: their forward overlaps the previous
+ * call's sweep, and their x_dev must satisfy the inputs_ready contract of xfr_triplet_contrastive.
  * Costs one extra copy of the forward workspace.  Synchronises the device. */
 xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
 

@@ -302,6 +302,31 @@ def test_triplet_step_equals_two_call_path(gpu_device):
         assert torch.equal(o, ref[i % len(batches)]), 'pipelined call %d differs' % i
 
 
+def test_pipelined_plain_calls(gpu_device):
+    """xfr_engine_set_pipeline(2): ebp / contrastive calls overlap across calls and still give the one-by-one results."""
+    bb, sd = make_backbone('lightcnn29v2', seed=2, num_classes=7)
+    subj = GC.engine_subject('lightcnn29v2', bb, 'affineonly_with_prior')
+    subj.wb.debug_trace = False
+    wb = subj.wb
+    eng = wb._engine(4)
+    xs = [make_images('lightcnn29v2', 3, seed=10 + i, smooth=False).to(gpu_device) for i in range(4)]
+    Pn = torch.zeros((1, 7)); Pn[0, 2] = 1
+    st, seed = wb.net.seed_for(Pn, 3)
+    seed = seed.unsqueeze(0).contiguous()
+    ref = [eng.ebp(x, st, seed)[1].clone() for x in xs]
+    enc = [eng.forward(x, wb.net._program.marks['encode']).clone() for x in xs]
+    torch.cuda.synchronize()
+    eng.set_pipeline(2)
+    outs = [eng.ebp(x, st, seed)[1] for x in xs * 2]
+    mid = eng.forward(xs[1], wb.net._program.marks['encode'])          # un-pipelined call in between
+    outs2 = [eng.ebp(x, st, seed)[1] for x in xs]
+    torch.cuda.synchronize()
+    eng.set_pipeline(0)
+    for i, o in enumerate(outs + outs2):
+        assert torch.equal(o, ref[i % 4]), i
+    assert torch.equal(mid, enc[1])
+
+
 def test_weight_arena_is_a_zero_copy_view(gpu_device):
     """The multi-GPU path broadcasts INTO the arena tensor: it must alias the engine's memory, not copy it."""
     import ctypes
@@ -333,6 +358,10 @@ def test_engine_argument_errors(gpu_device):
         wb.contrastive_ebp(x, 0, 5)
     with pytest.raises(ValueError):
         subj.enc(torch.zeros(1, 3, 100, 100))
+    with pytest.raises(ValueError):                    # empty batch
+        subj.enc(torch.zeros(0, 3, 224, 224))
+    with pytest.raises(ValueError):                    # more images than the engine was built for
+        wb._engine(1).forward(torch.zeros(wb._engine(1).max_batch + 1, 3, 224, 224), 1)
     with pytest.raises(ValueError):
         wb._engine(1).ebp(x, 2, torch.zeros(3, 1, 1))  # n_streams / seed shape
     with pytest.raises(ValueError):

@@ -185,6 +185,7 @@ struct xfr_engine {
     // cross-step pipelining (xfr_engine_set_pipeline): two forward slots (T, Pv, norms, argmax) so that the forward of
     // triplet call i+1 may run while the backward sweep of call i still reads slot i%2
     bool pipeline = false;
+    bool pipeline_all = false;     // level 2: xfr_ebp / xfr_contrastive calls are pipelined too (their inputs must be ready)
     int cur_slot = 0;
     long seq = 0;
     float* ws2 = nullptr;
@@ -1238,6 +1239,17 @@ xfr_status prof_end(xfr_engine* e, hipStream_t s)
     return XFR_OK;
 }
 
+// Any run that used forward slot 0 outside the pipelined paths must fence it, or a later pipelined forward (internal
+// stream) could overwrite activations this run's kernels on `s` are still using.
+xfr_status fence_slot0(xfr_engine* e, hipStream_t s)
+{
+    if (e->pipeline && e->ev_slot_done[0]) {
+        HIP_TRY(hipEventRecord(e->ev_slot_done[0], s));
+        e->slot_pending[0] = true;
+    }
+    return XFR_OK;
+}
+
 xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_tensor, const float* seed_dev, hipStream_t s)
 {
     if (seed_tensor < 2 || seed_tensor >= (int)e->tens.size()) return fail(XFR_INVALID_ARG, "bad seed tensor %d", seed_tensor);
@@ -1245,11 +1257,30 @@ xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_te
     BwdPlan* plan = nullptr;
     xfr_status st = get_plan(e, seed_tensor, &plan);
     if (st != XFR_OK) return st;
-    st = forward_all(e, x_dev, n, seed_tensor, true, s);
-    if (st != XFR_OK) return st;
+    // pipeline level 2: the forward of this call runs on an internal stream and only waits for the slot it overwrites, so it
+    // overlaps the backward sweep of the previous call (which is still reading the other slot)
+    const bool pipe = e->pipeline_all && !e->profile_on && e->s_b;
+    hipStream_t sf = pipe ? e->s_b : s;
+    e->cur_slot = pipe ? (int)(e->seq++ & 1) : 0;
+    const int slot = e->cur_slot;
+    if (pipe && e->slot_pending[slot]) HIP_TRY(hipStreamWaitEvent(sf, e->ev_slot_done[slot], 0));
+    st = forward_all(e, x_dev, n, seed_tensor, true, sf);
+    if (st != XFR_OK) { e->cur_slot = 0; return st; }
+    if (pipe) {
+        HIP_TRY(hipEventRecord(e->ev_b, sf));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_b, 0));
+    }
     const Tensor& sd = e->tens[seed_tensor];
     launch_seed_to_cnhw(seed_dev, e->G(seed_tensor), S * n, sd.C, sd.HW(), s);
-    return run_backward(e, *plan, n, S, s);
+    st = run_backward(e, *plan, n, S, s);
+    if (pipe && st == XFR_OK) {
+        HIP_TRY(hipEventRecord(e->ev_slot_done[slot], s));
+        e->slot_pending[slot] = true;
+    } else if (st == XFR_OK) {
+        st = fence_slot0(e, s);
+    }
+    e->cur_slot = 0;
+    return st;
 }
 
 }  // namespace
@@ -1439,6 +1470,8 @@ xfr_status xfr_forward(xfr_engine* e, const float* x_dev, int32_t n, int32_t ten
     const Tensor& t = e->tens[tensor_id];
     launch_cnhw_to_nchw(e->T(tensor_id), out_dev, n, t.C, t.HW(), s);
     HIP_TRY(hipGetLastError());
+    st = fence_slot0(e, s);
+    if (st != XFR_OK) return st;
     return prof_end(e, s);
 }
 
@@ -1458,6 +1491,17 @@ xfr_status xfr_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32_t n_strea
     if (pooled_dev) launch_channel_pool(e->ws + e->tap_off, pooled_dev, t1.C, SB, t1.HW(), s);
     HIP_TRY(hipGetLastError());
     return prof_end(e, s);
+}
+
+static xfr_status ensure_streams(xfr_engine* e)
+{
+    if (e->s_a) return XFR_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_a, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_b, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
+    return XFR_OK;
 }
 
 static xfr_status contrastive_tail(xfr_engine* e, int n, float percentile, float* sal_dev, hipStream_t s, bool raw = false)
@@ -1521,13 +1565,10 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     if (percentile > 100.f) return fail(XFR_INVALID_ARG, "percentile must be <= 100 (or < 0 for plain contrastive)");
     if (encode_tensor < 2 || encode_tensor >= (int)e->tens.size()) return fail(XFR_INVALID_ARG, "bad encode tensor %d", encode_tensor);
     hipStream_t s = (hipStream_t)stream;
-    if (!e->ws_enc) {
-        HIP_TRY(hipMalloc(&e->ws_enc, (e->t_region_floats + 4096) * sizeof(float)));
-        HIP_TRY(hipStreamCreateWithFlags(&e->s_a, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&e->s_b, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
+    if (!e->ws_enc) HIP_TRY(hipMalloc(&e->ws_enc, (e->t_region_floats + 4096) * sizeof(float)));
+    {
+        xfr_status es = ensure_streams(e);
+        if (es != XFR_OK) return es;
     }
     BwdPlan* plan = nullptr;
     st = get_plan(e, encode_tensor, &plan);
@@ -1601,7 +1642,9 @@ xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable)
             HIP_TRY(hipEventCreateWithFlags(&e->ev_slot_done[i], hipEventDisableTiming));
         }
     }
+    if (enable) { xfr_status es = ensure_streams(e); if (es != XFR_OK) return es; }
     e->pipeline = enable != 0;
+    e->pipeline_all = enable >= 2;
     e->slot_pending[0] = e->slot_pending[1] = false;
     e->seq = 0;
     return XFR_OK;
@@ -1753,7 +1796,7 @@ xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n_sweeps
     const Tensor& t1 = e->tens[1];
     launch_channel_pool(e->ws + e->tap_off, pooled_dev, t1.C, n_sweeps, t1.HW(), s);
     HIP_TRY(hipGetLastError());
-    return XFR_OK;
+    return fence_slot0(e, s);
 }
 
 xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,

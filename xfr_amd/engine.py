@@ -168,7 +168,7 @@ class Engine(object):
 
     def set_pipeline(self, on):
         """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
-        _lib.check(self.lib.xfr_engine_set_pipeline(self._h, 1 if on else 0))
+        _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call
 
     def mwp_to_saliency(self, pooled):
         pooled = pooled.detach().to(self.device, torch.float32).contiguous()
