@@ -101,3 +101,17 @@ def test_weighted_subtree_resnet101_golden(gpu_device):
     ref_k = [int(k) for k in g[key + '/k_valid']]
     assert len(set(k_valid) & set(ref_k)) >= 30, (k_valid, ref_k)      # near-equal layer weights may swap at the cut
     assert_map_close_robust(smap, g[key + '/map'], key, rtol=5e-3)
+
+
+def test_inpainting_game_workload_tool(gpu_device):
+    """tools/inpainting_game_workload.py (BASELINE.json configs[4] shape) runs end to end on one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(GC.GOLDEN_DIR.rstrip('/').rsplit('/', 1)[0])
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'inpainting_game_workload.py'), '--jobs', '3', '--mates', '2',
+                          '--topk', '4', '--num-classes', '300'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['jobs'] == 3 and res['jobs_per_s'] > 0

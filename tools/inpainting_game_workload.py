@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[4]: the workload SHAPE of the reference's inpainting-game whitebox saliency generator
+(eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:121-231 + python/xfr/inpainting_game/generate_whitebox_saliency.py:
+79-115,207-214,119-205) on synthetic data, sharded over ranks like the reference's one-worker-per-GPU pool.
+
+Per job (= one (subject, mask, probe) of the reference's cartesian job list) the four saliency methods are produced:
+    meanEBP                      ebp(probe, ones)                              generate_whitebox_saliency.py:207-214
+    contrastive triplet EBP      k mates / k non-mates encoded, averaged, unit-normalised, /2500  -> contrastive_ebp   :79-115
+    truncated contrastive (20%)  same classifier                                                                         :106-112
+    weighted subtree EBP, top-32 mode 'norelu'                                                                            :119-205
+The reference needs ~36 h for its 541 ResNet-101 jobs on one Titan X (README.md:166).  Launch:
+    python tools/inpainting_game_workload.py --jobs 64
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 tools/inpainting_game_workload.py --jobs 541
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--jobs', type=int, default=32)
+    ap.add_argument('--mates', type=int, default=4, help='mate / non-mate images per job')
+    ap.add_argument('--topk', type=int, default=32)
+    ap.add_argument('--num-classes', type=int, default=65359)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from xfr_amd import shard, synth
+    from xfr_amd.models import resnet, whitebox as WB
+
+    rank, world, local = shard.init_process_group()
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    bb = resnet.ResNet([3, 4, 23, 3], num_classes=args.num_classes)
+    bb.to(dev)
+    wbn = WB.WhiteboxSTResnet(bb)
+    wb = WB.Whitebox(wbn, ebp_subtree_mode='norelu')            # eval/create_wbnet.py:51-52 default for resnetv4/v6
+    from xfr_amd.engine import Engine
+    wbn._program = bb.build_program()
+    wbn._engine = Engine(wbn._program, 32, dev)
+    wbn._engine_key = (str(bb.device), id(bb))
+    shard.load_and_broadcast(wbn._engine, lambda: synth.synth_state_dict(bb, seed=0), src=0)     # one load, one broadcast
+    wbn._engine.loaded_version = bb.version
+
+    lo, hi = shard.shard_range(args.jobs, rank, world)
+    k = args.mates
+    done, t_methods = 0, np.zeros(4)
+    # synthetic stand-ins for the aligned IJB-C crops (git-LFS pointers in the reference): a small pool, generated up front
+    pool = [synth.synth_smooth_images(2 * k + 1, (3, 224, 224), seed=10000 + j, mean=resnet.MEAN_RGB).to(dev) for j in range(8)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for job in range(lo, hi):
+        imgs = pool[job % len(pool)]
+        probe, mates, nonmates = imgs[:1], imgs[1:1 + k], imgs[1 + k:]
+        t = time.perf_counter()
+        ones = torch.ones((1, args.num_classes))
+        wbn._classifier = None                                  # the checkpoint's hooked 65359-way fc2 for meanEBP
+        s_mean = wb.ebp(probe, ones)
+        t1 = time.perf_counter()
+        x_m = wb.encode(mates).mean(dim=0, keepdim=True)
+        x_n = wb.encode(nonmates).mean(dim=0, keepdim=True)
+        x_m = x_m / x_m.norm()
+        x_n = x_n / x_n.norm()
+        wb.net.set_triplet_classifier((1.0 / 2500.0) * x_m.cpu(), (1.0 / 2500.0) * x_n.cpu())
+        s_con = wb.contrastive_ebp(probe, 0, 1)
+        t2 = time.perf_counter()
+        s_tru = wb.truncated_contrastive_ebp(probe, 0, 1, percentile=20)
+        t3 = time.perf_counter()
+        s_sub = wb.weighted_subtree_ebp(probe, 0, 1, topk=args.topk, verbose=False, subtree_mode='norelu')[0]
+        t4 = time.perf_counter()
+        for m in (s_mean, s_con, s_tru, s_sub):
+            assert m.shape == (112, 112) and np.isfinite(m).all() and abs(float(m.sum()) - 1.0) < 1e-3
+        t_methods += np.array([t1 - t, t2 - t1, t3 - t2, t4 - t3])
+        done += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = torch.tensor([dt, float(done)], device=dev, dtype=torch.float64)
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dt, total = float(tmax[0]), int(stats[1])
+    else:
+        total = done
+    if rank == 0:
+        per = (t_methods / max(done, 1) * 1e3).round(1).tolist()
+        print(json.dumps({'workload': 'inpainting-game whitebox saliency generation shape, ResNet-101, synthetic', 'jobs': total,
+                          'n_gpus': world, 'seconds': dt, 'jobs_per_s': total / dt,
+                          'ms_per_job_rank0': {'meanEBP': per[0], 'contrastive(+%d encodes)' % (2 * k): per[1], 'truncated': per[2],
+                                               'weighted_subtree_top%d' % args.topk: per[3]},
+                          'reference': '~36 h for 541 jobs on one Titan X (README.md:166) = ~240 s/job'}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
