@@ -101,3 +101,23 @@ def test_unsupported_layer_kind_is_rejected_by_name():
             _lib.check(st)
     else:
         assert st == _lib.XFR_HIP_ERROR
+
+
+def test_create_wbnet_defaults_match_reference():
+    """eval/create_wbnet.py:24-132: default subtree modes, thresholds, Platt scalings; unknown names raise."""
+    import warnings
+    from xfr_amd.create_wbnet import create_wbnet
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        wb = create_wbnet('resnetv4_pytorch', device='cuda:0')
+        assert wb.ebp_subtree_mode() == 'norelu' and wb.match_threshold == 0.9722 and wb.platts_scaling == 16.61
+        wb = create_wbnet('resnetv6_pytorch', device='cuda:0', ebp_subtree_mode='all')
+        assert wb.ebp_subtree_mode() == 'all' and wb.match_threshold == 0.9636
+        wb = create_wbnet('vggface2_resnet50', device='cuda:0')
+        assert wb.ebp_subtree_mode() == 'norelu' and abs(wb.platts_scaling - 15.921608) < 1e-9
+        wb = create_wbnet('lightcnn', device='cuda:0')
+        assert wb.ebp_subtree_mode() == 'affineonly_with_prior' and wb.net.num_classes() == 80013
+    with pytest.raises(NotImplementedError):
+        create_wbnet('senet50', device='cuda:0')
+    with pytest.raises(DeprecationWarning):
+        create_wbnet('resnetv4_pytorch', device='cuda:0', ebp_version=3)
