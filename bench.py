@@ -122,8 +122,8 @@ def secondary(args, dev, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='triplets per GPU per step')
     ap.add_argument('--mode', default=None)
     ap.add_argument('--model', default='resnet101', choices=['resnet101', 'resnet50_128', 'lightcnn'],
