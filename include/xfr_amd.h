@@ -194,6 +194,14 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
  * Costs one extra copy of the forward workspace.  Synchronises the device. */
 xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
 
+/* Tail balancing of the convolution GEMMs (on by default).  A GEMM whose tile count is not a multiple of the CU count
+ * has its last tiles cut along K so that every CU gets an equal share of the final round (+7 % GEMM rate on
+ * ResNet-101 at 32-64 images).  The cut tiles add their K-parts in a fixed order: results are deterministic for a
+ * given batch size, but which tiles are cut depends on the batch size, so a sample's map can differ in the last fp32
+ * bits between batch sizes / positions.  enable = 0 restores batch-invariant arithmetic (every output element is
+ * accumulated in one K order regardless of the batch). */
+xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable);
+
 /* _mwp_to_saliency (whitebox.py:448-460, ebp_ver 6) on N pooled maps: in N x H x W -> out N x H x W. */
 xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w,
                                float* sal_dev, void* stream);

@@ -71,6 +71,13 @@ struct ConvParams {
     int ksplit;         // 0 = heuristic, 1 = no split, P > 1 = split K into P parts (partials via splitk_ws + reduce kernel)
     float* splitk_ws;   // scratch for split-K partial sums (nullptr: never split)
     size_t splitk_ws_bytes;
+    // tail balancing (conv_gemm.hip): the last tiles % CUs tiles of a small grid are cut along K into tail_s parts
+    // each, so that every CU gets the same share of the final round; parts meet in tail_ws, the last arriver reduces.
+    float* tail_ws;     // scratch for the parts' accumulators (nullptr: never balance); one per stream in flight
+    unsigned* tail_cnt; // arrival counters, zero between launches (XFR_TAIL_MAX_TILES entries)
+    size_t tail_ws_bytes;
+    int tail_force;     // 0 = heuristic, 1 = off, S >= 2 = force S parts per tail tile (tuning / tests)
+    int tail_q, tail_s; // set by launch_conv_gemm: whole tiles, parts per tail tile (tail_s <= 1: off)
     int tap_major;      // K ordered (kh, kw, ci) instead of (ci, kh, kw); requires Cin % 16 == 0
     int kh, kw, stride, pad;
     int OH, OW;
@@ -84,6 +91,8 @@ struct ConvParams {
     EwChain chain;      // epilogue micro-program applied to half 0 before the final store (n == 0: none)
 };
 
+constexpr int XFR_TAIL_MAX_TILES = 256;
+constexpr size_t XFR_TAIL_WS_BYTES = (size_t)16 << 20;
 void launch_conv_gemm(const ConvParams& p, hipStream_t s);
 int conv_gemm_pick_cfg(const ConvParams& p);
 

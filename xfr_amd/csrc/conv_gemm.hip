@@ -28,6 +28,7 @@
 // (buffer_load ... lds): per-lane 32-bit offsets are precomputed, the K walk is a scalar soffset, and masked im2col
 // elements (padding, K/M tails) are out-of-range offsets for which the hardware writes 0.0 -- the K-loop carries
 // no per-element address arithmetic and no branches.
+#include <algorithm>
 #include "common.h"
 #include <cstdlib>
 
@@ -96,9 +97,26 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     // n_co_tiles counts the tiles of BOTH halves of a dual launch (half 1 = relu(W) -> positive activations)
     // split-K: blocks [part * n_tiles, (part+1) * n_tiles) reduce K-steps [kt_lo, kt_hi) of every tile into a scratch slab
     const int n_tiles_all = n_co_tiles * n_m_tiles;
-    const int lid_all = xcd_remap(blockIdx.x, n_tiles_all * p.ksplit);
-    const int part = lid_all / n_tiles_all;
-    const int lid = lid_all - part * n_tiles_all;
+    int part, nparts, lid, tail_t = -1;
+    if (p.tail_s > 1) {
+        // tail balancing: blocks [0, tail_q) are whole tiles; the rest are K-parts of the last tiles
+        if ((int)blockIdx.x < p.tail_q) {
+            lid = xcd_remap(blockIdx.x, p.tail_q);
+            part = 0;
+            nparts = 1;
+        } else {
+            const int tb = blockIdx.x - p.tail_q;
+            tail_t = tb / p.tail_s;
+            part = tb - tail_t * p.tail_s;
+            nparts = p.tail_s;
+            lid = p.tail_q + tail_t;
+        }
+    } else {
+        const int lid_all = xcd_remap(blockIdx.x, n_tiles_all * p.ksplit);
+        part = lid_all / n_tiles_all;
+        lid = lid_all - part * n_tiles_all;
+        nparts = p.ksplit;
+    }
     const int tile_m = lid / n_co_tiles;
     const int tile_co_all = lid - tile_m * n_co_tiles;
     const int n_co_half = n_co_tiles / p.nhalves;
@@ -111,8 +129,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     float* __restrict__ osel = half ? p.out1 : p.out0;
 
     const int nk_all = (p.K + BK - 1) / BK;   // the packed weights are zero-padded to a multiple of 32 rows
-    const int kt_lo = (int)((long)nk_all * part / p.ksplit);
-    const int kt_hi = (int)((long)nk_all * (part + 1) / p.ksplit);
+    const int kt_lo = (int)((long)nk_all * part / nparts);
+    const int kt_hi = (int)((long)nk_all * (part + 1) / nparts);
     const int nk = kt_hi;                     // K-steps are numbered globally; this block runs [kt_lo, kt_hi)
     const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
     // weights are packed with K padded to a multiple of BK (zero rows): no K tail on the A side
@@ -279,6 +297,47 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     }
     wait_vmcnt<0>();   // drain the tail loads before the LDS is released
 
+    if (tail_t >= 0) {
+        // K-part of a tail tile: park the accumulators, count arrivals; the last part to arrive sums all parts in
+        // part order (deterministic) and runs the normal epilogue.  Agent-scope stores / loads: the parts ran on
+        // different XCDs, whose L2s are not coherent for plain accesses.
+        constexpr int TILE_FLOATS = TCO * TM;
+        float* __restrict__ slab = p.tail_ws + (long)(tail_t * nparts + part) * TILE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(slab + ((i * NJ + j) * 16 + r) * NT + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // write-through (agent-scope) stores, then only wait for them: a full __threadfence() would write back AND
+        // invalidate this XCD's whole L2 under the other resident workgroups (measured: 37 us per launch at 256 parts)
+        wait_vmcnt<0>();
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const unsigned old = atomicAdd(p.tail_cnt + tail_t, 1u);
+            const int last = (old == (unsigned)(nparts - 1));
+            if (last) atomicExch(p.tail_cnt + tail_t, 0u);     // ready for the next launch on this stream
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        const float* base = p.tail_ws + (long)tail_t * nparts * TILE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sum = 0.f;
+                    for (int q = 0; q < nparts; ++q)
+                        sum += __hip_atomic_load(base + (long)q * TILE_FLOATS + ((i * NJ + j) * 16 + r) * NT + tid,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[i][j][r] = sum;
+                }
+    }
+
     // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
     // Optional fused micro-program (half 0 only): forward = bias -> [store raw] -> BatchNorm -> [+residual] -> ReLU;
     // backward = [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP -> next GEMM's input.
@@ -432,16 +491,77 @@ __global__ __launch_bounds__(NT) void splitk_reduce_kernel(const float4* __restr
     }
 }
 
+int num_cus()
+{
+    static const int n = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+            cu = 256;
+        return cu;
+    }();
+    return n;
+}
+
+// Tail balancing.  A grid of T tiles on C CUs, all co-resident (T < ~6 C), finishes when the CUs that got
+// ceil(T / C) tiles finish: T = 784 (ResNet-101 layer 3 at 64 images) runs at 3.06 / 4 = 77 % of the rate of T = 768
+// (measured: 88 vs 104-114 TFLOP/s).  The last r = T % C tiles are therefore cut along K into S parts, r * S ~ C
+// small blocks: every CU receives floor(T / C) whole tiles plus one part.  Returns S (1 = leave the grid alone).
+int pick_tail_split(const ConvParams& p, int tiles, int nk, size_t tile_bytes)
+{
+    static const int qmax = getenv("XFR_TAIL_QMAX") ? atoi(getenv("XFR_TAIL_QMAX")) : 7;
+    static const int off = getenv("XFR_NO_TAIL") != nullptr;
+    if (!p.tail_ws || !p.tail_cnt || p.tail_force == 1 || off) return 1;
+    const int C = num_cus();
+    const int q = tiles / C, r = tiles % C;
+    if (r == 0 || r > XFR_TAIL_MAX_TILES) return 1;
+    const long max_blocks = (long)(p.tail_ws_bytes / tile_bytes);
+    if (p.tail_force >= 2) {
+        const int S = std::min(p.tail_force, nk);
+        return ((long)r * S <= max_blocks) ? S : 1;
+    }
+    if (q >= qmax || p.K < 1024) return 1;   // many rounds: blocks are dispatched as slots free up, the last round matters little
+    // Final-round cost in units of one whole tile: a CU runs ceil(r*S/C) parts of 1/S tile, each with a fixed ramp
+    // (ring fill, partial store, arrival) worth ~192 K-rows.  Measured on MI355X: parts shorter
+    // than 256 K-rows cost more than they balance, and nothing is gained below K = 1024.
+    const double ramp = 192.0 / (double)p.K;
+    const double whole = 1.0 + ramp;
+    double best = whole;
+    int bestS = 1;
+    const int Smax = std::min(std::min(8, p.K / 256), nk);
+    for (int S = 2; S <= Smax; ++S) {
+        if ((long)r * S > max_blocks) break;
+        const double per_cu = (double)(((long)r * S + C - 1) / C);
+        const double cost = per_cu * (1.0 / S + ramp) + 0.01 * S;
+        if (cost < best) { best = cost; bestS = S; }
+    }
+    // the whole grid takes q + 1 rounds unsplit; ask for a 4 % gain on that before adding the exchange
+    if (whole - best < 0.04 * (q + 1) * whole) bestS = 1;
+    return bestS;
+}
+
 template <int TCO, int TM, int BK, int NST, int MODE>
 void launch_one(const ConvParams& p, hipStream_t s)
 {
     const int n_co = ((p.CoutTot + TCO - 1) / TCO) * p.nhalves;
     const int n_m = (p.M + TM - 1) / TM;
     const size_t lds = (size_t)NST * BK * (TCO + TM) * sizeof(float);
+    ConvParams q = p;
+    int grid = n_co * n_m * p.ksplit;
+    q.tail_q = 0;
+    q.tail_s = 1;
+    if (p.ksplit == 1) {
+        const int S = pick_tail_split(p, n_co * n_m, (p.K + BK - 1) / BK, (size_t)TCO * TM * sizeof(float));
+        if (S > 1) {
+            const int r = (n_co * n_m) % num_cus();
+            q.tail_q = n_co * n_m - r;
+            q.tail_s = S;
+            grid = q.tail_q + r * S;
+        }
+    }
     if (p.relu_in)
-        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, true>), dim3(n_co * n_m * p.ksplit), dim3(NT), lds, s, p, n_co, n_m);
+        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, true>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false>), dim3(n_co * n_m * p.ksplit), dim3(NT), lds, s, p, n_co, n_m);
+        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
 }
 
 template <int TCO, int TM, int BK, int NST>

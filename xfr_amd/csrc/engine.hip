@@ -163,6 +163,12 @@ struct xfr_engine {
     bool fuse_fwd_add = true;          // XFR_NO_FWD_ADD=1 keeps the residual add as its own kernel
     float* splitk_buf[3] = {nullptr, nullptr, nullptr};   // split-K partial-sum slabs: caller stream, internal stream a, b
     size_t splitk_bytes = 0;
+    // tail-balancing scratch (conv_gemm.hip), one per stream that launches GEMMs; kernels on one stream serialise,
+    // so consecutive launches share it
+    struct TailWs { hipStream_t s; float* ws; unsigned* cnt; };
+    TailWs tail_ws[8];
+    int n_tail_ws = 0;
+    bool tail_balance = true;          // xfr_engine_set_tail_balance
     bool use_splitk = false;            // XFR_SPLITK=1
     bool fuse_gemm_epilogue = false;   // XFR_FUSE_GEMM=1: also run hook chains inside the backward GEMM epilogue (measured slower)
     bool no_fuse = false;          // XFR_NO_FUSE=1: one launch per schedule step (A/B and debugging)
@@ -492,6 +498,26 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
         p.splitk_ws = e->splitk_buf[which];
         p.splitk_ws_bytes = e->splitk_bytes;
         p.ksplit = 0;                           // heuristic
+    }
+    p.tail_force = 1;
+    if (e->tail_balance) {
+        p.tail_force = 0;
+        int k = 0;
+        while (k < e->n_tail_ws && e->tail_ws[k].s != s) ++k;
+        if (k == e->n_tail_ws && k < 8) {
+            float* ws = nullptr;
+            HIP_TRY(hipMalloc(&ws, XFR_TAIL_WS_BYTES + XFR_TAIL_MAX_TILES * sizeof(unsigned)));
+            unsigned* cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + XFR_TAIL_WS_BYTES);
+            HIP_TRY(hipMemset(cnt, 0, XFR_TAIL_MAX_TILES * sizeof(unsigned)));
+            HIP_TRY(hipDeviceSynchronize());
+            e->tail_ws[k] = {s, ws, cnt};
+            e->n_tail_ws = k + 1;
+        }
+        if (k < e->n_tail_ws) {
+            p.tail_ws = e->tail_ws[k].ws;
+            p.tail_cnt = e->tail_ws[k].cnt;
+            p.tail_ws_bytes = XFR_TAIL_WS_BYTES;
+        }
     }
     if (e->profile_on) {
         if (e->ev_used == e->ev_pool.size()) {
@@ -1330,6 +1356,7 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->trunc_ws) (void)hipFree(e->trunc_ws);
     if (e->ws_enc) (void)hipFree(e->ws_enc);
     for (int i = 0; i < 3; ++i) if (e->splitk_buf[i]) (void)hipFree(e->splitk_buf[i]);
+    for (int i = 0; i < e->n_tail_ws; ++i) (void)hipFree(e->tail_ws[i].ws);
     if (e->ws2) (void)hipFree(e->ws2);
     if (e->cap_dev) (void)hipFree(e->cap_dev);
     if (e->stat_v) (void)hipFree(e->stat_v);
@@ -1627,6 +1654,13 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     return prof_end(e, s);
 }
 
+xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->tail_balance = enable != 0;
+    return XFR_OK;
+}
+
 xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
@@ -1886,12 +1920,18 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     p.K = K; p.M = nb * p.OH * p.OW; p.CoutTot = cout; p.nhalves = 1; p.ldw = ldw;
     p.relu_in = relu_in; p.out_H = p.OH; p.out_W = p.OW; p.out_stride = 1;
     p.in_bytes = (unsigned)((size_t)cin * nb * h * w * sizeof(float));
-    p.tap_major = tap ? 1 : 0; p.force_cfg = cfg % 100; p.ksplit = (cfg >= 100) ? cfg / 100 : 1;
+    p.tap_major = tap ? 1 : 0; p.force_cfg = cfg % 100; p.ksplit = (cfg % 10000 >= 100) ? (cfg % 10000) / 100 : 1;
+    float* tws = nullptr;
+    HIP_TRY(hipMalloc(&tws, XFR_TAIL_WS_BYTES + XFR_TAIL_MAX_TILES * sizeof(unsigned)));
+    p.tail_ws = tws; p.tail_ws_bytes = XFR_TAIL_WS_BYTES;
+    p.tail_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tws) + XFR_TAIL_WS_BYTES);
+    HIP_TRY(hipMemset(p.tail_cnt, 0, XFR_TAIL_MAX_TILES * sizeof(unsigned)));
+    p.tail_force = cfg / 10000;          // 0 heuristic, 1 off, S >= 2 forced
     float* skws = nullptr;
     const size_t skbytes = (size_t)8 * cout * p.M * sizeof(float);
     HIP_TRY(hipMalloc(&skws, skbytes));
     p.splitk_ws = skws; p.splitk_ws_bytes = skbytes;
-    if (cfg >= 9900) p.ksplit = 0;   // heuristic
+    if (cfg % 10000 >= 9900) p.ksplit = 0;   // heuristic
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
@@ -1906,6 +1946,7 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     (void)hipFree(wd);
     (void)hipFree(skws);
+    (void)hipFree(tws);
     if (bd) (void)hipFree(bd);
     HIP_TRY(hipGetLastError());
     return XFR_OK;

@@ -170,6 +170,10 @@ class Engine(object):
         """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
         _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call
 
+    def set_tail_balance(self, on):
+        """GEMM tail balancing (default on); off = batch-invariant fp32 arithmetic (include/xfr_amd.h)."""
+        _lib.check(self.lib.xfr_engine_set_tail_balance(self._h, int(bool(on))))
+
     def mwp_to_saliency(self, pooled):
         pooled = pooled.detach().to(self.device, torch.float32).contiguous()
         n, h, w = pooled.shape
