@@ -198,6 +198,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sal = step()
+    t_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (launch-bound if close to dt)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -237,7 +238,7 @@ def main():
             'config': {'workload': 'ResNet-101 triplet contrastive EBP, batch=%d synthetic 224x224 triplets per GPU '
                                    '(2 encodes + contrastive_ebp per triplet), mode %s, eps 1e-16' % (B, args.mode),
                        'triplets_per_gpu': B, 'parallelism': 'independent triplets, %d process(es), weights broadcast once' % world},
-            'outputs_ok': ok,
+            'outputs_ok': ok, 'host_enqueue_ms_per_step': 1e3 * t_enqueue / args.steps,
         }
         if roof is not None:
             line['roofline'] = roof

@@ -580,9 +580,12 @@ int conv_gemm_pick_cfg(const ConvParams& p)
 {
     // Measured on MI355X over the ResNet-101 / ResNet-50 / Light-CNN GEMM shapes (M = 1.5k..400k, K = 64..4608,
     // Cout = 64..2048): the 64x64 tile wins or ties everywhere -- these grids are small (1-12 workgroups per CU), so
-    // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.  Deep-K,
-    // small-M layers (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers per MFMA.
-    if (p.K >= 1024 && p.M <= 8192 && (p.tap_major ? (p.Cin % 32 == 0) : true) ) return 5;
+    // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.  Deep-K
+    // launches of at most two tiles per CU (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers
+    // per MFMA.  Their 48 KB ring allows three workgroups per CU, so larger grids (the W / relu(W) dual launch of the
+    // same layer has twice the tiles) stay on the 24 KB ring where whole tiles and tail parts are all resident.
+    const long tiles = (long)((p.CoutTot + 63) / 64) * p.nhalves * ((p.M + 63) / 64);
+    if (p.K >= 1024 && tiles <= 512 && (p.tap_major ? (p.Cin % 32 == 0) : true)) return 5;
     return 4;
 }
 
