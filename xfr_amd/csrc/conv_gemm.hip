@@ -185,6 +185,29 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
             voffB[s] = OOB;
         }
     }
+    // generic gather (stems: Cin = 1 or 3): k -> (channel offset, dh, dw) comes from a table in LDS behind the ring
+    // instead of two integer divisions per load (the 7x7 stem was VALU-bound on them)
+    constexpr int KTAB_MAX = 512;
+    int2* ktab = reinterpret_cast<int2*>(smem + NST * STAGE);
+    const bool use_ktab = (MODE == MODE_GEN) && (nk_all * BK <= KTAB_MAX);
+    if (use_ktab) {
+        const int kk = p.kh * p.kw;
+        for (int k = tid; k < nk_all * BK; k += NT) {
+            int2 e;
+            if (k < p.K) {
+                const int ci = k / kk;
+                const int r = k - ci * kk;
+                const int dh = r / p.kw;
+                e.x = (int)((unsigned)ci * chan_bytes);
+                e.y = (dh << 8) | (r - dh * p.kw);
+            } else {
+                e.x = 0;
+                e.y = -1;
+            }
+            ktab[k] = e;
+        }
+        __syncthreads();
+    }
     int iss_tap = 0, iss_ci0 = 0;     // (tap, first input channel) of the next K-step to be issued
     if (MODE == MODE_TAP && kt_lo > 0) { iss_tap = (kt_lo * BK) / p.Cin; iss_ci0 = kt_lo * BK - iss_tap * p.Cin; }
     bool tap_dirty = true;
@@ -227,13 +250,27 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
                 const int q = wave * B_PER_WAVE + i;
                 const int row = q / MSLOTS, s = q - row * MSLOTS;
                 const int k = k0 + row;
-                const int kk = p.kh * p.kw;
-                const int ci = k / kk;
-                const int r = k - ci * kk;
-                const int dh = r / p.kw, dw = r - dh * p.kw;
-                const bool ok = (k < p.K) && ((unsigned)(ih0[s] + dh) < (unsigned)p.H) &&
-                                ((unsigned)(iw0[s] + dw) < (unsigned)p.W);
-                bload4(rIn, Bs + q * 64, ok ? (unsigned)(base_m[s] + dh * p.W + dw) * 4u : OOB, (unsigned)ci * chan_bytes);
+                int dh, dw;
+                unsigned coff;
+                bool kok;
+                if (use_ktab) {
+                    const int2 e = ktab[live ? k : 0];
+                    const int ey = __builtin_amdgcn_readfirstlane(e.y);
+                    coff = (unsigned)__builtin_amdgcn_readfirstlane(e.x);
+                    kok = live && ey >= 0;
+                    dh = ey >> 8;
+                    dw = ey & 255;
+                } else {
+                    const int kk = p.kh * p.kw;
+                    const int ci = k / kk;
+                    const int r = k - ci * kk;
+                    dh = r / p.kw;
+                    dw = r - dh * p.kw;
+                    coff = (unsigned)ci * chan_bytes;
+                    kok = k < p.K;
+                }
+                const bool ok = kok && ((unsigned)(ih0[s] + dh) < (unsigned)p.H) && ((unsigned)(iw0[s] + dw) < (unsigned)p.W);
+                bload4(rIn, Bs + q * 64, ok ? (unsigned)(base_m[s] + dh * p.W + dw) * 4u : OOB, coff);
             }
         }
     };
@@ -544,7 +581,7 @@ void launch_one(const ConvParams& p, hipStream_t s)
 {
     const int n_co = ((p.CoutTot + TCO - 1) / TCO) * p.nhalves;
     const int n_m = (p.M + TM - 1) / TM;
-    const size_t lds = (size_t)NST * BK * (TCO + TM) * sizeof(float);
+    const size_t lds = (size_t)NST * BK * (TCO + TM) * sizeof(float) + (MODE == MODE_GEN ? 512 * sizeof(int2) : 0);
     ConvParams q = p;
     int grid = n_co * n_m * p.ksplit;
     q.tail_q = 0;
