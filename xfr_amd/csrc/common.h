@@ -48,6 +48,8 @@ struct EwStep {
     // HOOK: capture p of one element (g-index) into *cap_dst (stand-alone kernels only)
     long cap_idx;
     float* cap_dst;
+    // float4 chain kernel: prefetch slots of p0 / p1 (elementwise.hip, plan_loads); -1: load in place, -2: not needed
+    int ls0, ls1;
 };
 
 struct EwChain {

@@ -7,6 +7,7 @@
 // every elementwise step that touches the same gradient into ONE pass (EwChain) so that each gradient element is
 // read and written once between two GEMMs.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -115,80 +116,187 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
     }
 }
 
-// float4 kernel: HW % 4 == 0, no trace.
-__global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restrict__ src, float4* __restrict__ dst,
-                                                        int accumulate, const EwChain ch, int C, int SB, int B, int HW4,
-                                                        float eps)
+// Operand prefetch plan of a chain (built on the host by plan_loads): the per-element operands of all steps -- the
+// forward stashes a / x of the hooks, ReLU masks, fan-in gradients -- do not depend on g, and several steps of one
+// chain read the same tensor (in-place ReLU: hook, BatchNorm hook and mask all see the ReLU output).  The kernel issues
+// the distinct loads together before interpreting the steps, instead of one dependent load after another.
+constexpr int EW_NLOADS = 4;      // distinct per-element operands hoisted per chain (ResNet / Light-CNN chains need <= 3)
+struct EwLoads {
+    int nl;
+    const float* lp[EW_NLOADS];
+    int lk[EW_NLOADS];                       // 0: indexed like the forward tensors (a-index), 1: like the gradient
+};
+
+// One element's prefetched operands.  Plain members, no arrays: the interpreter selects a slot with wave-uniform
+// compares, everything stays in registers.
+struct EwPre {
+    float4 g, od, v0, v1, v2, v3;
+    long idx, aidx;
+    bool ok;
+};
+
+__device__ __forceinline__ float pick1(float a0, float a1, float a2, float a3, int slot)
 {
-    const long per_c = (long)SB * HW4;
-    const long total = (long)C * per_c;
-    for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
-        const int c = (int)(idx / per_c);
-        const long r = idx - (long)c * per_c;
-        const int sb = (int)(r / HW4);
-        const int hw = (int)(r - (long)sb * HW4);
-        const int b = sb % B;
-        const long aidx = ((long)c * B + b) * HW4 + hw;
-        float4 gv = src[idx];
-        float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    float r = a0;
+    r = slot == 1 ? a1 : r;
+    r = slot == 2 ? a2 : r;
+    r = slot == 3 ? a3 : r;
+    return r;
+}
+// component-wise on plain floats: a select between float4 objects is lowered through memory (scratch)
+__device__ __forceinline__ float4 pick_slot(float4 v0, float4 v1, float4 v2, float4 v3, int slot)
+{
+    return make_float4(pick1(v0.x, v1.x, v2.x, v3.x, slot), pick1(v0.y, v1.y, v2.y, v3.y, slot),
+                       pick1(v0.z, v1.z, v2.z, v3.z, slot), pick1(v0.w, v1.w, v2.w, v3.w, slot));
+}
+
+__device__ __forceinline__ float4 ew_ld(const EwLoads& ld, int l, long idx, long aidx)
+{
+    return reinterpret_cast<const float4*>(ld.lp[l])[ld.lk[l] ? idx : aidx];
+}
+
+__device__ __forceinline__ void ew_issue(EwPre& e, const float4* __restrict__ src, const float4* __restrict__ dst, int accumulate,
+                                         const EwLoads& ld, int c, unsigned r, unsigned per_c, unsigned per_ca)
+{
+    e.ok = r < per_c;
+    const unsigned rr = e.ok ? r : 0u;
+    e.idx = (long)c * per_c + rr;
+    e.aidx = (long)c * per_ca + (rr % per_ca);             // sample b = sb % B, same (hw) position
+    e.g = src[e.idx];
+    e.v0 = e.v1 = e.v2 = e.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ld.nl > 0) e.v0 = ew_ld(ld, 0, e.idx, e.aidx);
+    if (ld.nl > 1) e.v1 = ew_ld(ld, 1, e.idx, e.aidx);
+    if (ld.nl > 2) e.v2 = ew_ld(ld, 2, e.idx, e.aidx);
+    if (ld.nl > 3) e.v3 = ew_ld(ld, 3, e.idx, e.aidx);
+    e.od = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (accumulate) e.od = dst[e.idx];
+}
+
+__device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, float4 gv, float4 od, float4 v0, float4 v1,
+                                             float4 v2, float4 v3, float4* __restrict__ dst,
+                                             int accumulate, const EwChain& ch, int c, float eps)
+{
+    if (!ok) return;
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll 1
-        for (int i = 0; i < ch.n; ++i) {
-            const EwStep& st = ch.s[i];
-            if (st.type == EW_HOOK) {
-                const float4 av = reinterpret_cast<const float4*>(st.p0)[aidx];
-                const float a[4] = {fmaxf(av.x, 0.f), fmaxf(av.y, 0.f), fmaxf(av.z, 0.f), fmaxf(av.w, 0.f)};
-                float p[4], zh[4];
+    for (int i = 0; i < ch.n; ++i) {
+        const EwStep& st = ch.s[i];
+        const int s0 = st.ls0, s1 = st.ls1;
+        if (st.type == EW_HOOK) {
+            if (s0 == -2) {          // p is not observed: the hook is relu(g) or the identity
+                if (st.action == HOOK_RELU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { zh[q] = fmaxf(g[q], 0.f); p[q] = a[q] * zh[q]; }
-                if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(p[0], p[1], p[2], p[3]);
-                if (st.action == HOOK_DIV) {
-                    float x[4];
-                    if (st.p1) {
-                        const float4 xv = reinterpret_cast<const float4*>(st.p1)[aidx];
-                        x[0] = fmaxf(xv.x, 0.f); x[1] = fmaxf(xv.y, 0.f); x[2] = fmaxf(xv.z, 0.f); x[3] = fmaxf(xv.w, 0.f);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) x[q] = a[q];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] = __fdiv_rn(p[q], x[q] + eps);
-                } else if (st.action == HOOK_RELU) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] = zh[q];
+                    for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
                 }
-            } else if (st.type == EW_MASK) {
-                const float4 tv = reinterpret_cast<const float4*>(st.p0)[aidx];
-                g[0] = tv.x > 0.f ? g[0] : 0.f; g[1] = tv.y > 0.f ? g[1] : 0.f;
-                g[2] = tv.z > 0.f ? g[2] : 0.f; g[3] = tv.w > 0.f ? g[3] : 0.f;
-            } else if (st.type == EW_SCALE_C) {
-                const float sc = st.p0[c];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] *= sc;
-            } else if (st.type == EW_SCALE) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] *= st.f;
-            } else if (st.type == EW_STORE) {
-                reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(g[0], g[1], g[2], g[3]);
-            } else if (st.type == EW_ADDP) {
-                const float4 d = reinterpret_cast<const float4*>(st.p0)[idx];
-                g[0] += d.x; g[1] += d.y; g[2] += d.z; g[3] += d.w;
-            } else if (st.type == EW_AFFINE_C) {
-                const float al = st.p0[c], be = st.p1[c];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(__fmul_rn(g[q], al), be);
-            } else if (st.type == EW_RELU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
-            } else {
-                const float al = st.p0[c], be = st.p1[c];
-                reinterpret_cast<float4*>(st.pstore)[idx] =
-                    make_float4(__fadd_rn(__fmul_rn(fmaxf(g[0], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[1], 0.f), al), be),
-                                __fadd_rn(__fmul_rn(fmaxf(g[2], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[3], 0.f), al), be));
+                continue;
             }
+            const float4 av = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[aidx];
+            const float a[4] = {fmaxf(av.x, 0.f), fmaxf(av.y, 0.f), fmaxf(av.z, 0.f), fmaxf(av.w, 0.f)};
+            float p[4], zh[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { zh[q] = fmaxf(g[q], 0.f); p[q] = a[q] * zh[q]; }
+            if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(p[0], p[1], p[2], p[3]);
+            if (st.action == HOOK_DIV) {
+                float x[4];
+                if (st.p1) {
+                    const float4 xv = s1 >= 0 ? pick_slot(v0, v1, v2, v3, s1) : reinterpret_cast<const float4*>(st.p1)[aidx];
+                    x[0] = fmaxf(xv.x, 0.f); x[1] = fmaxf(xv.y, 0.f); x[2] = fmaxf(xv.z, 0.f); x[3] = fmaxf(xv.w, 0.f);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = a[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = __fdiv_rn(p[q], x[q] + eps);
+            } else if (st.action == HOOK_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = zh[q];
+            }
+        } else if (st.type == EW_MASK) {
+            const float4 tv = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[aidx];
+            g[0] = tv.x > 0.f ? g[0] : 0.f; g[1] = tv.y > 0.f ? g[1] : 0.f;
+            g[2] = tv.z > 0.f ? g[2] : 0.f; g[3] = tv.w > 0.f ? g[3] : 0.f;
+        } else if (st.type == EW_SCALE_C) {
+            const float sc = st.p0[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] *= sc;
+        } else if (st.type == EW_SCALE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] *= st.f;
+        } else if (st.type == EW_STORE) {
+            reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(g[0], g[1], g[2], g[3]);
+        } else if (st.type == EW_ADDP) {
+            const float4 d = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[idx];
+            g[0] += d.x; g[1] += d.y; g[2] += d.z; g[3] += d.w;
+        } else if (st.type == EW_AFFINE_C) {
+            const float al = st.p0[c], be = st.p1[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(__fmul_rn(g[q], al), be);
+        } else if (st.type == EW_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
+        } else {
+            const float al = st.p0[c], be = st.p1[c];
+            reinterpret_cast<float4*>(st.pstore)[idx] =
+                make_float4(__fadd_rn(__fmul_rn(fmaxf(g[0], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[1], 0.f), al), be),
+                            __fadd_rn(__fmul_rn(fmaxf(g[2], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[3], 0.f), al), be));
         }
-        float4 o = make_float4(g[0], g[1], g[2], g[3]);
-        if (accumulate) { const float4 d = dst[idx]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
-        dst[idx] = o;
+    }
+    float4 o = make_float4(g[0], g[1], g[2], g[3]);
+    if (accumulate) { o.x += od.x; o.y += od.y; o.z += od.z; o.w += od.w; }
+    dst[idx] = o;
+}
+
+// float4 kernel: HW % 4 == 0, no trace.  blockIdx.y = channel; a thread owns EW_U float4 elements of the channel row
+// [SB][HW4], one block apart, and has all of their operand loads in flight before it interprets the steps.
+constexpr int EW_U = 2;
+__global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                        int accumulate, const EwChain ch, const EwLoads ld, int C, int SB,
+                                                        int B, int HW4, float eps)
+{
+    const int c = blockIdx.y;
+    const unsigned per_c = (unsigned)SB * (unsigned)HW4;       // < 2^31 (every tensor is < 2^31 bytes)
+    const unsigned per_ca = (unsigned)B * (unsigned)HW4;
+    const unsigned r0 = blockIdx.x * (unsigned)(NT * EW_U) + threadIdx.x;
+    EwPre e0, e1;
+    ew_issue(e0, src, dst, accumulate, ld, c, r0, per_c, per_ca);
+    ew_issue(e1, src, dst, accumulate, ld, c, r0 + NT, per_c, per_ca);
+    ew_interpret(e0.ok, e0.idx, e0.aidx, e0.g, e0.od, e0.v0, e0.v1, e0.v2, e0.v3, dst, accumulate, ch, c, eps);
+    ew_interpret(e1.ok, e1.idx, e1.aidx, e1.g, e1.od, e1.v0, e1.v1, e1.v2, e1.v3, dst, accumulate, ch, c, eps);
+}
+
+// Assign prefetch slots.  A load may be hoisted only if nothing in the chain (or the final store) writes the buffer it
+// reads: stores land at the same element index in the same thread, after the prefetch.
+static void plan_loads(EwChain& ch, const float* src, const float* dst, EwLoads& ld)
+{
+    memset(&ld, 0, sizeof(ld));
+    auto written = [&](const float* p) {
+        if (p == dst) return true;
+        for (int i = 0; i < ch.n; ++i)
+            if (ch.s[i].pstore == p) return true;
+        return false;
+    };
+    auto slot_for = [&](const float* p, int kind) -> int {
+        if (!p || written(p)) return -1;
+        for (int l = 0; l < ld.nl; ++l)
+            if (ld.lp[l] == p && ld.lk[l] == kind) return l;
+        if (ld.nl == EW_NLOADS) return -1;
+        ld.lp[ld.nl] = p;
+        ld.lk[ld.nl] = kind;
+        return ld.nl++;
+    };
+    for (int i = 0; i < ch.n; ++i) {
+        EwStep& st = ch.s[i];
+        st.ls0 = -1;
+        st.ls1 = -1;
+        if (st.type == EW_HOOK) {
+            if (!st.pstore && !st.trace && st.action != HOOK_DIV) { st.ls0 = -2; continue; }
+            st.ls0 = slot_for(st.p0, 0);
+            if (st.action == HOOK_DIV && st.p1) st.ls1 = slot_for(st.p1, 0);
+        } else if (st.type == EW_MASK) {
+            st.ls0 = slot_for(st.p0, 0);
+        } else if (st.type == EW_ADDP) {
+            st.ls0 = slot_for(st.p0, 1);
+        }
     }
 }
 
@@ -237,16 +345,24 @@ __global__ __launch_bounds__(NT) void affine_c_kernel(const float* __restrict__ 
     }
 }
 
+constexpr int ST_U = 4;    // float4 elements per thread of the streaming kernels (all loads issued before the stores)
+
 __global__ __launch_bounds__(NT) void affine_c_kernel_v4(const float4* __restrict__ in, float4* __restrict__ out,
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         int C, long per_c4, int relu_in, int relu_out)
 {
-    const long total = (long)C * per_c4;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i / per_c4);
-        const float al = alpha[c], be = beta[c];
-        float4 v = in[i];
-        float q[4] = {v.x, v.y, v.z, v.w};
+    const int c = blockIdx.y;
+    const float al = alpha[c], be = beta[c];
+    const long row = (long)c * per_c4;
+    const long r0 = (long)blockIdx.x * (NT * ST_U) + threadIdx.x;
+    float4 v[ST_U];
+#pragma unroll
+    for (int u = 0; u < ST_U; ++u)
+        if (r0 + u * NT < per_c4) v[u] = in[row + r0 + u * NT];
+#pragma unroll
+    for (int u = 0; u < ST_U; ++u) {
+        if (r0 + u * NT >= per_c4) continue;
+        float q[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float t = q[k];
@@ -255,7 +371,7 @@ __global__ __launch_bounds__(NT) void affine_c_kernel_v4(const float4* __restric
             if (relu_out) t = fmaxf(t, 0.f);
             q[k] = t;
         }
-        out[i] = make_float4(q[0], q[1], q[2], q[3]);
+        out[row + r0 + u * NT] = make_float4(q[0], q[1], q[2], q[3]);
     }
 }
 
@@ -285,13 +401,20 @@ __global__ __launch_bounds__(NT) void add2_kernel(const float* __restrict__ a, c
 __global__ __launch_bounds__(NT) void add2_kernel_v4(const float4* __restrict__ a, const float4* __restrict__ b,
                                                     float4* __restrict__ out, long n4, int relu_a, int relu_b, int relu_out)
 {
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
-        float4 x = a[i], y = b[i];
+    const long i0 = (long)blockIdx.x * (NT * ST_U) + threadIdx.x;
+    float4 xs[ST_U], ys[ST_U];
+#pragma unroll
+    for (int u = 0; u < ST_U; ++u)
+        if (i0 + u * NT < n4) { xs[u] = a[i0 + u * NT]; ys[u] = b[i0 + u * NT]; }
+#pragma unroll
+    for (int u = 0; u < ST_U; ++u) {
+        if (i0 + u * NT >= n4) continue;
+        float4 x = xs[u], y = ys[u];
         if (relu_a) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
         if (relu_b) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
         float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
         if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        out[i] = v;
+        out[i0 + u * NT] = v;
     }
 }
 
@@ -584,10 +707,16 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
         if (chain.s[i].prior_sb >= 0 || chain.s[i].cap_dst) special = true;
     }
     const long total = (long)C * SB * HW;
-    if (!trace && !special && (HW % 4) == 0) {
-        hipLaunchKernelGGL(ew_chain_kernel_v4, dim3(grid_for(total / 4)), dim3(NT), 0, s,
-                           reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), accumulate, chain, C, SB, B,
-                           HW / 4, eps);
+    for (int i = 0; i < chain.n; ++i)
+        if (accumulate && chain.s[i].pstore == dst) special = true;   // the float4 kernel reads dst before the chain runs
+    if (!trace && !special && (HW % 4) == 0 && C <= 65535) {
+        EwLoads ld;
+        EwChain planned = chain;
+        plan_loads(planned, src, dst, ld);
+        const long per_c4 = (long)SB * (HW / 4);
+        hipLaunchKernelGGL(ew_chain_kernel_v4, dim3((unsigned)((per_c4 + NT * EW_U - 1) / (NT * EW_U)), C), dim3(NT), 0, s,
+                           reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB,
+                           B, HW / 4, eps);
     } else if (trace) {
         hipLaunchKernelGGL(ew_chain_kernel<true>, dim3(grid_for(total)), dim3(NT), 0, s, src, dst, accumulate, chain, C, SB,
                            B, HW, eps);
@@ -608,8 +737,8 @@ void launch_cnhw_to_nchw(const float* in, float* out, int N, int C, int HW, hipS
 void launch_affine_c(const float* in, float* out, const float* alpha, const float* beta, int C, long per_c, int relu_in,
                      int relu_out, hipStream_t s)
 {
-    if ((per_c % 4) == 0)
-        hipLaunchKernelGGL(affine_c_kernel_v4, dim3(grid_for((long)C * per_c / 4)), dim3(NT), 0, s,
+    if ((per_c % 4) == 0 && C <= 65535)
+        hipLaunchKernelGGL(affine_c_kernel_v4, dim3((unsigned)((per_c / 4 + NT * ST_U - 1) / (NT * ST_U)), C), dim3(NT), 0, s,
                            reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), alpha, beta, C, per_c / 4,
                            relu_in, relu_out);
     else
@@ -627,7 +756,7 @@ void launch_scale(const float* in, float* out, long n, float f, int relu_in, hip
 void launch_add2(const float* a, const float* b, float* out, long n, int relu_a, int relu_b, int relu_out, hipStream_t s)
 {
     if ((n % 4) == 0)
-        hipLaunchKernelGGL(add2_kernel_v4, dim3(grid_for(n / 4)), dim3(NT), 0, s, reinterpret_cast<const float4*>(a),
+        hipLaunchKernelGGL(add2_kernel_v4, dim3((unsigned)((n / 4 + NT * ST_U - 1) / (NT * ST_U))), dim3(NT), 0, s, reinterpret_cast<const float4*>(a),
                            reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n / 4, relu_a, relu_b, relu_out);
     else
         hipLaunchKernelGGL(add2_kernel, dim3(grid_for(n)), dim3(NT), 0, s, a, b, out, n, relu_a, relu_b, relu_out);

@@ -1068,6 +1068,16 @@ xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out, bool plain = 
     xfr_status st = make_plan(e, seed_tensor, e->plans.back(), plain);
     if (st != XFR_OK) { e->plans.pop_back(); return st; }
     if (!plain) fuse_plan(e, e->plans.back());
+    if (getenv("XFR_PLAN_DUMP")) {   // debug: the fused backward schedule, one line per launch
+        static const char* kn[] = {"EW", "CONV_BWD", "MAXPOOL_BWD", "AVGPOOL_BWD", "COPY", "MAXHALVES_BWD", "NORMALIZE_BWD", "ZERO"};
+        for (const BwdStep& st : e->plans.back().fused) {
+            const int tt = st.kind == ST_EW ? st.ew_t : st.dst_t;
+            fprintf(stderr, "plan %-13s src %3d dst %3d acc %d", kn[st.kind], st.src_t, st.dst_t, st.accumulate);
+            if (tt >= 0) fprintf(stderr, " [%d x %d x %d]", e->tens[tt].C, e->tens[tt].H, e->tens[tt].W);
+            for (const auto& sy : st.chain) fprintf(stderr, " (%d:%d t%d x%d)", sy.type, sy.action, sy.t0, sy.x_t);
+            fprintf(stderr, "\n");
+        }
+    }
     *out = &e->plans.back();
     return XFR_OK;
 }
