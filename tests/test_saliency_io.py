@@ -1,0 +1,87 @@
+"""On-disk saliency format + resume (xfr_amd/saliency_io.py; reference python/xfr/show.py:196-232,131-137,46-129)."""
+import os
+
+import numpy as np
+import pytest
+
+from xfr_amd import saliency_io as SIO
+
+
+def test_method_names_match_generator_stems():
+    # generate_whitebox_saliency.py:304-309,340-356,383-391
+    assert SIO.method_name('meanEBP', 'affineonly_with_prior', 6, 'cuda') == 'meanEBP_mode=awp_v06_cuda'
+    assert SIO.method_name('contrastive', 'norelu', 6, 'cpu') == 'contrastive_triplet_ebp_mode=norelu_v06_cpu'
+    assert SIO.method_name('contrastive', 'norelu', 6, 'cuda', truncate_percent=20) == \
+        'trunc_contrastive_triplet_ebp_mode=norelu_v06_pct20_cuda'
+    assert SIO.method_name('weighted-subtree', 'affineonly_with_prior', 6, 'cuda', topk=32, mode_weighted='norelu') == \
+        'weighted_subtree_triplet_ebp_mode=awp,norelu_v06_top32_cuda'
+    with pytest.raises(RuntimeError):
+        SIO.method_name('rise', 'norelu')
+    assert SIO.saliency_paths('/o', '00012', 'm') == ('/o/00012-m-saliency-overlay.png', '/o/00012-m-saliency.npz')
+
+
+def test_jet_matches_matplotlib_table():
+    # values of matplotlib.cm.jet at 0, 0.5, 1 and at a knot
+    np.testing.assert_allclose(SIO.jet(0.0), [0.0, 0.0, 0.5], atol=1e-12)
+    np.testing.assert_allclose(SIO.jet(1.0), [0.5, 0.0, 0.0], atol=1e-12)
+    np.testing.assert_allclose(SIO.jet(0.5), [0.4901960784, 1.0, 0.4775458570], atol=1e-6)
+    np.testing.assert_allclose(SIO.jet(2.0), SIO.jet(1.0))
+    assert SIO.jet(np.zeros((3, 4))).shape == (3, 4, 3)
+
+
+def test_process_saliency_resize_semantics():
+    rng = np.random.default_rng(0)
+    sm = rng.random((112, 112))
+    img = np.zeros((224, 224, 3))
+    out = SIO.processSaliency(img, sm)
+    assert out.shape == (224, 224) and out.min() >= 0.0 and out.max() <= 1.0 + 1e-12
+    # same size: normalisation only (show.py:133-134)
+    same = SIO.processSaliency(np.zeros((112, 112, 3)), sm)
+    np.testing.assert_allclose(same, (sm - sm.min()) / ((sm - sm.min()).max() + 1e-9), atol=1e-12)
+    # a cubic spline reproduces a linear ramp; pixel centres map as (i + 0.5) / zoom - 0.5 (grid_mode)
+    ramp = np.tile(np.arange(32, dtype=np.float64), (32, 1))
+    up = SIO._resize_cubic(ramp, (64, 64))
+    i = np.arange(16, 48)
+    np.testing.assert_allclose(up[32, i], (i + 0.5) / 2 - 0.5, atol=1e-3)   # the zero border decays into the interior
+    # shrinking pre-smooths and stays inside the input range
+    down = SIO._resize_cubic(sm, (56, 56))
+    assert down.shape == (56, 56) and down.min() >= 0.0 and down.max() <= sm.max()
+
+
+def test_blend_properties():
+    img = np.full((64, 48, 3), 0.25)
+    sm = np.zeros((16, 12)); sm[8, 6] = 1.0
+    ov = SIO.blend_saliency_map(img, sm)
+    assert ov.shape == (64, 48, 3) and ov.min() >= 0.0 and ov.max() <= 1.0
+    np.testing.assert_allclose(ov[0, 0], img[0, 0] * (1 - 0.0) + 0.0, atol=1e-6)      # zero saliency: the image shows through
+    assert np.abs(ov[34, 26] - img[34, 26]).max() > 0.3                                 # the hot spot is coloured
+    np.testing.assert_allclose(SIO.blend_saliency_map(img, np.ones((4, 4))), img)       # constant map is suppressed
+
+
+def test_create_save_smap_format_and_resume(tmp_path):
+    out = str(tmp_path / 'subject_ID_7' / 'aligned')
+    probe = (np.random.default_rng(1).random((160, 128, 3)) * 255).astype(np.uint8)
+    calls = []
+
+    def smap_fn():
+        calls.append(1)
+        m = np.random.default_rng(2).random((112, 112)).astype(np.float32)
+        return m / m.sum()
+
+    name = SIO.method_name('contrastive', 'affineonly_with_prior', 6, 'cuda')
+    assert SIO.create_save_smap(name, out, False, smap_fn, '00003', probe) is True
+    ov, npz = SIO.saliency_paths(out, '00003', name)
+    assert os.path.exists(ov) and os.path.exists(npz) and not os.path.exists(npz + '.tmp.npz')
+    with np.load(npz) as z:
+        assert list(z.keys()) == ['saliency_map']
+        sm = z['saliency_map']
+    assert sm.shape == (160, 128) and sm.min() >= 0.0 and abs(sm.max() - 1.0) < 1e-3       # min-max normalised, probe-sized
+    import PIL.Image
+    assert PIL.Image.open(ov).size == (128, 160)
+    # resume: nothing is recomputed while both files exist
+    assert SIO.create_save_smap(name, out, False, smap_fn, '00003', probe) is False and len(calls) == 1
+    # a missing npz (interrupted job) or overwrite=True recomputes
+    os.remove(npz)
+    assert SIO.create_save_smap(name, out, False, smap_fn, '00003', probe) is True and len(calls) == 2
+    assert SIO.create_save_smap(name, out, True, smap_fn, '00003', probe) is True and len(calls) == 3
+    np.testing.assert_array_equal(SIO.load_smap(out, '00003', name), sm)

@@ -28,11 +28,15 @@ def main():
     ap.add_argument('--mates', type=int, default=4, help='mate / non-mate images per job')
     ap.add_argument('--topk', type=int, default=32)
     ap.add_argument('--num-classes', type=int, default=65359)
+    ap.add_argument('--output-dir', default=None,
+                    help='write {mask_id}-{method}-saliency.npz + overlay PNG per job and method (show.py:196-232); '
+                         'methods whose files exist are skipped unless --overwrite (the generator\'s resume)')
+    ap.add_argument('--overwrite', action='store_true')
     args = ap.parse_args()
     import numpy as np
     import torch
     import torch.distributed as dist
-    from xfr_amd import shard, synth
+    from xfr_amd import saliency_io as SIO, shard, synth
     from xfr_amd.models import resnet, whitebox as WB
 
     rank, world, local = shard.init_process_group()
@@ -51,7 +55,7 @@ def main():
 
     lo, hi = shard.shard_range(args.jobs, rank, world)
     k = args.mates
-    done, t_methods = 0, np.zeros(4)
+    done, t_methods, written, probe_u8 = 0, np.zeros(4), 0, None
     # synthetic stand-ins for the aligned IJB-C crops (git-LFS pointers in the reference): a small pool, generated up front
     pool = [synth.synth_smooth_images(2 * k + 1, (3, 224, 224), seed=10000 + j, mean=resnet.MEAN_RGB).to(dev) for j in range(8)]
     torch.cuda.synchronize()
@@ -59,24 +63,55 @@ def main():
     for job in range(lo, hi):
         imgs = pool[job % len(pool)]
         probe, mates, nonmates = imgs[:1], imgs[1:1 + k], imgs[1 + k:]
-        t = time.perf_counter()
-        ones = torch.ones((1, args.num_classes))
-        wbn._classifier = None                                  # the checkpoint's hooked 65359-way fc2 for meanEBP
-        s_mean = wb.ebp(probe, ones)
-        t1 = time.perf_counter()
-        x_m = wb.encode(mates).mean(dim=0, keepdim=True)
-        x_n = wb.encode(nonmates).mean(dim=0, keepdim=True)
-        x_m = x_m / x_m.norm()
-        x_n = x_n / x_n.norm()
-        wb.net.set_triplet_classifier((1.0 / 2500.0) * x_m.cpu(), (1.0 / 2500.0) * x_n.cpu())
-        s_con = wb.contrastive_ebp(probe, 0, 1)
-        t2 = time.perf_counter()
-        s_tru = wb.truncated_contrastive_ebp(probe, 0, 1, percentile=20)
-        t3 = time.perf_counter()
-        s_sub = wb.weighted_subtree_ebp(probe, 0, 1, topk=args.topk, verbose=False, subtree_mode='norelu')[0]
-        t4 = time.perf_counter()
-        for m in (s_mean, s_con, s_tru, s_sub):
-            assert m.shape == (112, 112) and np.isfinite(m).all() and abs(float(m.sum()) - 1.0) < 1e-3
+        state = {'cls': False}
+
+        def ensure_cls():
+            # run_contrastive_triplet_ebp (generate_whitebox_saliency.py:79-104): averaged, unit-normalised encodings / 2500
+            if not state['cls']:
+                x_m = wb.encode(mates).mean(dim=0, keepdim=True)
+                x_n = wb.encode(nonmates).mean(dim=0, keepdim=True)
+                wb.net.set_triplet_classifier((1.0 / 2500.0) * (x_m / x_m.norm()).cpu(), (1.0 / 2500.0) * (x_n / x_n.norm()).cpu())
+                state['cls'] = True
+
+        def f_mean():
+            wbn._classifier = None                              # the checkpoint's hooked 65359-way fc2 for meanEBP
+            state['cls'] = False
+            return wb.ebp(probe, torch.ones((1, args.num_classes)))
+
+        def f_con():
+            ensure_cls()
+            return wb.contrastive_ebp(probe, 0, 1)
+
+        def f_tru():
+            ensure_cls()
+            return wb.truncated_contrastive_ebp(probe, 0, 1, percentile=20)
+
+        def f_sub():
+            ensure_cls()
+            return wb.weighted_subtree_ebp(probe, 0, 1, topk=args.topk, verbose=False, subtree_mode='norelu')[0]
+
+        mode = wb.ebp_subtree_mode()
+        methods = [(SIO.method_name('meanEBP', mode, 6, 'cuda'), f_mean),
+                   (SIO.method_name('contrastive', mode, 6, 'cuda'), f_con),
+                   (SIO.method_name('contrastive', mode, 6, 'cuda', truncate_percent=20), f_tru),
+                   (SIO.method_name('weighted-subtree', mode, 6, 'cuda', topk=args.topk, mode_weighted='norelu'), f_sub)]
+        stamps = [time.perf_counter()]
+        for name, fn in methods:
+            def checked(fn=fn):
+                m = fn()
+                assert m.shape == (112, 112) and np.isfinite(m).all() and abs(float(m.sum()) - 1.0) < 1e-3
+                return m
+            if args.output_dir:
+                if probe_u8 is None:          # displayable stand-in for the aligned crop: min-max scaled to [0, 1]
+                    disp = probe[0].permute(1, 2, 0).cpu().numpy().astype(np.float64)
+                    probe_u8 = (disp - disp.min()) / (disp.max() - disp.min() + 1e-9)
+                written += int(SIO.create_save_smap(name, os.path.join(args.output_dir, 'subject_ID_%d' % (job % len(pool))), args.overwrite,
+                                                    checked, '%05d' % job, probe_u8))
+            else:
+                checked()
+            stamps.append(time.perf_counter())
+        probe_u8 = None
+        t, t1, t2, t3, t4 = stamps
         t_methods += np.array([t1 - t, t2 - t1, t3 - t2, t4 - t3])
         done += 1
     torch.cuda.synchronize()
@@ -95,6 +130,7 @@ def main():
                           'n_gpus': world, 'seconds': dt, 'jobs_per_s': total / dt,
                           'ms_per_job_rank0': {'meanEBP': per[0], 'contrastive(+%d encodes)' % (2 * k): per[1], 'truncated': per[2],
                                                'weighted_subtree_top%d' % args.topk: per[3]},
+                          'maps_written_rank0': written if args.output_dir else None,
                           'reference': '~36 h for 541 jobs on one Titan X (README.md:166) = ~240 s/job'}))
     if world > 1:
         dist.barrier()
