@@ -57,6 +57,55 @@ struct EwChain {
     EwStep s[XFR_MAX_EW_STEPS];
 };
 
+// Operand prefetch plan of a chain.  The per-element operands of all steps -- the forward stashes a / x of the hooks, ReLU
+// masks, fan-in gradients -- do not depend on g, and several steps of one chain read the same tensor (in-place ReLU: the
+// ReLU hook, the BatchNorm hook and the mask all see the ReLU output).  The float4 chain kernel and the chain epilogue
+// of the GEMM issue the distinct loads together before they interpret the steps, instead of one dependent load after
+// another.  EwStep::ls0/ls1 hold the slot of p0 / p1.
+constexpr int EW_NLOADS = 4;      // distinct per-element operands hoisted per chain (ResNet / Light-CNN chains need <= 4)
+struct EwLoads {
+    int nl;
+    const float* lp[EW_NLOADS];
+    int lk[EW_NLOADS];                       // 0: indexed like the forward tensors (a-index), 1: like the gradient
+};
+
+// Assign prefetch slots.  A load may be hoisted only if nothing in the chain (or the final store to dst) writes the
+// buffer it reads: stores land at the same element index in the same thread, after the prefetch.
+inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
+{
+    ld.nl = 0;
+    for (int l = 0; l < EW_NLOADS; ++l) { ld.lp[l] = nullptr; ld.lk[l] = 0; }
+    auto written = [&](const float* p) {
+        if (p == dst) return true;
+        for (int i = 0; i < ch.n; ++i)
+            if (ch.s[i].pstore == p) return true;
+        return false;
+    };
+    auto slot_for = [&](const float* p, int kind) -> int {
+        if (!p || written(p)) return -1;
+        for (int l = 0; l < ld.nl; ++l)
+            if (ld.lp[l] == p && ld.lk[l] == kind) return l;
+        if (ld.nl == EW_NLOADS) return -1;
+        ld.lp[ld.nl] = p;
+        ld.lk[ld.nl] = kind;
+        return ld.nl++;
+    };
+    for (int i = 0; i < ch.n; ++i) {
+        EwStep& st = ch.s[i];
+        st.ls0 = -1;
+        st.ls1 = -1;
+        if (st.type == EW_HOOK) {
+            if (!st.pstore && !st.trace && st.action != HOOK_DIV) { st.ls0 = -2; continue; }
+            st.ls0 = slot_for(st.p0, 0);
+            if (st.action == HOOK_DIV && st.p1) st.ls1 = slot_for(st.p1, 0);
+        } else if (st.type == EW_MASK) {
+            st.ls0 = slot_for(st.p0, 0);
+        } else if (st.type == EW_ADDP) {
+            st.ls0 = slot_for(st.p0, 1);
+        }
+    }
+}
+
 // ---- implicit-GEMM convolution -------------------------------------------------------------------------------
 struct ConvParams {
     const float* in;    // [Cin][NB][H][W]
@@ -91,6 +140,7 @@ struct ConvParams {
     int chain_B;        // forward batch for the a-index of the epilogue chain
     float chain_eps;    // eps of the hook divide
     EwChain chain;      // epilogue micro-program applied to half 0 before the final store (n == 0: none)
+    EwLoads chain_ld;   // its operand prefetch plan (set by launch_conv_gemm)
 };
 
 constexpr int XFR_TAIL_MAX_TILES = 256;

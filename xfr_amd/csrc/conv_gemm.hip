@@ -73,7 +73,16 @@ __device__ inline void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TCO, int TM, int BK, int NST, int MODE, bool RELU>
+__device__ __forceinline__ float pick4(float a0, float a1, float a2, float a3, int slot)
+{   // slot is wave-uniform
+    float r = a0;
+    r = slot == 1 ? a1 : r;
+    r = slot == 2 ? a2 : r;
+    r = slot == 3 ? a3 : r;
+    return r;
+}
+
+template <int TCO, int TM, int BK, int NST, int MODE, bool RELU, bool CHAIN>
 __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     constexpr int MI = TCO / 64;   // MFMA tiles per wave along co
@@ -395,117 +404,161 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         }
         return;
     }
-    const bool use_chain = (p.chain.n > 0) && (half == 0);
+    if constexpr (CHAIN) {
+        // Epilogue with a fused micro-program (backward: [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP ->
+        // the next GEMM's input).  The 16 accumulator registers of a 32x32 tile are 4 groups of 4 consecutive output
+        // channels; they are processed group by group, and all per-element operands of a group (plan in
+        // p.chain_ld, <= 4 distinct tensors) are in flight together before the steps are interpreted: every workgroup of
+        // a launch reaches its epilogue at the same time, so a chain of dependent loads here is paid in full.
+        const EwLoads& ld = p.chain_ld;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
-        if (m >= p.M) continue;
-        long col;
-        long row_stride;
-        const int ohw = p.OH * p.OW;
-        if (p.out_stride == 1) {
-            col = m;
-            row_stride = (long)p.out_nb * ohw;
-        } else {
-            const int n = m / ohw;
-            const int r = m - n * ohw;
-            const int oh = r / p.OW;
-            const int ow = r - oh * p.OW;
-            col = ((long)n * p.out_H + (long)oh * p.out_stride) * p.out_W + (long)ow * p.out_stride;
-            row_stride = (long)p.out_nb * p.out_H * p.out_W;
-        }
-        long acol = 0, arow = 0;
-        if (use_chain) {
+        for (int j = 0; j < NJ; ++j) {
+            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
+            if (m >= p.M) continue;
+            const int ohw = p.OH * p.OW;
+            const long col = m;                                   // chains are only fused into dense (out_stride 1) launches
+            const long row_stride = (long)p.out_nb * ohw;
             const int sb = m / ohw;
             const int hw = m - sb * ohw;
-            acol = (long)(sb % p.chain_B) * ohw + hw;
-            arow = (long)p.chain_B * ohw;
-        }
+            const long acol = (long)(sb % p.chain_B) * ohw + hw;
+            const long arow = (long)p.chain_B * ohw;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            // the 16 accumulator registers of a 32x32 tile are 4 groups of 4 consecutive output channels
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int co4 = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg;   // channels co4 .. co4+3
-                float g[4];
-                int gi[4];          // g-index (elements; every tensor is < 2^31 bytes)
-                bool ok[4];
+                for (int hf = 0; hf < 4; ++hf) {
+                    float g[4], pv0[4], pv1[4], pv2[4], pv3[4];
+                    int gi[4], ai[4];
+                    bool ok[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int co = co4 + q;
-                    ok[q] = co < p.CoutTot;
-                    gi[q] = (int)((long)co * row_stride + col);
-                    float v = acc[i][j][rg * 4 + q];
-                    if (ok[q]) {
-                        if (bsel) v += bsel[co];
-                        if (p.accumulate) v += osel[gi[q]];
+                    for (int e8 = 0; e8 < 4; ++e8) {
+                        const int rg = hf, q = e8;
+                        const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
+                        ok[e8] = co < p.CoutTot;
+                        const int cc = ok[e8] ? co : 0;
+                        gi[e8] = (int)((long)cc * row_stride + col);
+                        ai[e8] = (int)((long)cc * arow + acol);
+                        pv0[e8] = pv1[e8] = pv2[e8] = pv3[e8] = 0.f;
                     }
-                    g[q] = v;
-                }
-                if (use_chain) {
-                    int ai[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) ai[q] = (int)((long)(co4 + q) * arow + acol);
+                    for (int e8 = 0; e8 < 4; ++e8) {
+                        if (ld.nl > 0) pv0[e8] = ld.lp[0][ld.lk[0] ? gi[e8] : ai[e8]];
+                        if (ld.nl > 1) pv1[e8] = ld.lp[1][ld.lk[1] ? gi[e8] : ai[e8]];
+                        if (ld.nl > 2) pv2[e8] = ld.lp[2][ld.lk[2] ? gi[e8] : ai[e8]];
+                        if (ld.nl > 3) pv3[e8] = ld.lp[3][ld.lk[3] ? gi[e8] : ai[e8]];
+                    }
+#pragma unroll
+                    for (int e8 = 0; e8 < 4; ++e8) {
+                        const int rg = hf, q = e8;
+                        const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
+                        float v = acc[i][j][rg * 4 + q];
+                        if (ok[e8]) {
+                            if (bsel) v += bsel[co];
+                            if (p.accumulate) v += osel[gi[e8]];
+                        }
+                        g[e8] = v;
+                    }
 #pragma unroll 1
                     for (int sidx = 0; sidx < p.chain.n; ++sidx) {
                         const EwStep& st = p.chain.s[sidx];
-                        const int type = st.type;
+                        const int type = st.type, s0 = st.ls0, s1 = st.ls1;
                         if (type == EW_HOOK) {
-                            const float* __restrict__ pa = st.p0;
-                            const float* __restrict__ px = st.p1;
+                            if (s0 == -2) {                      // p is not observed: relu(g) or the identity
+                                if (st.action == HOOK_RELU) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                if (ok[q]) {
-                                    const float a = fmaxf(pa[ai[q]], 0.f);
-                                    const float zh = fmaxf(g[q], 0.f);
-                                    const float pp = a * zh;
-                                    if (st.pstore) st.pstore[gi[q]] = pp;
-                                    if (st.action == HOOK_DIV) {
-                                        const float x = px ? fmaxf(px[ai[q]], 0.f) : a;
-                                        g[q] = __fdiv_rn(pp, x + p.chain_eps);
-                                    } else if (st.action == HOOK_RELU) {
-                                        g[q] = zh;
-                                    }
+                                    for (int e8 = 0; e8 < 4; ++e8) g[e8] = fmaxf(g[e8], 0.f);
+                                }
+                                continue;
+                            }
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                if (!ok[e8]) continue;
+                                const float a = fmaxf(s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]], 0.f);
+                                const float zh = fmaxf(g[e8], 0.f);
+                                const float pp = a * zh;
+                                if (st.pstore) st.pstore[gi[e8]] = pp;
+                                if (st.action == HOOK_DIV) {
+                                    const float x = st.p1 ? fmaxf(s1 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s1) : st.p1[ai[e8]], 0.f) : a;
+                                    g[e8] = __fdiv_rn(pp, x + p.chain_eps);
+                                } else if (st.action == HOOK_RELU) {
+                                    g[e8] = zh;
                                 }
                             }
                         } else if (type == EW_MASK) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (ok[q]) g[q] = (st.p0[ai[q]] > 0.f) ? g[q] : 0.f;
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                if (!ok[e8]) continue;
+                                const float t = s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]];
+                                g[e8] = t > 0.f ? g[e8] : 0.f;
+                            }
                         } else if (type == EW_SCALE_C) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (ok[q]) g[q] *= st.p0[co4 + q];
+                            for (int e8 = 0; e8 < 4; ++e8)
+                                if (ok[e8]) g[e8] *= st.p0[co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8];
                         } else if (type == EW_SCALE) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) g[q] *= st.f;
+                            for (int e8 = 0; e8 < 4; ++e8) g[e8] *= st.f;
                         } else if (type == EW_STORE) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (ok[q]) st.pstore[gi[q]] = g[q];
+                            for (int e8 = 0; e8 < 4; ++e8)
+                                if (ok[e8]) st.pstore[gi[e8]] = g[e8];
                         } else if (type == EW_ADDP) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (ok[q]) g[q] += st.p0[gi[q]];
+                            for (int e8 = 0; e8 < 4; ++e8)
+                                if (ok[e8]) g[e8] += s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[gi[e8]];
                         } else if (type == EW_AFFINE_C) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (ok[q]) g[q] = __fadd_rn(__fmul_rn(g[q], st.p0[co4 + q]), st.p1[co4 + q]);
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
+                                if (ok[e8]) g[e8] = __fadd_rn(__fmul_rn(g[e8], st.p0[co]), st.p1[co]);
+                            }
                         } else if (type == EW_RELU) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
+                            for (int e8 = 0; e8 < 4; ++e8) g[e8] = fmaxf(g[e8], 0.f);
                         } else {   // EW_FORK_POSBN
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (ok[q])
-                                    st.pstore[gi[q]] = __fadd_rn(__fmul_rn(fmaxf(g[q], 0.f), st.p0[co4 + q]), st.p1[co4 + q]);
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
+                                if (ok[e8]) st.pstore[gi[e8]] = __fadd_rn(__fmul_rn(fmaxf(g[e8], 0.f), st.p0[co]), st.p1[co]);
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ok[q]) osel[gi[q]] = g[q];
+                    for (int e8 = 0; e8 < 4; ++e8)
+                        if (ok[e8]) osel[gi[e8]] = g[e8];
+                }
             }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
+            if (m >= p.M) continue;
+            long col;
+            long row_stride;
+            const int ohw = p.OH * p.OW;
+            if (p.out_stride == 1) {
+                col = m;
+                row_stride = (long)p.out_nb * ohw;
+            } else {
+                const int n = m / ohw;
+                const int r = m - n * ohw;
+                const int oh = r / p.OW;
+                const int ow = r - oh * p.OW;
+                col = ((long)n * p.out_H + (long)oh * p.out_stride) * p.out_W + (long)ow * p.out_stride;
+                row_stride = (long)p.out_nb * p.out_H * p.out_W;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wrow * (TCO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co >= p.CoutTot) continue;
+                    const long gi = (long)co * row_stride + col;
+                    float v = acc[i][j][r];
+                    if (bsel) v += bsel[co];
+                    if (p.accumulate) v += osel[gi];
+                    osel[gi] = v;
+                }
         }
     }
 }
@@ -595,10 +648,17 @@ void launch_one(const ConvParams& p, hipStream_t s)
             grid = q.tail_q + r * S;
         }
     }
+    if constexpr (TCO == 64 && TM == 64) {
+        if (q.chain.n > 0) {      // fused micro-program: backward launches only (no relu_in, one half)
+            ew_plan_loads(q.chain, q.out0, q.chain_ld);
+            hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, true>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+            return;
+        }
+    }
     if (p.relu_in)
-        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, true>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, true, false>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+        hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, false>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
 }
 
 template <int TCO, int TM, int BK, int NST>
@@ -661,6 +721,7 @@ void launch_conv_gemm(const ConvParams& p, hipStream_t s)
     if (p.force_cfg == 0 && cfg == 4 && remap4 > 0) cfg = remap4;
     static const int remap5 = getenv("XFR_CFG5") ? atoi(getenv("XFR_CFG5")) : 0;
     if (p.force_cfg == 0 && cfg == 5 && remap5 > 0) cfg = remap5;
+    if (p.chain.n > 0 && cfg != 4 && cfg != 5 && cfg != 9 && cfg != 10 && cfg != 11 && cfg != 12) cfg = 4;   // the chain epilogue exists for 64x64 tiles
     ConvParams q = p;
     q.ksplit = p.ksplit > 0 ? p.ksplit : conv_gemm_pick_ksplit(p, cfg);
     {   // a requested split is honoured only where the slab layout and the float4 reduce apply

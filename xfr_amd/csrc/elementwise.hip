@@ -116,17 +116,6 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
     }
 }
 
-// Operand prefetch plan of a chain (built on the host by plan_loads): the per-element operands of all steps -- the
-// forward stashes a / x of the hooks, ReLU masks, fan-in gradients -- do not depend on g, and several steps of one
-// chain read the same tensor (in-place ReLU: hook, BatchNorm hook and mask all see the ReLU output).  The kernel issues
-// the distinct loads together before interpreting the steps, instead of one dependent load after another.
-constexpr int EW_NLOADS = 4;      // distinct per-element operands hoisted per chain (ResNet / Light-CNN chains need <= 3)
-struct EwLoads {
-    int nl;
-    const float* lp[EW_NLOADS];
-    int lk[EW_NLOADS];                       // 0: indexed like the forward tensors (a-index), 1: like the gradient
-};
-
 // One element's prefetched operands.  Plain members, no arrays: the interpreter selects a slot with wave-uniform
 // compares, everything stays in registers.
 struct EwPre {
@@ -264,41 +253,6 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
     ew_interpret(e1.ok, e1.idx, e1.aidx, e1.g, e1.od, e1.v0, e1.v1, e1.v2, e1.v3, dst, accumulate, ch, c, eps);
 }
 
-// Assign prefetch slots.  A load may be hoisted only if nothing in the chain (or the final store) writes the buffer it
-// reads: stores land at the same element index in the same thread, after the prefetch.
-static void plan_loads(EwChain& ch, const float* src, const float* dst, EwLoads& ld)
-{
-    memset(&ld, 0, sizeof(ld));
-    auto written = [&](const float* p) {
-        if (p == dst) return true;
-        for (int i = 0; i < ch.n; ++i)
-            if (ch.s[i].pstore == p) return true;
-        return false;
-    };
-    auto slot_for = [&](const float* p, int kind) -> int {
-        if (!p || written(p)) return -1;
-        for (int l = 0; l < ld.nl; ++l)
-            if (ld.lp[l] == p && ld.lk[l] == kind) return l;
-        if (ld.nl == EW_NLOADS) return -1;
-        ld.lp[ld.nl] = p;
-        ld.lk[ld.nl] = kind;
-        return ld.nl++;
-    };
-    for (int i = 0; i < ch.n; ++i) {
-        EwStep& st = ch.s[i];
-        st.ls0 = -1;
-        st.ls1 = -1;
-        if (st.type == EW_HOOK) {
-            if (!st.pstore && !st.trace && st.action != HOOK_DIV) { st.ls0 = -2; continue; }
-            st.ls0 = slot_for(st.p0, 0);
-            if (st.action == HOOK_DIV && st.p1) st.ls1 = slot_for(st.p1, 0);
-        } else if (st.type == EW_MASK) {
-            st.ls0 = slot_for(st.p0, 0);
-        } else if (st.type == EW_ADDP) {
-            st.ls0 = slot_for(st.p0, 1);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void nchw_to_cnhw_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -712,7 +666,7 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
     if (!trace && !special && (HW % 4) == 0 && C <= 65535) {
         EwLoads ld;
         EwChain planned = chain;
-        plan_loads(planned, src, dst, ld);
+        ew_plan_loads(planned, dst, ld);
         const long per_c4 = (long)SB * (HW / 4);
         hipLaunchKernelGGL(ew_chain_kernel_v4, dim3((unsigned)((per_c4 + NT * EW_U - 1) / (NT * EW_U)), C), dim3(NT), 0, s,
                            reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB,

@@ -159,8 +159,6 @@ struct xfr_engine {
     // Measured on MI355X (bench.py, B=32): folding BatchNorm/ReLU(/residual) into the forward GEMM epilogue is 2-4 % SLOWER
     // than separate streaming kernels -- the HBM-bound elementwise kernels of one stream overlap the MFMA-bound GEMMs of
     // the other for free, while extra epilogue stores stretch every workgroup of a lock-step grid.  Kept for experiments.
-    bool fuse_fwd = false;             // XFR_FWD_FUSE=1 enables it
-    bool fuse_fwd_add = true;          // XFR_NO_FWD_ADD=1 keeps the residual add as its own kernel
     float* splitk_buf[3] = {nullptr, nullptr, nullptr};   // split-K partial-sum slabs: caller stream, internal stream a, b
     size_t splitk_bytes = 0;
     // tail-balancing scratch (conv_gemm.hip), one per stream that launches GEMMs; kernels on one stream serialise,
@@ -557,64 +555,6 @@ void conv_geometry(xfr_engine* e, int k, int NB, ConvParams& p)
     p.tap_major = o.tap_fwd ? 1 : 0;
 }
 
-// Forward epilogue fusion: Conv -> BatchNorm [-> (Add | functional add) with an already computed operand] [-> in-place
-// ReLU] collapses into the GEMM's epilogue (per-channel affine, optional residual read, clamp), so the raw convolution
-// output is written at most once (only when the backward sweep needs A = relu(conv out)) and never re-read.
-void fuse_forward_epilogue(xfr_engine* e, int k, int B, bool want_pos, ConvParams& p)
-{
-    const xfr_op_desc& d = e->ops[k].d;
-    const Tensor& c = e->tens[d.out];
-    if (c.consumers.size() != 1) return;
-    const int k1 = c.consumers[0];
-    if (k1 > e->fwd_last_op) return;
-    const OpRec& bn = e->ops[k1];
-    if (bn.d.kind != XFR_OP_BATCHNORM) return;
-    const int bn_out = bn.d.out;
-    EwChain& ch = p.chain;
-    ch.n = 0;
-    auto push = [&](int type) -> EwStep& { EwStep& q = ch.s[ch.n++]; memset(&q, 0, sizeof(q)); q.type = type; return q; };
-    const bool need_raw = want_pos;          // the BatchNorm hook needs a = relu(conv out); forward-only runs do not
-    if (need_raw) push(EW_STORE).pstore = e->T(d.out);
-    bool pos_bn = false;
-    if (want_pos && e->tens[bn_out].need_pv) {   // positive-pass BatchNorm output relu(gamma)-affine of relu(conv out)
-        EwStep& q = push(EW_FORK_POSBN);
-        q.pstore = e->Pv(bn_out);
-        q.p0 = e->arena + bn.bn_alpha_p;
-        q.p1 = e->arena + (e->with_bias ? bn.bn_beta_pb : bn.bn_beta_p);
-        pos_bn = true;
-    }
-    {
-        EwStep& q = push(EW_AFFINE_C);
-        q.p0 = e->arena + bn.bn_alpha_t;
-        q.p1 = e->arena + bn.bn_beta_t;
-    }
-    int final_t = bn_out;
-    bool fused_add = false;
-    int k2 = -1;
-    if (e->fuse_fwd_add && !bn.fuse_relu && e->tens[bn_out].consumers.size() == 1) {
-        k2 = e->tens[bn_out].consumers[0];
-        const OpRec& ad = e->ops[k2];
-        if (k2 <= e->fwd_last_op && (ad.d.kind == XFR_OP_ADD || ad.d.kind == XFR_OP_G_ADD)) {
-            const int other = (ad.d.in0 == bn_out) ? ad.d.in1 : ad.d.in0;
-            const int prod = e->tens[other].producer;
-            if (other != bn_out && prod < k) {          // the other operand is already computed
-                if (want_pos && e->tens[ad.d.out].need_pv) push(EW_STORE).pstore = e->T(bn_out);   // Add+ needs relu(bn out)
-                push(EW_ADDP).p0 = e->T(other);
-                if (ad.fuse_relu) push(EW_RELU);
-                final_t = ad.d.out;
-                fused_add = true;
-            }
-        }
-    }
-    if (!fused_add && bn.fuse_relu) push(EW_RELU);
-    p.out0 = e->T(final_t);
-    p.chain_B = B;
-    p.chain_eps = e->eps;
-    e->fwd_done[k1] = 1;
-    if (pos_bn) e->pos_done[k1] = 1;
-    if (fused_add) e->fwd_done[k2] = 1;
-}
-
 // forward of op k on true values (and, for "dual" convolutions, the positive output in the same launch)
 xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
 {
@@ -643,7 +583,6 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
                 p.out1 = e->Pv(d.out);
                 p.nhalves = 2;
             } else p.nhalves = 1;
-            if (!e->no_fuse && e->fuse_fwd) fuse_forward_epilogue(e, k, B, want_pos, p);
             return run_conv(e, p, s);
         }
         case XFR_OP_BATCHNORM:
@@ -1344,8 +1283,6 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     e->no_fuse = getenv("XFR_NO_FUSE") != nullptr;
     e->fuse_gemm_epilogue = getenv("XFR_FUSE_GEMM") != nullptr;
     e->use_splitk = getenv("XFR_SPLITK") != nullptr;
-    e->fuse_fwd = getenv("XFR_FWD_FUSE") != nullptr;
-    e->fuse_fwd_add = getenv("XFR_NO_FWD_ADD") == nullptr;
     e->device = device; e->max_batch = max_batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
     xfr_status st = build(e, ops, n_ops);
     if (st == XFR_OK) st = layout_arena(e);
