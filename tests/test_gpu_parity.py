@@ -312,6 +312,53 @@ def test_resnet101_batch32_properties(gpu_device):
     assert bool(torch.isfinite(sal_t).all()) and float((sal_t.sum(dim=(1, 2)) - 1.0).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize('arch,mode,B,pct', [('resnet50_128', 'norelu', 64, 20),           # BASELINE.json configs[2]
+                                             ('lightcnn29v2', 'affineonly', 128, None)])     # BASELINE.json configs[3]
+def test_secondary_configs_full_size_properties(gpu_device, arch, mode, B, pct):
+    """The other two single-GPU configurations at their full batch: finite, non-negative, unit-sum maps, bit-identical
+    between runs; a sample computed alone equals its row of the batch (batch-invariant arithmetic: 1e-5; default: the
+    map tolerance); the first two samples also agree with the per-sample CPU oracle."""
+    from oracle import ebp_oracle as O
+    bb, sd = make_backbone(arch, seed=5, num_classes=None if arch == 'resnet50_128' else 80013)
+    x = make_images(arch, B, seed=4321, smooth=False).to(gpu_device)
+    subj = GC.engine_subject(arch, bb, mode)
+    wb = subj.wb
+    if arch == 'resnet50_128':
+        D = emb_dim(arch)
+        xm = (synth.unit_rows(B, D, seed=7) / 2500).to(gpu_device)
+        xn = (synth.unit_rows(B, D, seed=8) / 2500).to(gpu_device)
+        subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
+        run = lambda lo, hi: wb.contrastive_triplet_ebp_batch(x[lo:hi], xm[lo:hi], xn[lo:hi], percentile=pct)   # noqa: E731
+        tol_on = MAP_RTOL_CONTRAST
+    else:
+        onehot = torch.zeros((1, 80013)); onehot[0, 0] = 1.0
+        def run(lo, hi):                                   # Whitebox.ebp takes N x C seeds (whitebox.py:482-504)
+            out = np.asarray(wb.ebp(x[lo:hi], onehot.expand(hi - lo, -1)))
+            return torch.as_tensor(out.reshape((hi - lo,) + out.shape[-2:]))
+        tol_on = 1e-3
+    eng = wb._engine(B)
+    for balanced, tol in ((False, 1e-5), (True, tol_on)):
+        eng.set_tail_balance(balanced)
+        sal = run(0, B)
+        sal = sal if torch.is_tensor(sal) else torch.as_tensor(sal)
+        assert sal.shape[0] == B and bool(torch.isfinite(sal).all()) and float(sal.min()) >= 0.0
+        assert float((sal.sum(dim=(1, 2)) - 1.0).abs().max()) < 1e-4
+        assert torch.equal(run(0, B).cpu(), sal.cpu())
+        for i in (0, B // 2 + 1, B - 1):
+            alone = run(i, i + 1)
+            rel, cos = map_metrics(alone[0].cpu().numpy(), sal[i].cpu().numpy())
+            assert rel <= tol and cos >= 0.99999, (balanced, i, rel, cos)
+    for i in range(2):
+        ow = O.OracleWhitebox(arch, sd, ('hooked', None), mode)
+        if arch == 'resnet50_128':
+            ow.set_triplet_classifier(xm[i:i + 1].cpu(), xn[i:i + 1].cpu())
+            want = ow.truncated_contrastive_ebp(x[i:i + 1].cpu(), 0, 1, percentile=pct)
+            assert_map_close_robust(sal[i].cpu().numpy(), want, '%s sample %d' % (arch, i), rtol=MAP_RTOL_CONTRAST)
+        else:
+            want = ow.ebp(x[i:i + 1].cpu(), onehot)
+            assert_map_close_robust(sal[i].cpu().numpy(), want, '%s sample %d' % (arch, i))
+
+
 def test_triplet_step_equals_two_call_path(gpu_device):
     """xfr_triplet_contrastive (fused + two-stream) == encode(), encode(), contrastive() done call by call."""
     bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=5)
