@@ -95,7 +95,7 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
         st.ls0 = -1;
         st.ls1 = -1;
         if (st.type == EW_HOOK) {
-            if (!st.pstore && !st.trace && st.action != HOOK_DIV) { st.ls0 = -2; continue; }
+            if (!st.pstore && !st.trace && st.action != HOOK_DIV && st.prior_sb < 0 && !st.cap_dst) { st.ls0 = -2; continue; }
             st.ls0 = slot_for(st.p0, 0);
             if (st.action == HOOK_DIV && st.p1) st.ls1 = slot_for(st.p1, 0);
         } else if (st.type == EW_MASK) {
@@ -188,8 +188,12 @@ void launch_seed_to_cnhw(const float* seed, float* g, int SB, int C, int HW, hip
 void launch_fill(float* p, long n, float v, hipStream_t s);
 // per sample n: v = (gate_ge0 ? gm >= 0 : gm < 0) * (-gn) over the C*HW elements of gm = G[:, n], gn = G[:, N+n] (two gradient streams);
 // vmax[n] = max v, vidx[n] = smallest c*HW+hw attaining it   (whitebox.py:689-690)
-void launch_subtree_stats(const float* G, float* vmax, int* vidx, void* scratch, int C, int N, int HW, int gate_ge0, hipStream_t s);
-size_t subtree_stats_scratch_bytes(int N);
+// weighted-subtree layer weights for all hooked tensors of a sweep in two launches: tensor u = desc[u] ([C][2N][HW]
+// gradients, mate stream then non-mate stream); firing f reads tensor f2u[f]; vmax / vidx are [n_firings][N]
+struct StatDesc { const float* G; int C; int HW; };
+void launch_subtree_stats(const StatDesc* desc_dev, int n_tensors, const int* f2u_dev, int n_firings, float* vmax, int* vidx,
+                          void* scratch, int N, int gate_ge0, hipStream_t s);
+size_t subtree_stats_scratch_bytes(int N, int n_tensors);
 
 // ---- saliency post-processing --------------------------------------------------------------------------------
 // pooled[sb][hw] = sum_c P[c][sb][hw]

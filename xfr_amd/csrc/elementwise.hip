@@ -121,6 +121,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
 struct EwPre {
     float4 g, od, v0, v1, v2, v3;
     long idx, aidx;
+    int sb, el0;       // sample-stream of the element; c*HW + hw of its first component (layerwise priors)
     bool ok;
 };
 
@@ -145,10 +146,16 @@ __device__ __forceinline__ float4 ew_ld(const EwLoads& ld, int l, long idx, long
 }
 
 __device__ __forceinline__ void ew_issue(EwPre& e, const float4* __restrict__ src, const float4* __restrict__ dst, int accumulate,
-                                         const EwLoads& ld, int c, unsigned r, unsigned per_c, unsigned per_ca)
+                                         const EwLoads& ld, int c, unsigned r, unsigned per_c, unsigned per_ca, unsigned HW4)
 {
     e.ok = r < per_c;
     const unsigned rr = e.ok ? r : 0u;
+    e.sb = 0;
+    e.el0 = 0;
+    if (HW4 != 0u) {      // only the PRIOR instantiation passes HW4
+        e.sb = (int)(rr / HW4);
+        e.el0 = (int)(((unsigned)c * HW4 + (rr - (unsigned)e.sb * HW4)) * 4u);
+    }
     e.idx = (long)c * per_c + rr;
     e.aidx = (long)c * per_ca + (rr % per_ca);             // sample b = sb % B, same (hw) position
     e.g = src[e.idx];
@@ -161,7 +168,8 @@ __device__ __forceinline__ void ew_issue(EwPre& e, const float4* __restrict__ sr
     if (accumulate) e.od = dst[e.idx];
 }
 
-__device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, float4 gv, float4 od, float4 v0, float4 v1,
+template <bool PRIOR>
+__device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int sb, int el0, float4 gv, float4 od, float4 v0, float4 v1,
                                              float4 v2, float4 v3, float4* __restrict__ dst,
                                              int accumulate, const EwChain& ch, int c, float eps)
 {
@@ -184,6 +192,34 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, float
             float p[4], zh[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { zh[q] = fmaxf(g[q], 0.f); p[q] = a[q] * zh[q]; }
+            if (PRIOR && st.prior_sb >= 0 && sb == st.prior_sb) {
+                // layerwise EBP: p of this sample is overridden by the prior (whitebox.py:390-392)
+                float pr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pr[q] = st.prior_dense ? st.prior_dense[el0 + q] : ((el0 + q) == st.prior_elem ? st.prior_val : 0.f);
+                if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+                if (st.prior_action == PRIOR_DIV) {
+                    float x[4] = {a[0], a[1], a[2], a[3]};
+                    if (st.p1) {
+                        const float4 xv = s1 >= 0 ? pick_slot(v0, v1, v2, v3, s1) : reinterpret_cast<const float4*>(st.p1)[aidx];
+                        x[0] = fmaxf(xv.x, 0.f); x[1] = fmaxf(xv.y, 0.f); x[2] = fmaxf(xv.z, 0.f); x[3] = fmaxf(xv.w, 0.f);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = __fdiv_rn(pr[q], x[q] + eps);
+                } else if (st.prior_action == PRIOR_GATEZ) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = pr[q] > 0.f ? g[q] : 0.f;
+                }
+                if (st.cap_dst) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (idx * 4 + q == st.cap_idx) *st.cap_dst = pr[q];
+                }
+                continue;
+            }
+            if (PRIOR && st.cap_dst) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (idx * 4 + q == st.cap_idx) *st.cap_dst = p[q];
+            }
             if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(p[0], p[1], p[2], p[3]);
             if (st.action == HOOK_DIV) {
                 float x[4];
@@ -238,6 +274,7 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, float
 // float4 kernel: HW % 4 == 0, no trace.  blockIdx.y = channel; a thread owns EW_U float4 elements of the channel row
 // [SB][HW4], one block apart, and has all of their operand loads in flight before it interprets the steps.
 constexpr int EW_U = 2;
+template <bool PRIOR>      // PRIOR: the chain carries layerwise-EBP priors or captures (EwStep.prior_*, cap_*)
 __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restrict__ src, float4* __restrict__ dst,
                                                         int accumulate, const EwChain ch, const EwLoads ld, int C, int SB,
                                                         int B, int HW4, float eps)
@@ -247,10 +284,10 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
     const unsigned per_ca = (unsigned)B * (unsigned)HW4;
     const unsigned r0 = blockIdx.x * (unsigned)(NT * EW_U) + threadIdx.x;
     EwPre e0, e1;
-    ew_issue(e0, src, dst, accumulate, ld, c, r0, per_c, per_ca);
-    ew_issue(e1, src, dst, accumulate, ld, c, r0 + NT, per_c, per_ca);
-    ew_interpret(e0.ok, e0.idx, e0.aidx, e0.g, e0.od, e0.v0, e0.v1, e0.v2, e0.v3, dst, accumulate, ch, c, eps);
-    ew_interpret(e1.ok, e1.idx, e1.aidx, e1.g, e1.od, e1.v0, e1.v1, e1.v2, e1.v3, dst, accumulate, ch, c, eps);
+    ew_issue(e0, src, dst, accumulate, ld, c, r0, per_c, per_ca, PRIOR ? (unsigned)HW4 : 0u);
+    ew_issue(e1, src, dst, accumulate, ld, c, r0 + NT, per_c, per_ca, PRIOR ? (unsigned)HW4 : 0u);
+    ew_interpret<PRIOR>(e0.ok, e0.idx, e0.aidx, e0.sb, e0.el0, e0.g, e0.od, e0.v0, e0.v1, e0.v2, e0.v3, dst, accumulate, ch, c, eps);
+    ew_interpret<PRIOR>(e1.ok, e1.idx, e1.aidx, e1.sb, e1.el0, e1.g, e1.od, e1.v0, e1.v1, e1.v2, e1.v3, dst, accumulate, ch, c, eps);
 }
 
 
@@ -592,10 +629,12 @@ __global__ __launch_bounds__(NT) void seed_to_cnhw_kernel(const float* __restric
 // weighted-subtree layer weights (whitebox.py:689-690): max / first argmax of (gm >= 0) * (-gn) per sample
 struct StatPartial { float v; int i; };
 
-__global__ __launch_bounds__(NT) void subtree_stats_kernel(const float* __restrict__ G, StatPartial* __restrict__ part, int C,
-                                                          int N, int HW, int chunks, int gate_ge0)
+__global__ __launch_bounds__(NT) void subtree_stats_kernel(const StatDesc* __restrict__ desc, StatPartial* __restrict__ part,
+                                                          int N, int chunks, int gate_ge0)
 {
-    const int n = blockIdx.y;
+    const int n = blockIdx.y, u = blockIdx.z;
+    const float* __restrict__ G = desc[u].G;
+    const int C = desc[u].C, HW = desc[u].HW;
     const long total = (long)C * HW;
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -620,45 +659,55 @@ __global__ __launch_bounds__(NT) void subtree_stats_kernel(const float* __restri
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { part[(long)n * chunks + blockIdx.x].v = sv[0]; part[(long)n * chunks + blockIdx.x].i = si[0]; }
+    if (threadIdx.x == 0) {
+        StatPartial& q = part[((long)u * N + n) * chunks + blockIdx.x];
+        q.v = sv[0];
+        q.i = si[0];
+    }
 }
 
-__global__ void subtree_stats_final_kernel(const StatPartial* __restrict__ part, float* __restrict__ vmax, int* __restrict__ vidx,
-                                           int chunks)
+// one thread per (firing, sample): several hooks on one tensor see the same gradient
+__global__ void subtree_stats_final_kernel(const StatPartial* __restrict__ part, const int* __restrict__ f2u, float* __restrict__ vmax,
+                                           int* __restrict__ vidx, int chunks, int N, int n_firings)
 {
-    const int n = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_firings * N) return;
+    const int f = t / N, n = t - f * N;
+    const int u = f2u[f];
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int k = 0; k < chunks; ++k) {
-        const StatPartial q = part[(long)n * chunks + k];
+        const StatPartial q = part[((long)u * N + n) * chunks + k];
         if (q.v > best || (q.v == best && q.i < bi)) { best = q.v; bi = q.i; }
     }
-    vmax[n] = best;
-    vidx[n] = bi;
+    vmax[t] = best;
+    vidx[t] = bi;
 }
 
-constexpr int STAT_CHUNKS = 64;
+constexpr int STAT_CHUNKS = 16;
 
 }  // namespace
 
-size_t subtree_stats_scratch_bytes(int N) { return sizeof(StatPartial) * (size_t)N * STAT_CHUNKS; }
+size_t subtree_stats_scratch_bytes(int N, int n_tensors) { return sizeof(StatPartial) * (size_t)N * STAT_CHUNKS * (size_t)n_tensors; }
 
-void launch_subtree_stats(const float* G, float* vmax, int* vidx, void* scratch, int C, int N, int HW, int gate_ge0, hipStream_t s)
+void launch_subtree_stats(const StatDesc* desc_dev, int n_tensors, const int* f2u_dev, int n_firings, float* vmax, int* vidx,
+                          void* scratch, int N, int gate_ge0, hipStream_t s)
 {
     StatPartial* part = reinterpret_cast<StatPartial*>(scratch);
-    hipLaunchKernelGGL(subtree_stats_kernel, dim3(STAT_CHUNKS, N), dim3(NT), 0, s, G, part, C, N, HW, STAT_CHUNKS, gate_ge0);
-    hipLaunchKernelGGL(subtree_stats_final_kernel, dim3(N), dim3(64), 0, s, part, vmax, vidx, STAT_CHUNKS);
+    hipLaunchKernelGGL(subtree_stats_kernel, dim3(STAT_CHUNKS, N, n_tensors), dim3(NT), 0, s, desc_dev, part, N, STAT_CHUNKS, gate_ge0);
+    const int total = n_firings * N;
+    hipLaunchKernelGGL(subtree_stats_final_kernel, dim3((total + 63) / 64), dim3(64), 0, s, part, f2u_dev, vmax, vidx, STAT_CHUNKS, N,
+                       n_firings);
 }
 
 void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain& chain, int C, int SB, int B, int HW,
                      float eps, hipStream_t s)
 {
-    bool trace = false, special = false;
+    bool trace = false, special = false, prior = false;
     for (int i = 0; i < chain.n; ++i) {
         if (chain.s[i].type != EW_HOOK) continue;
         if (chain.s[i].trace) trace = true;
-        if (chain.s[i].prior_sb >= 0 || chain.s[i].cap_dst) special = true;
+        if (chain.s[i].prior_sb >= 0 || chain.s[i].cap_dst) prior = true;
     }
     const long total = (long)C * SB * HW;
     for (int i = 0; i < chain.n; ++i)
@@ -668,9 +717,13 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
         EwChain planned = chain;
         ew_plan_loads(planned, dst, ld);
         const long per_c4 = (long)SB * (HW / 4);
-        hipLaunchKernelGGL(ew_chain_kernel_v4, dim3((unsigned)((per_c4 + NT * EW_U - 1) / (NT * EW_U)), C), dim3(NT), 0, s,
-                           reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB,
-                           B, HW / 4, eps);
+        const dim3 grid((unsigned)((per_c4 + NT * EW_U - 1) / (NT * EW_U)), C);
+        if (prior)
+            hipLaunchKernelGGL(ew_chain_kernel_v4<true>, grid, dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
+                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps);
+        else
+            hipLaunchKernelGGL(ew_chain_kernel_v4<false>, grid, dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
+                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps);
     } else if (trace) {
         hipLaunchKernelGGL(ew_chain_kernel<true>, dim3(grid_for(total)), dim3(NT), 0, s, src, dst, accumulate, chain, C, SB,
                            B, HW, eps);

@@ -150,6 +150,10 @@ struct xfr_engine {
     float* stat_v = nullptr;                          // [n_firings][max_batch]
     int* stat_i = nullptr;
     void* stat_scratch = nullptr;
+    StatDesc* stat_desc = nullptr;                    // [n_firings] tensor descriptors + firing -> tensor map of the last plan used
+    int* stat_f2u = nullptr;
+    const void* stat_plan = nullptr;
+    int stat_nu = 0;
     int store_slot = -1;                              // firing whose full P tensor is kept in store_dev
     float* store_dev = nullptr;
     int store_tensor = -1, store_sb = 0;
@@ -398,6 +402,7 @@ void compute_need(xfr_engine* e)
             }
     e->need_dirty = false;
     e->plans.clear();
+    e->stat_plan = nullptr;       // the cached descriptor table belonged to one of those plans
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1083,7 +1088,8 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
         e->last_trace_kinds = plan.firing_kinds;
     }
     const bool special = !e->rc_prior_sb.empty() || !e->rc_cap_idx.empty() || e->store_slot >= 0;
-    const bool use_fused = !e->trace_on && !e->no_fuse && !plan.fused.empty() && !plan.plain && !special;
+    static const bool fuse_special = getenv("XFR_NO_FUSE_SPECIAL") == nullptr;
+    const bool use_fused = !e->trace_on && !e->no_fuse && !plan.fused.empty() && !plan.plain && (!special || fuse_special);
     for (const BwdStep& st : (use_fused ? plan.fused : plan.steps)) {
         switch (st.kind) {
             case ST_EW: {
@@ -1309,6 +1315,8 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->stat_v) (void)hipFree(e->stat_v);
     if (e->stat_i) (void)hipFree(e->stat_i);
     if (e->stat_scratch) (void)hipFree(e->stat_scratch);
+    if (e->stat_desc) (void)hipFree(e->stat_desc);
+    if (e->stat_f2u) (void)hipFree(e->stat_f2u);
     if (e->store_dev) (void)hipFree(e->store_dev);
     if (e->idx_ws2) (void)hipFree(e->idx_ws2);
     for (int i = 0; i < 2; ++i) { if (e->seedbuf[i]) (void)hipFree(e->seedbuf[i]); if (e->ev_slot_done[i]) (void)hipEventDestroy(e->ev_slot_done[i]); }
@@ -1653,7 +1661,9 @@ static xfr_status ensure_subtree_scratch(xfr_engine* e)
     HIP_TRY(hipMalloc(&e->cap_dev, nf * sizeof(float)));
     HIP_TRY(hipMalloc(&e->stat_v, nf * e->max_batch * sizeof(float)));
     HIP_TRY(hipMalloc(&e->stat_i, nf * e->max_batch * sizeof(int)));
-    HIP_TRY(hipMalloc(&e->stat_scratch, subtree_stats_scratch_bytes(e->max_batch)));
+    HIP_TRY(hipMalloc(&e->stat_scratch, subtree_stats_scratch_bytes(e->max_batch, (int)nf)));
+    HIP_TRY(hipMalloc(&e->stat_desc, nf * sizeof(StatDesc)));
+    HIP_TRY(hipMalloc(&e->stat_f2u, nf * sizeof(int)));
     HIP_TRY(hipMalloc(&e->store_dev, 2 * (size_t)e->max_batch * max_per_n * sizeof(float)));
     return XFR_OK;
 }
@@ -1690,18 +1700,23 @@ xfr_status xfr_subtree_weights(xfr_engine* e, const float* x_dev, int32_t n, int
     e->rc_prior_sb.clear(); e->rc_cap_idx.clear(); e->store_slot = -1;
     st = run_backward(e, *plan, n, 2, s);
     if (st != XFR_OK) return st;
-    int last_t = -1;
-    for (int f = 0; f < nf; ++f) {
-        const int t = plan->firing_tensor[f];
-        if (t == last_t) {          // several hooks on one tensor see the same gradient
-            HIP_TRY(hipMemcpyAsync(e->stat_v + (size_t)f * n, e->stat_v + (size_t)(f - 1) * n, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-            HIP_TRY(hipMemcpyAsync(e->stat_i + (size_t)f * n, e->stat_i + (size_t)(f - 1) * n, n * sizeof(int), hipMemcpyDeviceToDevice, s));
-        } else {
-            const Tensor& x = e->tens[t];
-            launch_subtree_stats(e->G(t), e->stat_v + (size_t)f * n, e->stat_i + (size_t)f * n, e->stat_scratch, x.C, n, x.HW(), gate_ge0, s);
+    if (e->stat_plan != plan) {       // descriptor table of this plan: one entry per distinct gradient tensor
+        std::vector<StatDesc> desc;
+        std::vector<int> f2u(nf);
+        int last_t = -1;
+        for (int f = 0; f < nf; ++f) {
+            const int t = plan->firing_tensor[f];
+            if (t != last_t) desc.push_back(StatDesc{e->G(t), e->tens[t].C, e->tens[t].HW()});   // several hooks on one tensor see the same gradient
+            f2u[f] = (int)desc.size() - 1;
+            last_t = t;
         }
-        last_t = t;
+        HIP_TRY(hipMemcpyAsync(e->stat_desc, desc.data(), desc.size() * sizeof(StatDesc), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(e->stat_f2u, f2u.data(), f2u.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));     // the host vectors go out of scope
+        e->stat_plan = plan;
+        e->stat_nu = (int)desc.size();
     }
+    launch_subtree_stats(e->stat_desc, e->stat_nu, e->stat_f2u, nf, e->stat_v, e->stat_i, e->stat_scratch, n, gate_ge0, s);
     HIP_TRY(hipMemcpyAsync(w_host, e->stat_v, (size_t)nf * n * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(idx_host, e->stat_i, (size_t)nf * n * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
