@@ -141,6 +141,7 @@ struct ConvParams {
     float chain_eps;    // eps of the hook divide
     EwChain chain;      // epilogue micro-program applied to half 0 before the final store (n == 0: none)
     EwLoads chain_ld;   // its operand prefetch plan (set by launch_conv_gemm)
+    unsigned long long* dbg_ts;   // tuning: per-workgroup timestamps {start, first K-step ready, K loop done, end, XCC/CU id} (nullptr: off)
 };
 
 constexpr int XFR_TAIL_MAX_TILES = 256;

@@ -97,6 +97,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (p.dbg_ts) ts0 = __builtin_readcyclecounter();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         // guarantees every wave is done reading the stage we are about to refill.
         wait_vmcnt<(NST - 2) * L>();
         __builtin_amdgcn_s_barrier();
+        if (p.dbg_ts && kt == kt_lo) ts1 = __builtin_readcyclecounter();
         int st_fill = st + NST - 1;
         if (st_fill >= NST) st_fill -= NST;
         issue(kt + NST - 1, st_fill);
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         st = (st + 1 == NST) ? 0 : st + 1;
     }
     wait_vmcnt<0>();   // drain the tail loads before the LDS is released
+    if (p.dbg_ts) ts2 = __builtin_readcyclecounter();
 
     if (tail_t >= 0) {
         // K-part of a tail tile: park the accumulators, count arrivals; the last part to arrive sums all parts in
@@ -560,6 +564,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
                     osel[gi] = v;
                 }
         }
+    }
+    if (p.dbg_ts && tid == 0) {
+        unsigned long long* d = p.dbg_ts + (size_t)blockIdx.x * 5;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter();
+        d[4] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
     }
 }
 

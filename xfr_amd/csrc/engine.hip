@@ -1898,6 +1898,24 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     launch_conv_gemm(p, 0);
+    if (const char* tsf = getenv("XFR_CONV_TS")) {     // tuning: per-workgroup phase timestamps of one launch -> csv
+        const size_t nblk = 8192;
+        unsigned long long* ts = nullptr;
+        HIP_TRY(hipMalloc(&ts, nblk * 5 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(ts, 0, nblk * 5 * sizeof(unsigned long long)));
+        ConvParams q = p;
+        q.dbg_ts = ts;
+        launch_conv_gemm(q, 0);
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(nblk * 5);
+        HIP_TRY(hipMemcpy(h.data(), ts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(tsf, "a")) {
+            for (size_t i = 0; i < nblk && h[i * 5 + 3]; ++i)
+                fprintf(f, "%d,%d,%zu,%llu,%llu,%llu,%llu,%llu\n", K, p.M, i, h[i * 5], h[i * 5 + 1], h[i * 5 + 2], h[i * 5 + 3], h[i * 5 + 4]);
+            fclose(f);
+        }
+        (void)hipFree(ts);
+    }
     HIP_TRY(hipEventRecord(a, 0));
     for (int r = 0; r < reps; ++r) launch_conv_gemm(p, 0);
     HIP_TRY(hipEventRecord(b, 0));
