@@ -151,8 +151,10 @@ int conv_gemm_pick_cfg(const ConvParams& p);
 
 // g = src[idx]; run chain; dst[idx] = (accumulate ? dst[idx] : 0) + g.   Tensors are [C][SB][HW] for the gradient
 // and [C][B][HW] for the forward-side sources (sample b = sb % B).
+// SBa <= SB: only the first SBa gradient streams of every channel row are processed (layerwise sweeps whose later
+// streams are still identically zero); the float4 kernel honours it, the scalar kernels process all SB.
 void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain& chain,
-                     int C, int SB, int B, int HW, float eps, hipStream_t s);
+                     int C, int SB, int B, int HW, float eps, hipStream_t s, int SBa = -1);
 
 // ---- simple forward / backward kernels -----------------------------------------------------------------------
 void launch_nchw_to_cnhw(const float* in, float* out, int N, int C, int HW, hipStream_t s);

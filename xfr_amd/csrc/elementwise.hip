@@ -146,9 +146,10 @@ __device__ __forceinline__ float4 ew_ld(const EwLoads& ld, int l, long idx, long
 }
 
 __device__ __forceinline__ void ew_issue(EwPre& e, const float4* __restrict__ src, const float4* __restrict__ dst, int accumulate,
-                                         const EwLoads& ld, int c, unsigned r, unsigned per_c, unsigned per_ca, unsigned HW4)
+                                         const EwLoads& ld, int c, unsigned r, unsigned per_c, unsigned per_c_act, unsigned per_ca,
+                                         unsigned HW4)
 {
-    e.ok = r < per_c;
+    e.ok = r < per_c_act;
     const unsigned rr = e.ok ? r : 0u;
     e.sb = 0;
     e.el0 = 0;
@@ -277,15 +278,16 @@ constexpr int EW_U = 2;
 template <bool PRIOR>      // PRIOR: the chain carries layerwise-EBP priors or captures (EwStep.prior_*, cap_*)
 __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restrict__ src, float4* __restrict__ dst,
                                                         int accumulate, const EwChain ch, const EwLoads ld, int C, int SB,
-                                                        int B, int HW4, float eps)
+                                                        int B, int HW4, float eps, int SBa)
 {
     const int c = blockIdx.y;
-    const unsigned per_c = (unsigned)SB * (unsigned)HW4;       // < 2^31 (every tensor is < 2^31 bytes)
+    const unsigned per_c = (unsigned)SB * (unsigned)HW4;       // row stride; < 2^31 (every tensor is < 2^31 bytes)
+    const unsigned per_c_act = (unsigned)SBa * (unsigned)HW4;  // processed prefix of the row
     const unsigned per_ca = (unsigned)B * (unsigned)HW4;
     const unsigned r0 = blockIdx.x * (unsigned)(NT * EW_U) + threadIdx.x;
     EwPre e0, e1;
-    ew_issue(e0, src, dst, accumulate, ld, c, r0, per_c, per_ca, PRIOR ? (unsigned)HW4 : 0u);
-    ew_issue(e1, src, dst, accumulate, ld, c, r0 + NT, per_c, per_ca, PRIOR ? (unsigned)HW4 : 0u);
+    ew_issue(e0, src, dst, accumulate, ld, c, r0, per_c, per_c_act, per_ca, PRIOR ? (unsigned)HW4 : 0u);
+    ew_issue(e1, src, dst, accumulate, ld, c, r0 + NT, per_c, per_c_act, per_ca, PRIOR ? (unsigned)HW4 : 0u);
     ew_interpret<PRIOR>(e0.ok, e0.idx, e0.aidx, e0.sb, e0.el0, e0.g, e0.od, e0.v0, e0.v1, e0.v2, e0.v3, dst, accumulate, ch, c, eps);
     ew_interpret<PRIOR>(e1.ok, e1.idx, e1.aidx, e1.sb, e1.el0, e1.g, e1.od, e1.v0, e1.v1, e1.v2, e1.v3, dst, accumulate, ch, c, eps);
 }
@@ -701,8 +703,9 @@ void launch_subtree_stats(const StatDesc* desc_dev, int n_tensors, const int* f2
 }
 
 void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain& chain, int C, int SB, int B, int HW,
-                     float eps, hipStream_t s)
+                     float eps, hipStream_t s, int SBa)
 {
+    if (SBa < 0 || SBa > SB) SBa = SB;
     bool trace = false, special = false, prior = false;
     for (int i = 0; i < chain.n; ++i) {
         if (chain.s[i].type != EW_HOOK) continue;
@@ -716,14 +719,14 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
         EwLoads ld;
         EwChain planned = chain;
         ew_plan_loads(planned, dst, ld);
-        const long per_c4 = (long)SB * (HW / 4);
+        const long per_c4 = (long)SBa * (HW / 4);
         const dim3 grid((unsigned)((per_c4 + NT * EW_U - 1) / (NT * EW_U)), C);
         if (prior)
             hipLaunchKernelGGL(ew_chain_kernel_v4<true>, grid, dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
-                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps);
+                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps, SBa);
         else
             hipLaunchKernelGGL(ew_chain_kernel_v4<false>, grid, dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
-                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps);
+                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps, SBa);
     } else if (trace) {
         hipLaunchKernelGGL(ew_chain_kernel<true>, dim3(grid_for(total)), dim3(NT), 0, s, src, dst, accumulate, chain, C, SB,
                            B, HW, eps);

@@ -142,6 +142,8 @@ struct xfr_engine {
     // trace / profile
     int trace_on = 0;
     // per-call context of the backward sweep ("next" rows: layerwise / weighted-subtree EBP)
+    std::vector<int> rc_active;                       // layerwise sweeps in ascending firing order: stream j is identically zero before firing rc_active[j]
+    size_t g_begin = 0, g_end = 0;                    // the gradient region of the workspace (floats)
     std::vector<int> rc_prior_sb, rc_prior_elem;      // per firing slot: sample with a prior (-1 none), its element
     std::vector<float> rc_prior_val;
     const float* rc_prior_dense = nullptr;            // dense prior tensor (single sweep) instead of (elem, val)
@@ -434,7 +436,9 @@ xfr_status allocate(xfr_engine* e)
     e->misc_off = take(std::max<size_t>(misc, 64));
     take(4096);
     e->fwd_region_floats = off;
+    e->g_begin = off;
     for (size_t t = 1; t < e->tens.size(); ++t) e->tens[t].g_off = take(2 * B * e->tens[t].per_n());
+    e->g_end = off;
     size_t max_per_n = 0;
     for (auto& x : e->tens) max_per_n = std::max(max_per_n, (size_t)x.per_n());
     e->seed_off = take(2 * B * max_per_n);
@@ -1090,13 +1094,25 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
     const bool special = !e->rc_prior_sb.empty() || !e->rc_cap_idx.empty() || e->store_slot >= 0;
     static const bool fuse_special = getenv("XFR_NO_FUSE_SPECIAL") == nullptr;
     const bool use_fused = !e->trace_on && !e->no_fuse && !plan.fused.empty() && !plan.plain && (!special || fuse_special);
+    // Layerwise sweeps sorted by firing (rc_active): stream j is identically zero until the step that holds its prior
+    // hook, so the GEMMs and hook chains before that step leave it out (the gradient region was zero-filled; the small
+    // pool / copy kernels still run over all streams and move zeros).  SBa = streams alive at this step.
+    const bool prefix = !e->rc_active.empty() && (int)e->rc_active.size() == SB;
+    int run_max = -1;
     for (const BwdStep& st : (use_fused ? plan.fused : plan.steps)) {
+        int SBa = SB;
+        if (prefix) {
+            for (const auto& sy : st.chain)
+                if (sy.type == EW_HOOK && sy.slot > run_max) run_max = sy.slot;
+            SBa = (int)(std::upper_bound(e->rc_active.begin(), e->rc_active.end(), run_max) - e->rc_active.begin());
+            if (SBa == 0) continue;
+        }
         switch (st.kind) {
             case ST_EW: {
                 EwChain ch;
                 resolve_chain(e, st.chain, ch, trace, SB, plan.plain);
                 const Tensor& x = e->tens[st.ew_t];
-                launch_ew_chain(e->G(st.src_t), e->G(st.dst_t), st.accumulate, ch, x.C, SB, B, x.HW(), e->eps, s);
+                launch_ew_chain(e->G(st.src_t), e->G(st.dst_t), st.accumulate, ch, x.C, SB, B, x.HW(), e->eps, s, SBa);
                 break;
             }
             case ST_ZERO:
@@ -1112,7 +1128,7 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                 p.in = e->G(st.src_t);
                 p.w = e->arena + (plan.plain ? o.w_bwd_true : o.w_bwd);
                 p.out0 = e->G(st.dst_t);
-                p.Cin = t.C; p.H = t.H; p.W = t.W; p.NB = SB; p.in_nb = SB; p.out_nb = SB;
+                p.Cin = t.C; p.H = t.H; p.W = t.W; p.NB = SBa; p.in_nb = SB; p.out_nb = SB;
                 p.tap_major = (d.stride == 1 && o.tap_bwd) ? 1 : 0;
                 p.in_bytes = (unsigned)((size_t)SB * t.per_n() * sizeof(float));
                 p.CoutTot = a.C; p.nhalves = 1; p.ldw = o.ldb;
@@ -1131,7 +1147,7 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                     p.out_H = a.H; p.out_W = a.W; p.out_stride = d.stride;
                     p.accumulate = 1;   // the target was zero-filled or already holds other contributions
                 }
-                p.M = SB * p.OH * p.OW;
+                p.M = SBa * p.OH * p.OW;
                 if (!st.chain.empty()) {
                     resolve_chain(e, st.chain, p.chain, nullptr, SB);
                     p.chain_B = B;
@@ -1778,14 +1794,22 @@ xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n_sweeps
         e->rc_prior_sb[f] = j;
         if (!dense_prior_dev) { e->rc_prior_elem[f] = elem_host[j]; e->rc_prior_val[f] = val_host[j]; }
     }
+    // sweeps given in ascending firing order: each one joins the backward pass at its own firing (run_backward)
+    e->rc_active.clear();
+    bool ascending = n_sweeps > 1;
+    for (int j = 1; j < n_sweeps; ++j) ascending = ascending && firing_host[j] > firing_host[j - 1];
+    static const bool no_prefix = getenv("XFR_NO_SWEEP_PREFIX") != nullptr;
+    if (ascending && !no_prefix && !e->trace_on) e->rc_active.assign(firing_host, firing_host + n_sweeps);
     // one forward for all sweeps (whitebox.py:581 runs ebp(img, 0*P0) again for every layer); zero seeds: all the
     // gradient enters through the priors
     st = forward_all(e, x_dev, 1, seed_tensor, true, s);
     if (st == XFR_OK) {
         const Tensor& sd = e->tens[seed_tensor];
+        if (!e->rc_active.empty()) HIP_TRY(hipMemsetAsync(e->ws + e->g_begin, 0, (e->g_end - e->g_begin) * sizeof(float), s));
         launch_fill(e->G(seed_tensor), (long)sd.per_n() * n_sweeps, 0.f, s);
         st = run_backward(e, *plan, 1, n_sweeps, s);
     }
+    e->rc_active.clear();
     e->rc_prior_sb.clear();
     e->rc_prior_dense = nullptr;
     if (st != XFR_OK) return st;

@@ -215,9 +215,17 @@ class Engine(object):
         return np.frombuffer(out, dtype=np.float32).copy()
 
     def layerwise(self, x, seed_tensor, firings, elems=None, vals=None, dense_prior=None):
-        """Batch of layerwise sweeps of one image -> J x H1 x W1 pooled P[-2]."""
+        """Batch of layerwise sweeps of one image -> J x H1 x W1 pooled P[-2] (in the order of `firings`).  The sweeps are
+        handed to the engine in ascending firing order: each then joins the backward pass at its own firing."""
         x = self._prep(x)
         J = len(firings)
+        order = sorted(range(J), key=lambda j: int(firings[j]))
+        if order != list(range(J)) and dense_prior is None:
+            out = self.layerwise(x, seed_tensor, [firings[j] for j in order], [elems[j] for j in order] if elems is not None else None,
+                                 [vals[j] for j in order] if vals is not None else None)
+            inv = torch.empty(J, dtype=torch.long)
+            inv[torch.tensor(order)] = torch.arange(J)
+            return out[inv.to(out.device)]
         fi = (ctypes.c_int32 * J)(*[int(v) for v in firings])
         el = (ctypes.c_int32 * J)(*[int(v) for v in elems]) if elems is not None else None
         va = (ctypes.c_float * J)(*[float(v) for v in vals]) if vals is not None else None
