@@ -194,6 +194,14 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
  * Costs one extra copy of the forward workspace.  Synchronises the device. */
 xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
 
+/* Share one forward pass between consecutive calls on the same input (off by default).  While hold = 1, a run call
+ * (xfr_subtree_weights, xfr_ebp_capture, xfr_layerwise_ebp, xfr_ebp, ...) whose x_dev, n, seed tensor and stream equal those
+ * of the previous call skips its forward and sweeps over the activations that are still in the workspace -- the three phases
+ * of weighted_subtree_ebp (whitebox.py:647-737) run the same image through the network four times.  The caller promises
+ * that the content of x_dev did not change in between.  Loading weights, changing the mode, or any forward on other
+ * inputs drops the held state; hold = 0 ends the group. */
+xfr_status xfr_engine_hold_forward(xfr_engine* e, int32_t hold);
+
 /* Tail balancing of the convolution GEMMs (on by default).  A GEMM whose tile count is not a multiple of the CU count
  * has its last tiles cut along K so that every CU gets an equal share of the final round (+7 % GEMM rate on
  * ResNet-101 at 32-64 images).  The cut tiles add their K-parts in a fixed order: results are deterministic for a

@@ -456,3 +456,31 @@ def test_engine_argument_errors(gpu_device):
         wb._engine(1).ebp(x, 2, torch.zeros(3, 1, 1))  # n_streams / seed shape
     with pytest.raises(ValueError):
         wb.net.engine().set_mode('nonsense')
+
+
+def test_hold_forward_shares_and_drops_state(gpu_device):
+    """xfr_engine_hold_forward: calls on the same input skip the forward and give the same bits; a different input, a
+    mode change or hold = 0 never reuses stale activations."""
+    bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=5)
+    subj = GC.engine_subject('stresnet_mini', bb, 'affineonly_with_prior')
+    wb = subj.wb
+    subj.set_cls(synth.unit_rows(1, 512, seed=1) / 2500, synth.unit_rows(1, 512, seed=2) / 2500)
+    x = make_images('stresnet_mini', 2, seed=5, smooth=False).to(gpu_device)
+    a, b = x[0:1].contiguous(), x[1:2].contiguous()
+    ref_a = wb.contrastive_ebp(a, 0, 1).copy()
+    ref_b = wb.contrastive_ebp(b, 0, 1).copy()
+    ref_t = wb.truncated_contrastive_ebp(a, 0, 1, percentile=20).copy()
+    eng = wb._engine(1)
+    eng.hold_forward(True)
+    try:
+        assert np.array_equal(wb.contrastive_ebp(a, 0, 1), ref_a)
+        assert np.array_equal(wb.contrastive_ebp(a, 0, 1), ref_a)              # forward skipped
+        assert np.array_equal(wb.truncated_contrastive_ebp(a, 0, 1, percentile=20), ref_t)
+        assert np.array_equal(wb.contrastive_ebp(b, 0, 1), ref_b)              # other input: new forward
+        assert np.array_equal(wb.contrastive_ebp(a, 0, 1), ref_a)
+        enc = wb.encode(b)                                                      # another call kind in between
+        assert np.array_equal(wb.contrastive_ebp(a, 0, 1), ref_a)
+        assert torch.equal(enc, wb.encode(b))
+    finally:
+        eng.hold_forward(False)
+    assert np.array_equal(wb.contrastive_ebp(b, 0, 1), ref_b)

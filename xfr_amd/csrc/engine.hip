@@ -142,6 +142,11 @@ struct xfr_engine {
     // trace / profile
     int trace_on = 0;
     // per-call context of the backward sweep ("next" rows: layerwise / weighted-subtree EBP)
+    // xfr_engine_hold_forward: the forward state of (held_x, held_B, held_last) is still in slot 0
+    bool hold_forward = false, held_pos = false;
+    const float* held_x = nullptr;
+    int held_B = 0, held_last = -1;
+    hipStream_t held_stream = nullptr;
     std::vector<int> rc_active;                       // layerwise sweeps in ascending firing order: stream j is identically zero before firing rc_active[j]
     size_t g_begin = 0, g_end = 0;                    // the gradient region of the workspace (floats)
     std::vector<int> rc_prior_sb, rc_prior_elem;      // per firing slot: sample with a prior (-1 none), its element
@@ -685,6 +690,13 @@ xfr_status pos_op(xfr_engine* e, int k, int B, hipStream_t s)
 
 xfr_status forward_all(xfr_engine* e, const float* x_dev, int B, int last_tensor, bool with_pos, hipStream_t s)
 {
+    // xfr_engine_hold_forward: consecutive calls on the same input share one forward (slot 0, main bank only)
+    const bool holdable = e->hold_forward && e->cur_slot == 0 && !e->t_bank;
+    if (holdable && e->held_x == x_dev && e->held_B == B && e->held_last == last_tensor && e->held_stream == s &&
+        (e->held_pos || !with_pos))
+        return XFR_OK;
+    if (holdable) with_pos = true;           // later calls of the group may need the positive pass
+    e->held_x = nullptr;
     const Tensor& in = e->tens[0];
     launch_nchw_to_cnhw(x_dev, e->T(0), B, in.C, in.HW(), s);
     const int last_op = e->tens[last_tensor].producer;
@@ -704,6 +716,7 @@ xfr_status forward_all(xfr_engine* e, const float* x_dev, int B, int last_tensor
             }
         }
     }
+    if (holdable) { e->held_x = x_dev; e->held_B = B; e->held_last = last_tensor; e->held_pos = with_pos; e->held_stream = s; }
     return XFR_OK;
 }
 
@@ -1348,6 +1361,7 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
 
 xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int32_t n_weights)
 {
+    if (e) e->held_x = nullptr;
     if (!e || !w) return fail(XFR_INVALID_ARG, "null argument");
     if (n_weights != e->n_weights) return fail(XFR_INVALID_ARG, "expected %d weight views, got %d", e->n_weights, n_weights);
     HIP_TRY(hipSetDevice(e->device));
@@ -1432,6 +1446,7 @@ xfr_status xfr_engine_weight_arena(xfr_engine* e, void** dev_ptr, size_t* bytes)
 
 xfr_status xfr_engine_mark_weights_loaded(xfr_engine* e)
 {
+    if (e) e->held_x = nullptr;
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     e->weights_loaded = true;
     return XFR_OK;
@@ -1442,8 +1457,11 @@ xfr_status xfr_engine_set_mode(xfr_engine* e, int32_t subtree_mode, float eps, i
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     if (subtree_mode < 0 || subtree_mode > 3) return fail(XFR_INVALID_ARG, "Invalid subtree mode %d", subtree_mode);
     if (!(eps >= 0.f)) return fail(XFR_INVALID_ARG, "eps must be >= 0");
-    e->mode = subtree_mode; e->eps = eps; e->with_bias = with_bias ? 1 : 0;
+    const int wb = with_bias ? 1 : 0;
+    if (e->mode == subtree_mode && e->eps == eps && e->with_bias == wb) return XFR_OK;     // nothing to re-plan
+    e->mode = subtree_mode; e->eps = eps; e->with_bias = wb;
     e->need_dirty = true;
+    e->held_x = nullptr;
     return XFR_OK;
 }
 
@@ -1623,6 +1641,14 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     }
     e->cur_slot = 0;
     return prof_end(e, s);
+}
+
+xfr_status xfr_engine_hold_forward(xfr_engine* e, int32_t hold)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->hold_forward = hold != 0;
+    e->held_x = nullptr;
+    return XFR_OK;
 }
 
 xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable)

@@ -170,6 +170,10 @@ class Engine(object):
         """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
         _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call
 
+    def hold_forward(self, on):
+        """Consecutive calls on the same input tensor share one forward pass while held (include/xfr_amd.h)."""
+        _lib.check(self.lib.xfr_engine_hold_forward(self._h, int(bool(on))))
+
     def set_tail_balance(self, on):
         """GEMM tail balancing (default on); off = batch-invariant fp32 arithmetic (include/xfr_amd.h)."""
         _lib.check(self.lib.xfr_engine_set_tail_balance(self._h, int(bool(on))))

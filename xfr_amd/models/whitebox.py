@@ -410,6 +410,16 @@ class Whitebox(object):
             g = torch.softmax(y, dim=1)
             g[0, 0] -= 1.0                                                      # d cross_entropy(y,[0])/dy  (:657,:664)
             _, s0 = self.net.seed_for(g, 1)
+        img_probe = eng._prep(img_probe)                                       # one device tensor for all phases
+        eng.hold_forward(True)                                                  # ... which share its forward pass
+        try:
+            return self._weighted_subtree_held(eng, img_probe, seed_tensor, s0, s1, k_poschannel, topk, verbose, do_max_subtree,
+                                               do_mated_similarity_gating, do_mwp_to_saliency, sweep_batch, C)
+        finally:
+            eng.hold_forward(False)
+
+    def _weighted_subtree_held(self, eng, img_probe, seed_tensor, s0, s1, k_poschannel, topk, verbose, do_max_subtree,
+                               do_mated_similarity_gating, do_mwp_to_saliency, sweep_batch, C):
         w, idx = eng.subtree_weights(img_probe, seed_tensor, torch.stack((s0, s1), dim=0), gate_ge0=do_mated_similarity_gating)
         P_subtree = [float(v) for v in w[:, 0]]
         P_subtree_idx = [int(v) for v in idx[:, 0]]
