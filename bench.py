@@ -119,6 +119,31 @@ def secondary(args, dev, rank, world):
                                        'gemm_ms_per_step': ms}}))
 
 
+def pmc_traffic(root):
+    """HBM bytes per conv_gemm launch from the committed PMC passes of this same command (profiles/rNN/pmc_FETCH_SIZE.txt,
+    pmc_WRITE_SIZE.txt: separate rocprofv3 --pmc runs, KB summed over the dispatches of 3 steps).  FETCH_SIZE is doubled:
+    on gfx950 it reports half the bytes of 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM section); the dword-wide
+    im2col reads of the KxK layers are not calibrated, so this is an upper bound.  Counters cannot be read from inside
+    the timed process, hence the file; {} if no profile has been committed."""
+    import glob
+    import re
+    dirs = sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9]*')))
+    for d in reversed(dirs):
+        try:
+            vals = {}
+            for name in ('FETCH_SIZE', 'WRITE_SIZE'):
+                for ln in open(os.path.join(d, 'pmc_%s.txt' % name)):
+                    m = re.match(r'conv_gemm_kernel\s+dispatches\s+(\d+)\s+.*%s=([0-9.e+]+)' % name, ln)
+                    if m:
+                        vals[name] = (int(m.group(1)), float(m.group(2)))
+            (n, f), (n2, w) = vals['FETCH_SIZE'], vals['WRITE_SIZE']
+            return {'traffic': (2.0 * f * 1024 / n + w * 1024 / n2), 'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)',
+                    'traffic_source': os.path.relpath(d, root) + '/pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE.txt'}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -227,6 +252,8 @@ def main():
                 'kernel': 'conv_gemm_kernel (all shapes of one step)', 'launches_per_step': tot_n // reps,
                 'avg_launch_ms': tot_ms / max(tot_n, 1), 'gemm_ms_per_step': tot_ms / reps,
                 'executed_flop_per_step': tot_fl / reps, 'algorithmic_flop_per_step': alg / reps}
+        if B == 32 and args.mode == 'affineonly_with_prior':
+            roof.update(pmc_traffic(os.path.dirname(os.path.abspath(__file__))))
 
     if rank == 0:
         value = world * B * args.steps / dt
