@@ -81,14 +81,22 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
             if (ch.s[i].pstore == p) return true;
         return false;
     };
+    // slots 0..2 hold operands indexed like the forward tensors (shared by the gradient streams of one position), slot 3
+    // the one gradient-indexed operand (fan-in)
     auto slot_for = [&](const float* p, int kind) -> int {
         if (!p || written(p)) return -1;
-        for (int l = 0; l < ld.nl; ++l)
-            if (ld.lp[l] == p && ld.lk[l] == kind) return l;
-        if (ld.nl == EW_NLOADS) return -1;
-        ld.lp[ld.nl] = p;
-        ld.lk[ld.nl] = kind;
-        return ld.nl++;
+        if (kind == 1) {
+            if (ld.lp[3] == p) return 3;
+            if (ld.lp[3]) return -1;
+            ld.lp[3] = p;
+            ld.lk[3] = 1;
+            return 3;
+        }
+        for (int l = 0; l < 3; ++l) {
+            if (ld.lp[l] == p) return l;
+            if (!ld.lp[l]) { ld.lp[l] = p; ld.lk[l] = 0; return l; }
+        }
+        return -1;
     };
     for (int i = 0; i < ch.n; ++i) {
         EwStep& st = ch.s[i];
@@ -104,6 +112,7 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
             st.ls0 = slot_for(st.p0, 1);
         }
     }
+    ld.nl = ld.lp[3] ? 4 : (ld.lp[2] ? 3 : (ld.lp[1] ? 2 : (ld.lp[0] ? 1 : 0)));   // slots in use form a prefix, except that 3 may follow a gap
 }
 
 // ---- implicit-GEMM convolution -------------------------------------------------------------------------------

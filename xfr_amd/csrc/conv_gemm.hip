@@ -445,10 +445,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
                     }
 #pragma unroll
                     for (int e8 = 0; e8 < 4; ++e8) {
-                        if (ld.nl > 0) pv0[e8] = ld.lp[0][ld.lk[0] ? gi[e8] : ai[e8]];
-                        if (ld.nl > 1) pv1[e8] = ld.lp[1][ld.lk[1] ? gi[e8] : ai[e8]];
-                        if (ld.nl > 2) pv2[e8] = ld.lp[2][ld.lk[2] ? gi[e8] : ai[e8]];
-                        if (ld.nl > 3) pv3[e8] = ld.lp[3][ld.lk[3] ? gi[e8] : ai[e8]];
+                        if (ld.lp[0]) pv0[e8] = ld.lp[0][ld.lk[0] ? gi[e8] : ai[e8]];
+                        if (ld.lp[1]) pv1[e8] = ld.lp[1][ld.lk[1] ? gi[e8] : ai[e8]];
+                        if (ld.lp[2]) pv2[e8] = ld.lp[2][ld.lk[2] ? gi[e8] : ai[e8]];
+                        if (ld.lp[3]) pv3[e8] = ld.lp[3][ld.lk[3] ? gi[e8] : ai[e8]];
                     }
 #pragma unroll
                     for (int e8 = 0; e8 < 4; ++e8) {

@@ -116,15 +116,6 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
     }
 }
 
-// One element's prefetched operands.  Plain members, no arrays: the interpreter selects a slot with wave-uniform
-// compares, everything stays in registers.
-struct EwPre {
-    float4 g, od, v0, v1, v2, v3;
-    long idx, aidx;
-    int sb, el0;       // sample-stream of the element; c*HW + hw of its first component (layerwise priors)
-    bool ok;
-};
-
 __device__ __forceinline__ float pick1(float a0, float a1, float a2, float a3, int slot)
 {
     float r = a0;
@@ -138,35 +129,6 @@ __device__ __forceinline__ float4 pick_slot(float4 v0, float4 v1, float4 v2, flo
 {
     return make_float4(pick1(v0.x, v1.x, v2.x, v3.x, slot), pick1(v0.y, v1.y, v2.y, v3.y, slot),
                        pick1(v0.z, v1.z, v2.z, v3.z, slot), pick1(v0.w, v1.w, v2.w, v3.w, slot));
-}
-
-__device__ __forceinline__ float4 ew_ld(const EwLoads& ld, int l, long idx, long aidx)
-{
-    return reinterpret_cast<const float4*>(ld.lp[l])[ld.lk[l] ? idx : aidx];
-}
-
-__device__ __forceinline__ void ew_issue(EwPre& e, const float4* __restrict__ src, const float4* __restrict__ dst, int accumulate,
-                                         const EwLoads& ld, int c, unsigned r, unsigned per_c, unsigned per_c_act, unsigned per_ca,
-                                         unsigned HW4)
-{
-    e.ok = r < per_c_act;
-    const unsigned rr = e.ok ? r : 0u;
-    e.sb = 0;
-    e.el0 = 0;
-    if (HW4 != 0u) {      // only the PRIOR instantiation passes HW4
-        e.sb = (int)(rr / HW4);
-        e.el0 = (int)(((unsigned)c * HW4 + (rr - (unsigned)e.sb * HW4)) * 4u);
-    }
-    e.idx = (long)c * per_c + rr;
-    e.aidx = (long)c * per_ca + (rr % per_ca);             // sample b = sb % B, same (hw) position
-    e.g = src[e.idx];
-    e.v0 = e.v1 = e.v2 = e.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ld.nl > 0) e.v0 = ew_ld(ld, 0, e.idx, e.aidx);
-    if (ld.nl > 1) e.v1 = ew_ld(ld, 1, e.idx, e.aidx);
-    if (ld.nl > 2) e.v2 = ew_ld(ld, 2, e.idx, e.aidx);
-    if (ld.nl > 3) e.v3 = ew_ld(ld, 3, e.idx, e.aidx);
-    e.od = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (accumulate) e.od = dst[e.idx];
 }
 
 template <bool PRIOR>
@@ -272,26 +234,49 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int s
     dst[idx] = o;
 }
 
-// float4 kernel: HW % 4 == 0, no trace.  blockIdx.y = channel; a thread owns EW_U float4 elements of the channel row
-// [SB][HW4], one block apart, and has all of their operand loads in flight before it interprets the steps.
-constexpr int EW_U = 2;
-template <bool PRIOR>      // PRIOR: the chain carries layerwise-EBP priors or captures (EwStep.prior_*, cap_*)
+// float4 kernel: HW % 4 == 0, no trace.  blockIdx.y = channel, blockIdx.z = group of SG gradient streams; a thread owns one
+// (sample, position) of the channel row and runs the chain for the SG streams at that position: the forward-side operands
+// (a, x, masks: slots 0..2) are loaded once for all of them, the per-stream ones (g, the fan-in slot 3, dst) once each, all
+// in flight before the steps are interpreted.  Contrastive EBP has two streams per sample, the layerwise sweeps up to 64.
+template <bool PRIOR, int SG>     // PRIOR: the chain carries layerwise-EBP priors or captures (EwStep.prior_*, cap_*)
 __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restrict__ src, float4* __restrict__ dst,
                                                         int accumulate, const EwChain ch, const EwLoads ld, int C, int SB,
                                                         int B, int HW4, float eps, int SBa)
 {
     const int c = blockIdx.y;
+    const unsigned per_ca = (unsigned)B * (unsigned)HW4;       // one stream of the channel row
     const unsigned per_c = (unsigned)SB * (unsigned)HW4;       // row stride; < 2^31 (every tensor is < 2^31 bytes)
-    const unsigned per_c_act = (unsigned)SBa * (unsigned)HW4;  // processed prefix of the row
-    const unsigned per_ca = (unsigned)B * (unsigned)HW4;
-    const unsigned r0 = blockIdx.x * (unsigned)(NT * EW_U) + threadIdx.x;
-    EwPre e0, e1;
-    ew_issue(e0, src, dst, accumulate, ld, c, r0, per_c, per_c_act, per_ca, PRIOR ? (unsigned)HW4 : 0u);
-    ew_issue(e1, src, dst, accumulate, ld, c, r0 + NT, per_c, per_c_act, per_ca, PRIOR ? (unsigned)HW4 : 0u);
-    ew_interpret<PRIOR>(e0.ok, e0.idx, e0.aidx, e0.sb, e0.el0, e0.g, e0.od, e0.v0, e0.v1, e0.v2, e0.v3, dst, accumulate, ch, c, eps);
-    ew_interpret<PRIOR>(e1.ok, e1.idx, e1.aidx, e1.sb, e1.el0, e1.g, e1.od, e1.v0, e1.v1, e1.v2, e1.v3, dst, accumulate, ch, c, eps);
+    const unsigned pos = blockIdx.x * (unsigned)NT + threadIdx.x;
+    if (pos >= per_ca) return;
+    const long aidx = (long)c * per_ca + pos;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s0 = z4, s1 = z4, s2 = z4;
+    if (ld.lp[0]) s0 = reinterpret_cast<const float4*>(ld.lp[0])[aidx];
+    if (ld.lp[1]) s1 = reinterpret_cast<const float4*>(ld.lp[1])[aidx];
+    if (ld.lp[2]) s2 = reinterpret_cast<const float4*>(ld.lp[2])[aidx];
+    unsigned b = 0, hw = pos;
+    if (PRIOR || SBa < SB) { b = pos / (unsigned)HW4; hw = pos - b * (unsigned)HW4; }
+    float4 g[SG], od[SG], v3[SG];
+    long idx[SG];
+    int sb[SG];
+    bool ok[SG];
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+        const unsigned st = blockIdx.z * (unsigned)SG + u;                    // stream
+        sb[u] = (int)(st * (unsigned)B + b);
+        ok[u] = st * (unsigned)B < (unsigned)SB && sb[u] < SBa;
+        idx[u] = (long)c * per_c + (ok[u] ? st * per_ca + pos : pos);
+        g[u] = src[idx[u]];
+        v3[u] = z4;
+        if (ld.lp[3]) v3[u] = reinterpret_cast<const float4*>(ld.lp[3])[idx[u]];
+        od[u] = z4;
+        if (accumulate) od[u] = dst[idx[u]];
+    }
+    const int el0 = (int)(((unsigned)c * (unsigned)HW4 + hw) * 4u);
+#pragma unroll
+    for (int u = 0; u < SG; ++u)
+        ew_interpret<PRIOR>(ok[u], idx[u], aidx, sb[u], el0, g[u], od[u], s0, s1, s2, v3[u], dst, accumulate, ch, c, eps);
 }
-
 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void nchw_to_cnhw_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -715,18 +700,19 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
     const long total = (long)C * SB * HW;
     for (int i = 0; i < chain.n; ++i)
         if (accumulate && chain.s[i].pstore == dst) special = true;   // the float4 kernel reads dst before the chain runs
-    if (!trace && !special && (HW % 4) == 0 && C <= 65535) {
+    if (!trace && !special && (HW % 4) == 0 && C <= 65535 && SB % B == 0 && SB / B <= 2 * 65535) {
         EwLoads ld;
         EwChain planned = chain;
         ew_plan_loads(planned, dst, ld);
-        const long per_c4 = (long)SBa * (HW / 4);
-        const dim3 grid((unsigned)((per_c4 + NT * EW_U - 1) / (NT * EW_U)), C);
-        if (prior)
-            hipLaunchKernelGGL(ew_chain_kernel_v4<true>, grid, dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
+        const int S = SB / B, Sa = (SBa + B - 1) / B;                    // streams, streams with live samples
+        const long per_ca4 = (long)B * (HW / 4);
+        const unsigned gx = (unsigned)((per_ca4 + NT - 1) / NT);
+        auto go = [&](auto kern, int sg) {
+            hipLaunchKernelGGL(kern, dim3(gx, C, (unsigned)((Sa + sg - 1) / sg)), dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
                                reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps, SBa);
-        else
-            hipLaunchKernelGGL(ew_chain_kernel_v4<false>, grid, dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
-                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps, SBa);
+        };
+        if (S == 1) { if (prior) go(ew_chain_kernel_v4<true, 1>, 1); else go(ew_chain_kernel_v4<false, 1>, 1); }
+        else { if (prior) go(ew_chain_kernel_v4<true, 2>, 2); else go(ew_chain_kernel_v4<false, 2>, 2); }
     } else if (trace) {
         hipLaunchKernelGGL(ew_chain_kernel<true>, dim3(grid_for(total)), dim3(NT), 0, s, src, dst, accumulate, chain, C, SB,
                            B, HW, eps);
