@@ -27,27 +27,44 @@ FLOPS_PER_TRIPLET = 6 * F_FWD_R101   # 2 encodes + true fwd + relu(W) fwd + 2 ba
 PEAK_F32_MFMA = 157.3e12         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
 
 
-def cpu_baseline(sd, probes, mates, nonmates, mode, budget_s=25.0):
+def cpu_baseline(sd, probes, mates, nonmates, mode, budget_s=20.0):
     """The oracle (kind "port": hook-free CPU restatement of the reference, bit-exact against it in the build
     container) timed on this box's host cores on a bounded sample of the same workload: whole triplets
-    (2 encodes + contrastive EBP) until ~budget_s of CPU time is spent (at least one)."""
+    (2 encodes + contrastive EBP) until ~budget_s of CPU time is spent (at least one).  The reference's path is batch 1
+    (whitebox.py:512); its convolutions stop scaling long before a 128-core host is used up (measured on the GPU box:
+    8.7 s per triplet with 128 threads, 1.0 s with 32, 0.46 s with 16), so the thread count is chosen by a short probe and
+    reported as `cores`."""
     import torch
     from oracle import ebp_oracle as O
     ow = O.OracleWhitebox('stresnet101', sd, ('hooked', None), mode)
-    n = 0
-    t0 = time.time()
-    while True:
-        i = n % probes.shape[0]
+
+    def triplet(i):
         xm = ow.encode(mates[i:i + 1]) / 2500.0
         xn = ow.encode(nonmates[i:i + 1]) / 2500.0
         ow.set_triplet_classifier(xm, xn)
         ow.contrastive_ebp(probes[i:i + 1], 0, 1)
+
+    ncpu = os.cpu_count() or 1
+    best_t, best_dt = None, None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32)}):
+        torch.set_num_threads(th)
+        t0 = time.time()
+        triplet(0)
+        d = time.time() - t0
+        if best_dt is None or d < best_dt:
+            best_t, best_dt = th, d
+    torch.set_num_threads(best_t)
+    n = 0
+    t0 = time.time()
+    while True:
+        triplet(n % probes.shape[0])
         n += 1
-        if time.time() - t0 > budget_s or n >= 8:
+        if time.time() - t0 > budget_s or n >= 64:
             break
     dt = time.time() - t0
-    return {'value': n / dt, 'unit': 'maps/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-            'sample': '%d ResNet-101 triplet(s) (2 encodes + contrastive_ebp each), batch 1, %.1f s' % (n, dt)}
+    return {'value': n / dt, 'unit': 'maps/s', 'cores': int(best_t), 'kind': 'port',
+            'sample': '%d ResNet-101 triplet(s) (2 encodes + contrastive_ebp each), batch 1, %.1f s, %d threads (best of 8/16/32; host has %d)'
+                      % (n, dt, best_t, ncpu)}
 
 
 def secondary(args, dev, rank, world):
