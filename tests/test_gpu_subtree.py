@@ -115,3 +115,34 @@ def test_inpainting_game_workload_tool(gpu_device):
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     res = json.loads(line)
     assert res['jobs'] == 3 and res['jobs_per_s'] > 0
+
+
+def test_workload_tool_writes_and_resumes(gpu_device, tmp_path):
+    """--output-dir: every job's four maps land in the generator's npz/PNG layout; a second run recomputes nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(GC.GOLDEN_DIR.rstrip('/').rsplit('/', 1)[0])
+    cmd = [sys.executable, os.path.join(root, 'tools', 'inpainting_game_workload.py'), '--jobs', '2', '--mates', '2', '--topk', '4',
+           '--num-classes', '300', '--output-dir', str(tmp_path)]
+    written = []
+    for _ in range(2):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        written.append(json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])['maps_written_rank0'])
+    assert written == [8, 0]
+    files = [f for _, _, fs in os.walk(str(tmp_path)) for f in fs]
+    assert sum(f.endswith('-saliency.npz') for f in files) == 8 and sum(f.endswith('-saliency-overlay.png') for f in files) == 8
+
+
+def test_embeddings_sweep_tool(gpu_device):
+    """tools/embeddings_sweep.py (SURVEY.md 8f row 3 shape) runs end to end."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(GC.GOLDEN_DIR.rstrip('/').rsplit('/', 1)[0])
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'embeddings_sweep.py'), '--masks', '48', '--batch', '32'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['masks'] == 48 and res['images_per_s'] > 0 and -1.0 <= res['mean_similarity'] <= 1.0
