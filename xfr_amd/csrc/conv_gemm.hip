@@ -224,22 +224,28 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     bool tap_dirty = true;
 
     // ---- issue the loads of one K-step into LDS stage `st`
-    auto issue = [&](int kt, int st) {
+    // `part` < 0: all loads of the K-step; 0 .. NP-1: the share that is issued after the part-th quarter of the step's
+    // MFMAs (the K loop interleaves the loads of a later step with the MFMAs of the current one: a vector-memory
+    // instruction issued while the wave's own MFMA executes costs the MFMA pipe nothing, a block of them between the
+    // barrier and the first MFMA does)
+    constexpr int NP = 4;
+    auto issue = [&](int kt, int st, int part) {
+        auto mine = [&](int i, int n) { return part < 0 || (i * NP) / n == part; };
         float* As = smem + st * STAGE;
         float* Bs = As + A_FLOATS;
         const int k0 = kt * BK;
         const bool live = kt < nk;      // steps past the end load nothing real (uniform vmcnt accounting)
 #pragma unroll
         for (int i = 0; i < A_PER_WAVE; ++i)
-            bload16(rW, As + (wave * A_PER_WAVE + i) * 256, live ? voffA[i] : OOB, (unsigned)kt * a_step);
+            if (mine(i, A_PER_WAVE)) bload16(rW, As + (wave * A_PER_WAVE + i) * 256, live ? voffA[i] : OOB, (unsigned)kt * a_step);
         if (MODE == MODE_VEC) {
 #pragma unroll
             for (int i = 0; i < B_PER_WAVE; ++i)
-                bload16(rIn, Bs + (wave * B_PER_WAVE + i) * 256, live ? voffB[i] : OOB, (unsigned)k0 * chan_bytes);
+                if (mine(i, B_PER_WAVE)) bload16(rIn, Bs + (wave * B_PER_WAVE + i) * 256, live ? voffB[i] : OOB, (unsigned)k0 * chan_bytes);
         } else if (MODE == MODE_TAP) {
             // Cin % 16 == 0: one tap per K-step; K-steps are issued in order, so (tap, ci0) advance incrementally
             const int tap = iss_tap, ci0 = iss_ci0;
-            if (tap_dirty) {                          // wave-uniform: new tap => new per-lane shifted offsets
+            if (part <= 0 && tap_dirty) {             // wave-uniform: new tap => new per-lane shifted offsets
                 tap_dirty = false;
                 const int dh = tap / p.kw, dw = tap - dh * p.kw;
                 const int shift = dh * p.W + dw;
@@ -251,13 +257,16 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
             for (int i = 0; i < B_PER_WAVE; ++i) {
                 const int q = wave * B_PER_WAVE + i;  // (k row, 64-wide m segment)
                 const int row = q / MSLOTS, s = q - row * MSLOTS;
-                bload4(rIn, Bs + q * 64, voffB[s], (unsigned)(ci0 + row) * chan_bytes);
+                if (mine(i, B_PER_WAVE)) bload4(rIn, Bs + q * 64, voffB[s], (unsigned)(ci0 + row) * chan_bytes);
             }
-            iss_ci0 += BK;
-            if (iss_ci0 >= p.Cin) { iss_ci0 = 0; iss_tap += 1; tap_dirty = true; }
+            if (part < 0 || part == NP - 1) {
+                iss_ci0 += BK;
+                if (iss_ci0 >= p.Cin) { iss_ci0 = 0; iss_tap += 1; tap_dirty = true; }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < B_PER_WAVE; ++i) {
+                if (!mine(i, B_PER_WAVE)) continue;
                 const int q = wave * B_PER_WAVE + i;
                 const int row = q / MSLOTS, s = q - row * MSLOTS;
                 const int k = k0 + row;
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
 
     // prologue: fill NST-1 stages
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s) issue(kt_lo + s, s);
+    for (int s = 0; s < NST - 1; ++s) issue(kt_lo + s, s, -1);
 
     const int a_off = wrow * (TCO / 2) + l31;
     const int b_off = wcol * (TM / 2) + l31;
@@ -310,7 +319,6 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         if (p.dbg_ts && kt == kt_lo) ts1 = __builtin_readcyclecounter();
         int st_fill = st + NST - 1;
         if (st_fill >= NST) st_fill -= NST;
-        issue(kt + NST - 1, st_fill);
         const float* As = smem + st * STAGE;
         const float* Bs = As + A_FLOATS;
         // software-pipelined LDS reads: the fragments of k-pair kk+2 are in flight while the MFMAs of kk run
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+            if ((kk / 2) % (BK / 2 / NP) == 0) issue(kt + NST - 1, st_fill, (kk / 2) / (BK / 2 / NP));
             if (kk + 2 < BK) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) a_cur[i] = a_nxt[i];
