@@ -541,6 +541,30 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
                 }
             }
         }
+    } else if (MI == 1 && NJ == 1 && NST * STAGE >= 4 * 32 * 36 && p.out_stride == 1 && (p.M & 3) == 0 && ((p.out_nb * p.OH * p.OW) & 3) == 0) {
+        // Dense output rows: turn the wave's 32x32 accumulator tile through LDS (the ring is free) so that a lane holds
+        // four consecutive m of one channel and the tile leaves in 4 dwordx4 stores per lane instead of 16 dword stores
+        // (8 x 128-byte rows per store instruction instead of 2).
+        constexpr int LD = 36;                                   // row pitch in floats: 16-byte aligned rows, no bank clash
+        __syncthreads();                                         // every wave is done reading the ring
+        float* tile = smem + wave * (32 * LD);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = acc[0][0][r];
+        const long row_stride = (long)p.out_nb * p.OH * p.OW;
+        const int mq = (lane & 7) * 4;
+        const int m = m0 + wcol * 32 + mq;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int cl = it * 8 + (lane >> 3);
+            const int co = co0 + wrow * 32 + cl;
+            float4 v = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
+            if (co < p.CoutTot && m < p.M) {
+                float4* dst = reinterpret_cast<float4*>(osel + (long)co * row_stride + m);
+                if (bsel) { const float b = bsel[co]; v.x += b; v.y += b; v.z += b; v.w += b; }
+                if (p.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *dst = v;
+            }
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
