@@ -30,6 +30,7 @@
 // no per-element address arithmetic and no branches.
 #include <algorithm>
 #include "common.h"
+#include "ew_interp.h"
 #include <cstdlib>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -424,6 +425,54 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         // p.chain_ld, <= 4 distinct tensors) are in flight together before the steps are interpreted: every workgroup of
         // a launch reaches its epilogue at the same time, so a chain of dependent loads here is paid in full.
         const EwLoads& ld = p.chain_ld;
+        if (MI == 1 && NJ == 1 && NST * STAGE >= 4 * 32 * 36 && (p.M & 3) == 0 && ((p.OH * p.OW) & 3) == 0) {
+            // vector path: the tile is turned through LDS like in the plain epilogue, a lane then owns float4 pieces
+            // (one channel, four consecutive positions of one sample) and runs the same float4 interpreter as the
+            // stand-alone chain kernel, operands fetched as 16-byte loads
+            constexpr int LD = 36;
+            __syncthreads();
+            float* tile = smem + wave * (32 * LD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = acc[0][0][r];
+            const int ohw = p.OH * p.OW;
+            const long row4 = (long)p.out_nb * ohw / 4, arow4 = (long)p.chain_B * ohw / 4;
+            const int mq = (lane & 7) * 4;
+            const int m = m0 + wcol * 32 + mq;
+            const int mm = m < p.M ? m : 0;
+            const int sb = mm / ohw;
+            const int hw = mm - sb * ohw;
+            const long acol4 = ((long)(sb % p.chain_B) * ohw + hw) / 4;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4* out4 = reinterpret_cast<float4*>(osel);
+#pragma unroll
+            for (int hf = 0; hf < 4; ++hf) {
+                float4 g[1], od[1], v0[1], v1[1], v2[1], v3[1];
+                long idx4[1], aidx4[1];
+                bool ok[1];
+                int cos[1];
+#pragma unroll
+                for (int u = 0; u < 1; ++u) {
+                    const int cl = (hf + u) * 8 + (lane >> 3);
+                    cos[u] = co0 + wrow * 32 + cl;
+                    ok[u] = cos[u] < p.CoutTot && m < p.M;
+                    const int cc = ok[u] ? cos[u] : 0;
+                    idx4[u] = (long)cc * row4 + mm / 4;
+                    aidx4[u] = (long)cc * arow4 + acol4;
+                    g[u] = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
+                    v0[u] = v1[u] = v2[u] = v3[u] = od[u] = z4;
+                    if (ld.lp[0]) v0[u] = reinterpret_cast<const float4*>(ld.lp[0])[aidx4[u]];
+                    if (ld.lp[1]) v1[u] = reinterpret_cast<const float4*>(ld.lp[1])[aidx4[u]];
+                    if (ld.lp[2]) v2[u] = reinterpret_cast<const float4*>(ld.lp[2])[aidx4[u]];
+                    if (ld.lp[3]) v3[u] = reinterpret_cast<const float4*>(ld.lp[3])[idx4[u]];
+                    if (p.accumulate) od[u] = out4[idx4[u]];
+                    if (bsel && ok[u]) { const float b = bsel[cos[u]]; g[u].x += b; g[u].y += b; g[u].z += b; g[u].w += b; }
+                }
+#pragma unroll
+                for (int u = 0; u < 1; ++u)
+                    ew_interpret<false>(ok[u], idx4[u], aidx4[u], sb, 0, g[u], od[u], v0[u], v1[u], v2[u], v3[u], out4, p.accumulate,
+                                        p.chain, cos[u], p.chain_eps);
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int m = m0 + wcol * (TM / 2) + j * 32 + l31;

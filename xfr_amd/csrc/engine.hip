@@ -105,7 +105,8 @@ struct BwdPlan {
     bool plain = false;              // true-weight gradients without hooks (whitebox.py:652-676 dA lists)
     std::vector<int> firing_tensor;  // tensor whose gradient each firing sees
     std::vector<BwdStep> steps;      // one launch per step, no cross-kernel fusion (used when tracing)
-    std::vector<BwdStep> fused;      // after copy forwarding and chain -> GEMM-epilogue fusion
+    std::vector<BwdStep> fused;      // after copy forwarding and chain -> chain merging
+    std::vector<BwdStep> fused_gemm; // ... and with the chains that follow a backward GEMM run in its epilogue
     std::vector<int> firing_kinds;   // xfr_op_kind per firing, reference order
     int n_firings = 0;
 };
@@ -179,7 +180,8 @@ struct xfr_engine {
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
     bool use_splitk = false;            // XFR_SPLITK=1
-    bool fuse_gemm_epilogue = false;   // XFR_FUSE_GEMM=1: also run hook chains inside the backward GEMM epilogue (measured slower)
+    bool fuse_gemm_epilogue = false;   // XFR_FUSE_GEMM=1: hook chains that follow a backward GEMM run in its (vector) epilogue
+                                       // (step -1.7 %, but 3 ms of HBM-bound chain work then sit inside the MFMA kernel: DESIGN.md section 6)
     bool no_fuse = false;          // XFR_NO_FUSE=1: one launch per schedule step (A/B and debugging)
     int last_trace_firings = 0, last_trace_sb = 0;
     std::vector<int> last_trace_kinds;
@@ -961,14 +963,17 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
         }
         st.swap(out);
     }
-    // ---- 2 + 3, to a fixed point
+    // ---- 2 + 3, to a fixed point: first among the chain launches only (plan.fused: the schedule of the sweeps that carry
+    // priors / captures), then with the backward GEMMs as heads of chains too (plan.fused_gemm)
+    for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) plan.fused = st;
     bool changed = true;
     while (changed) {
         changed = false;
         for (size_t i = 0; i < st.size() && !changed; ++i) {
             BwdStep& a = st[i];
             const bool a_ew = a.kind == ST_EW;
-            const bool a_conv = e->fuse_gemm_epilogue && a.kind == ST_CONV_BWD && !scatter_conv(a);
+            const bool a_conv = pass == 1 && a.kind == ST_CONV_BWD && !scatter_conv(a);
             if (!a_ew && !a_conv) continue;
             const int b_t = a.dst_t;
             if (b_t < 0) continue;
@@ -1018,7 +1023,8 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             changed = true;
         }
     }
-    plan.fused.swap(st);
+    }
+    plan.fused_gemm.swap(st);
 }
 
 xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out, bool plain = false)
@@ -1031,7 +1037,7 @@ xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out, bool plain = 
     if (!plain) fuse_plan(e, e->plans.back());
     if (getenv("XFR_PLAN_DUMP")) {   // debug: the fused backward schedule, one line per launch
         static const char* kn[] = {"EW", "CONV_BWD", "MAXPOOL_BWD", "AVGPOOL_BWD", "COPY", "MAXHALVES_BWD", "NORMALIZE_BWD", "ZERO"};
-        for (const BwdStep& st : e->plans.back().fused) {
+        for (const BwdStep& st : (e->fuse_gemm_epilogue ? e->plans.back().fused_gemm : e->plans.back().fused)) {
             const int tt = st.kind == ST_EW ? st.ew_t : st.dst_t;
             fprintf(stderr, "plan %-13s src %3d dst %3d acc %d", kn[st.kind], st.src_t, st.dst_t, st.accumulate);
             if (tt >= 0) fprintf(stderr, " [%d x %d x %d]", e->tens[tt].C, e->tens[tt].H, e->tens[tt].W);
@@ -1112,7 +1118,8 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
     // pool / copy kernels still run over all streams and move zeros).  SBa = streams alive at this step.
     const bool prefix = !e->rc_active.empty() && (int)e->rc_active.size() == SB;
     int run_max = -1;
-    for (const BwdStep& st : (use_fused ? plan.fused : plan.steps)) {
+    const bool use_gemm_fusion = use_fused && e->fuse_gemm_epilogue && !special && !plan.fused_gemm.empty();
+    for (const BwdStep& st : (use_gemm_fusion ? plan.fused_gemm : use_fused ? plan.fused : plan.steps)) {
         int SBa = SB;
         if (prefix) {
             for (const auto& sy : st.chain)

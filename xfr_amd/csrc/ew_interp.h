@@ -1,0 +1,123 @@
+// Shared device code: the float4 interpreter of a hook-chain micro-program (EwChain), used by the stand-alone chain kernel
+// (elementwise.hip) and by the chain epilogue of the convolution GEMM (conv_gemm.hip).
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ float pick1(float a0, float a1, float a2, float a3, int slot)
+{
+    float r = a0;
+    r = slot == 1 ? a1 : r;
+    r = slot == 2 ? a2 : r;
+    r = slot == 3 ? a3 : r;
+    return r;
+}
+// component-wise on plain floats: a select between float4 objects is lowered through memory (scratch)
+__device__ __forceinline__ float4 pick_slot(float4 v0, float4 v1, float4 v2, float4 v3, int slot)
+{
+    return make_float4(pick1(v0.x, v1.x, v2.x, v3.x, slot), pick1(v0.y, v1.y, v2.y, v3.y, slot),
+                       pick1(v0.z, v1.z, v2.z, v3.z, slot), pick1(v0.w, v1.w, v2.w, v3.w, slot));
+}
+
+template <bool PRIOR>
+__device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int sb, int el0, float4 gv, float4 od, float4 v0, float4 v1,
+                                             float4 v2, float4 v3, float4* __restrict__ dst,
+                                             int accumulate, const EwChain& ch, int c, float eps)
+{
+    if (!ok) return;
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll 1
+    for (int i = 0; i < ch.n; ++i) {
+        const EwStep& st = ch.s[i];
+        const int s0 = st.ls0, s1 = st.ls1;
+        if (st.type == EW_HOOK) {
+            if (s0 == -2) {          // p is not observed: the hook is relu(g) or the identity
+                if (st.action == HOOK_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
+                }
+                continue;
+            }
+            const float4 av = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[aidx];
+            const float a[4] = {fmaxf(av.x, 0.f), fmaxf(av.y, 0.f), fmaxf(av.z, 0.f), fmaxf(av.w, 0.f)};
+            float p[4], zh[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { zh[q] = fmaxf(g[q], 0.f); p[q] = a[q] * zh[q]; }
+            if (PRIOR && st.prior_sb >= 0 && sb == st.prior_sb) {
+                // layerwise EBP: p of this sample is overridden by the prior (whitebox.py:390-392)
+                float pr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pr[q] = st.prior_dense ? st.prior_dense[el0 + q] : ((el0 + q) == st.prior_elem ? st.prior_val : 0.f);
+                if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+                if (st.prior_action == PRIOR_DIV) {
+                    float x[4] = {a[0], a[1], a[2], a[3]};
+                    if (st.p1) {
+                        const float4 xv = s1 >= 0 ? pick_slot(v0, v1, v2, v3, s1) : reinterpret_cast<const float4*>(st.p1)[aidx];
+                        x[0] = fmaxf(xv.x, 0.f); x[1] = fmaxf(xv.y, 0.f); x[2] = fmaxf(xv.z, 0.f); x[3] = fmaxf(xv.w, 0.f);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = __fdiv_rn(pr[q], x[q] + eps);
+                } else if (st.prior_action == PRIOR_GATEZ) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = pr[q] > 0.f ? g[q] : 0.f;
+                }
+                if (st.cap_dst) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (idx * 4 + q == st.cap_idx) *st.cap_dst = pr[q];
+                }
+                continue;
+            }
+            if (PRIOR && st.cap_dst) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (idx * 4 + q == st.cap_idx) *st.cap_dst = p[q];
+            }
+            if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(p[0], p[1], p[2], p[3]);
+            if (st.action == HOOK_DIV) {
+                float x[4];
+                if (st.p1) {
+                    const float4 xv = s1 >= 0 ? pick_slot(v0, v1, v2, v3, s1) : reinterpret_cast<const float4*>(st.p1)[aidx];
+                    x[0] = fmaxf(xv.x, 0.f); x[1] = fmaxf(xv.y, 0.f); x[2] = fmaxf(xv.z, 0.f); x[3] = fmaxf(xv.w, 0.f);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = a[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = __fdiv_rn(p[q], x[q] + eps);
+            } else if (st.action == HOOK_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = zh[q];
+            }
+        } else if (st.type == EW_MASK) {
+            const float4 tv = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[aidx];
+            g[0] = tv.x > 0.f ? g[0] : 0.f; g[1] = tv.y > 0.f ? g[1] : 0.f;
+            g[2] = tv.z > 0.f ? g[2] : 0.f; g[3] = tv.w > 0.f ? g[3] : 0.f;
+        } else if (st.type == EW_SCALE_C) {
+            const float sc = st.p0[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] *= sc;
+        } else if (st.type == EW_SCALE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] *= st.f;
+        } else if (st.type == EW_STORE) {
+            reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(g[0], g[1], g[2], g[3]);
+        } else if (st.type == EW_ADDP) {
+            const float4 d = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[idx];
+            g[0] += d.x; g[1] += d.y; g[2] += d.z; g[3] += d.w;
+        } else if (st.type == EW_AFFINE_C) {
+            const float al = st.p0[c], be = st.p1[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(__fmul_rn(g[q], al), be);
+        } else if (st.type == EW_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
+        } else {
+            const float al = st.p0[c], be = st.p1[c];
+            reinterpret_cast<float4*>(st.pstore)[idx] =
+                make_float4(__fadd_rn(__fmul_rn(fmaxf(g[0], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[1], 0.f), al), be),
+                            __fadd_rn(__fmul_rn(fmaxf(g[2], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[3], 0.f), al), be));
+        }
+    }
+    float4 o = make_float4(g[0], g[1], g[2], g[3]);
+    if (accumulate) { o.x += od.x; o.y += od.y; o.z += od.z; o.w += od.w; }
+    dst[idx] = o;
+}
+
