@@ -124,11 +124,14 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
 template <bool PRIOR, int SG>     // PRIOR: the chain carries layerwise-EBP priors or captures (EwStep.prior_*, cap_*)
 __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restrict__ src, float4* __restrict__ dst,
                                                         int accumulate, const EwChain ch, const EwLoads ld, int C, int SB,
-                                                        int B, int HW4, float eps, int SBa)
+                                                        int B, int HW4, float eps, int SBa, int per_ca4)
 {
+    // per_ca4 = B*HW/4: one stream of the channel row in float4 pieces.  HW4 = HW/4 is only used to split a position into
+    // (sample, hw) for priors and for stream prefixes; when HW % 4 != 0 but B*HW % 4 == 0 (7x7 maps at an even batch) a
+    // piece may straddle two samples of the same stream, which the chain arithmetic does not care about
     const int c = blockIdx.y;
-    const unsigned per_ca = (unsigned)B * (unsigned)HW4;       // one stream of the channel row
-    const unsigned per_c = (unsigned)SB * (unsigned)HW4;       // row stride; < 2^31 (every tensor is < 2^31 bytes)
+    const unsigned per_ca = (unsigned)per_ca4;
+    const unsigned per_c = (unsigned)(SB / B) * per_ca;        // row stride; < 2^31 (every tensor is < 2^31 bytes)
     const unsigned pos = blockIdx.x * (unsigned)NT + threadIdx.x;
     if (pos >= per_ca) return;
     const long aidx = (long)c * per_ca + pos;
@@ -583,16 +586,19 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
     const long total = (long)C * SB * HW;
     for (int i = 0; i < chain.n; ++i)
         if (accumulate && chain.s[i].pstore == dst) special = true;   // the float4 kernel reads dst before the chain runs
-    if (!trace && !special && (HW % 4) == 0 && C <= 65535 && SB % B == 0 && SB / B <= 2 * 65535) {
+    // float4 pieces: whole samples when HW % 4 == 0; otherwise (7x7 maps) pieces of the flat [B*HW] stream row, which is
+    // fine as long as nothing needs the sample of a piece (no priors, no stream prefix)
+    const bool pieces_ok = (HW % 4) == 0 || (((long)B * HW) % 4 == 0 && !prior && SBa == SB);
+    if (!trace && !special && pieces_ok && C <= 65535 && SB % B == 0 && SB / B <= 2 * 65535) {
         EwLoads ld;
         EwChain planned = chain;
         ew_plan_loads(planned, dst, ld);
         const int S = SB / B, Sa = (SBa + B - 1) / B;                    // streams, streams with live samples
-        const long per_ca4 = (long)B * (HW / 4);
+        const long per_ca4 = (long)B * HW / 4;
         const unsigned gx = (unsigned)((per_ca4 + NT - 1) / NT);
         auto go = [&](auto kern, int sg) {
             hipLaunchKernelGGL(kern, dim3(gx, C, (unsigned)((Sa + sg - 1) / sg)), dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
-                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps, SBa);
+                               reinterpret_cast<float4*>(dst), accumulate, planned, ld, C, SB, B, HW / 4, eps, SBa, (int)per_ca4);
         };
         if (S == 1) { if (prior) go(ew_chain_kernel_v4<true, 1>, 1); else go(ew_chain_kernel_v4<false, 1>, 1); }
         else { if (prior) go(ew_chain_kernel_v4<true, 2>, 2); else go(ew_chain_kernel_v4<false, 2>, 2); }
