@@ -271,6 +271,18 @@ def main():
                 'executed_flop_per_step': tot_fl / reps, 'algorithmic_flop_per_step': alg / reps}
         if B == 32 and args.mode == 'affineonly_with_prior':
             roof.update(pmc_traffic(os.path.dirname(os.path.abspath(__file__))))
+        # the same launches with the elementwise epilogues un-fused (convolution work only): reference figure for the MFMA
+        # kernel by itself; the product path above is the fused one
+        eng.set_epilogue_fusion(False)
+        eng.set_profile(True)
+        u_ms, u_n = 0.0, 0
+        for _ in range(reps):
+            eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, None)
+            ms, n, fl = eng.get_profile(); u_ms += ms; u_n += n
+        eng.set_profile(False)
+        eng.set_epilogue_fusion(True)
+        roof['unfused_epilogues'] = {'achieved': alg / (u_ms * 1e-3) / 1e12, 'frac': alg / (u_ms * 1e-3) / PEAK_F32_MFMA,
+                                     'gemm_ms_per_step': u_ms / reps, 'avg_launch_ms': u_ms / max(u_n, 1)}
 
     if rank == 0:
         value = world * B * args.steps / dt

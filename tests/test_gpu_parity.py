@@ -484,3 +484,29 @@ def test_hold_forward_shares_and_drops_state(gpu_device):
     finally:
         eng.hold_forward(False)
     assert np.array_equal(wb.contrastive_ebp(b, 0, 1), ref_b)
+
+
+@pytest.mark.parametrize('arch,mode', [('stresnet_mini', 'affineonly_with_prior'), ('stresnet_mini', 'norelu'), ('resnet50_128', 'norelu'),
+                                       ('lightcnn29v2', 'affineonly')])
+def test_epilogue_fusion_is_bit_identical(gpu_device, arch, mode):
+    """xfr_engine_set_epilogue_fusion: hook chains / BatchNorm+add+ReLU inside the GEMM epilogue (default) or as their own
+    launches run the same arithmetic in the same order: identical bits for encodings, EBP and contrastive maps."""
+    bb, sd = make_backbone(arch, seed=6, num_classes=None if arch == 'resnet50_128' else 7)
+    subj = GC.engine_subject(arch, bb, mode)
+    wb = subj.wb
+    n = 4
+    x = make_images(arch, n, seed=31, smooth=False).to(gpu_device)
+    D = emb_dim(arch)
+    xm = (synth.unit_rows(n, D, seed=3) / 2500).to(gpu_device)
+    xn = (synth.unit_rows(n, D, seed=4) / 2500).to(gpu_device)
+    subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
+    eng = wb._engine(2 * n)
+    res = {}
+    for fused in (True, False):
+        eng.set_epilogue_fusion(fused)
+        res[fused] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
+                      wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone(),
+                      wb.triplet_images_ebp_batch(x[:2], x[2:4], x[1:3]).clone())
+    eng.set_epilogue_fusion(True)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)

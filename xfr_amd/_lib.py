@@ -43,6 +43,7 @@ SYMBOLS = [
     ('xfr_engine_set_pipeline', _I, [_P, _I]),
     ('xfr_engine_set_tail_balance', _I, [_P, _I]),
     ('xfr_engine_hold_forward', _I, [_P, _I]),
+    ('xfr_engine_set_epilogue_fusion', _I, [_P, _I]),
     ('xfr_mwp_to_saliency', _I, [_P, _P, _I, _I, _I, _P, _P]),
     ('xfr_firing_count', _I, [_P, _I, ctypes.POINTER(_I)]),
     ('xfr_subtree_weights', _I, [_P, _P, _I, _I, _P, _I, ctypes.POINTER(_F), ctypes.POINTER(_I), _I, _P]),

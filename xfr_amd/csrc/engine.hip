@@ -180,8 +180,9 @@ struct xfr_engine {
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
     bool use_splitk = false;            // XFR_SPLITK=1
-    bool fuse_gemm_epilogue = false;   // XFR_FUSE_GEMM=1: hook chains that follow a backward GEMM run in its (vector) epilogue
-                                       // (step -1.7 %, but 3 ms of HBM-bound chain work then sit inside the MFMA kernel: DESIGN.md section 6)
+    bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue; XFR_NO_ENC_FUSE=1: own kernels
+    bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue; XFR_NO_FUSE_GEMM=1:
+                                       // stand-alone launches (DESIGN.md section 6 has both measurements)
     bool no_fuse = false;          // XFR_NO_FUSE=1: one launch per schedule step (A/B and debugging)
     int last_trace_firings = 0, last_trace_sb = 0;
     std::vector<int> last_trace_kinds;
@@ -571,6 +572,51 @@ void conv_geometry(xfr_engine* e, int k, int NB, ConvParams& p)
     p.tap_major = o.tap_fwd ? 1 : 0;
 }
 
+// Forward-only runs (encode, embeddings, the gallery of a triplet step) never need the raw convolution output:
+// Conv -> BatchNorm [-> Add with an already computed operand] [-> in-place ReLU] runs in the GEMM's chain epilogue
+// (per-channel affine, residual read as 16-byte pieces, clamp), same arithmetic in the same order as the stand-alone
+// kernels.
+void fuse_forward_only(xfr_engine* e, int k, int B, ConvParams& p)
+{
+    const xfr_op_desc& d = e->ops[k].d;
+    const Tensor& c = e->tens[d.out];
+    if (c.consumers.size() != 1) return;
+    const int k1 = c.consumers[0];
+    if (k1 > e->fwd_last_op) return;
+    const OpRec& bn = e->ops[k1];
+    if (bn.d.kind != XFR_OP_BATCHNORM) return;
+    const int bn_out = bn.d.out;
+    EwChain& ch = p.chain;
+    ch.n = 0;
+    auto push = [&](int type) -> EwStep& { EwStep& q = ch.s[ch.n++]; memset(&q, 0, sizeof(q)); q.type = type; q.prior_sb = -1; q.cap_idx = -1; return q; };
+    {
+        EwStep& q = push(EW_AFFINE_C);
+        q.p0 = e->arena + bn.bn_alpha_t;
+        q.p1 = e->arena + bn.bn_beta_t;
+    }
+    int final_t = bn_out, k2 = -1;
+    bool fused_add = false;
+    if (!bn.fuse_relu && e->tens[bn_out].consumers.size() == 1) {
+        k2 = e->tens[bn_out].consumers[0];
+        const OpRec& ad = e->ops[k2];
+        if (k2 <= e->fwd_last_op && (ad.d.kind == XFR_OP_ADD || ad.d.kind == XFR_OP_G_ADD)) {
+            const int other = (ad.d.in0 == bn_out) ? ad.d.in1 : ad.d.in0;
+            if (other != bn_out && e->tens[other].producer < k) {          // the other operand is already computed
+                push(EW_ADDP).p0 = e->T(other);
+                if (ad.fuse_relu) push(EW_RELU);
+                final_t = ad.d.out;
+                fused_add = true;
+            }
+        }
+    }
+    if (!fused_add && bn.fuse_relu) push(EW_RELU);
+    p.out0 = e->T(final_t);
+    p.chain_B = B;
+    p.chain_eps = e->eps;
+    e->fwd_done[k1] = 1;
+    if (fused_add) e->fwd_done[k2] = 1;
+}
+
 // forward of op k on true values (and, for "dual" convolutions, the positive output in the same launch)
 xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
 {
@@ -599,6 +645,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
                 p.out1 = e->Pv(d.out);
                 p.nhalves = 2;
             } else p.nhalves = 1;
+            if (!want_pos && !e->no_fuse && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p);
             return run_conv(e, p, s);
         }
         case XFR_OP_BATCHNORM:
@@ -1323,7 +1370,8 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
         return fail(XFR_UNSUPPORTED_LAYER, "the first layer must be a convolution on the input image");
     xfr_engine* e = new xfr_engine();
     e->no_fuse = getenv("XFR_NO_FUSE") != nullptr;
-    e->fuse_gemm_epilogue = getenv("XFR_FUSE_GEMM") != nullptr;
+    e->fuse_gemm_epilogue = getenv("XFR_NO_FUSE_GEMM") == nullptr;
+    e->fuse_fwd_only = getenv("XFR_NO_ENC_FUSE") == nullptr;
     e->use_splitk = getenv("XFR_SPLITK") != nullptr;
     e->device = device; e->max_batch = max_batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
     xfr_status st = build(e, ops, n_ops);
@@ -1648,6 +1696,15 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     }
     e->cur_slot = 0;
     return prof_end(e, s);
+}
+
+xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->fuse_gemm_epilogue = enable != 0;
+    e->fuse_fwd_only = enable != 0;
+    e->held_x = nullptr;
+    return XFR_OK;
 }
 
 xfr_status xfr_engine_hold_forward(xfr_engine* e, int32_t hold)

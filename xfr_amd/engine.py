@@ -170,6 +170,10 @@ class Engine(object):
         """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
         _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call
 
+    def set_epilogue_fusion(self, on):
+        """Hook chains / BatchNorm+add+ReLU inside the GEMM epilogue (default on) or as their own launches."""
+        _lib.check(self.lib.xfr_engine_set_epilogue_fusion(self._h, int(bool(on))))
+
     def hold_forward(self, on):
         """Consecutive calls on the same input tensor share one forward pass while held (include/xfr_amd.h)."""
         _lib.check(self.lib.xfr_engine_hold_forward(self._h, int(bool(on))))
