@@ -9,7 +9,7 @@ P=profiles/$R
 export TMPDIR=/tmp
 mkdir -p "$D" "$P"
 ST="--kernel-trace --stats --output-format csv"
-rocprofv3 $ST -d $D/serial -o $R -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --serial > $P/bench_serial_under_rocprof.json 2> $D/serial.err
+rocprofv3 $ST -d $D/serial -o $R -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --serial --no-unfused-ref > $P/bench_serial_under_rocprof.json 2> $D/serial.err
 rocprofv3 $ST -d $D/pipelined -o $R -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-profile > $P/bench_pipelined_under_rocprof.json 2> $D/pipelined.err
 cp $D/serial/${R}_kernel_stats.csv $P/kernel_stats_serial.csv
 cp $D/pipelined/${R}_kernel_stats.csv $P/kernel_stats_pipelined.csv
