@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define XFR_AMD_ABI_VERSION 1
+#define XFR_AMD_ABI_VERSION 2
 
 typedef enum {
     XFR_OK = 0,
@@ -194,6 +194,14 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
  * Costs one extra copy of the forward workspace.  Synchronises the device. */
 xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
 
+/* Pipeline level 2 only.  ready = 0 (default): the internal forward stream of xfr_ebp / xfr_contrastive /
+ * xfr_contrastive_raw first waits for everything already enqueued on the caller's `stream`, so an x_dev that is still
+ * being produced there (a cast, a host-to-device copy) is safe -- at the price of the cross-call overlap.  ready = 1: the
+ * caller promises that x_dev of the following calls is already valid on the device and stays untouched until the result
+ * has been consumed (the inputs_ready contract of xfr_triplet_contrastive); the forward then only waits for the slot it
+ * overwrites.  The reference has no counterpart: its inputs are host tensors moved with .to(device) on one stream. */
+xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
+
 /* Epilogue fusion (on by default): the hook chain that follows a backward-data GEMM, and BatchNorm / residual add / ReLU
  * after a convolution of a forward-only run (encode, the gallery of a triplet step), execute in the GEMM's epilogue on the
  * LDS-transposed accumulator tile instead of in their own launches -- same arithmetic in the same order, bit-identical maps,
@@ -226,6 +234,10 @@ xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n
 
 /* Number of hook firings of a sweep seeded at `seed_tensor` (= len(Whitebox.P) - 1: the image hook is not computed). */
 xfr_status xfr_firing_count(xfr_engine* e, int32_t seed_tensor, int32_t* n_firings);
+
+/* xfr_op_kind of the hooked module of every firing, reference order: what Whitebox.P_layername (whitebox.py:393) lists,
+ * without running anything. */
+xfr_status xfr_firing_kinds(xfr_engine* e, int32_t seed_tensor, int32_t* kinds, int32_t capacity);
 
 /* whitebox.py:652-697: true-weight gradients of the two classifier outputs at every hooked module input (the `dA`
  * lists of the 'activation'-mode `_savegrad` hooks, :355-358), reduced per firing k to
@@ -263,7 +275,8 @@ xfr_status xfr_engine_get_trace(xfr_engine* e, double* sums, int32_t* kinds, int
 
 /* Test / tuning hook: one forward convolution through the engine's implicit-GEMM kernel, outside any engine.
  * in_dev/out_dev are CNHW device tensors ([C][NB][H][W]); w_host/bias_host are PyTorch-layout host arrays.
- * cfg = 0 lets the launcher pick the tile configuration, cfg > 0 forces configuration `cfg`.  The kernel is run
+ * cfg % 100: 0 lets the launcher pick the tile configuration, 4 / 5 force the 16- / 32-deep 64x64 configuration;
+ * cfg / 10000: tail balancing 0 = heuristic, 1 = off, S >= 2 = S parts per tail tile.  The kernel is run
  * `reps` times after one untimed launch; *ms_out receives the average duration (HIP events on the null stream). */
 xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float* bias_host, float* out_dev, int32_t cin,
                           int32_t h, int32_t w, int32_t nb, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
@@ -277,6 +290,22 @@ xfr_status xfr_engine_memory(xfr_engine* e, size_t* weight_bytes, size_t* worksp
  * bench.py for the live roofline figure. */
 xfr_status xfr_engine_set_profile(xfr_engine* e, int32_t enable);
 xfr_status xfr_engine_get_profile(xfr_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+/* While profiling is on, also append one CSV record per GEMM launch to `path` (NULL: stop):
+ * Cout,nhalves,K,M,kh,stride,out_stride,relu_in,accumulate,ms,TFLOP/s  (profiles/layer_table.py reads it). */
+xfr_status xfr_engine_profile_csv(xfr_engine* e, const char* path);
+
+/* Process-wide counts of GEMM launches that carried a fused elementwise chain: those whose epilogue was one of the
+ * compile-time specialised ones (xfr_amd/csrc/chain_sigs.inc) and those that fell back to the interpreter; n_signatures =
+ * size of the compiled table.  bench.py and the tests assert interpreted == 0 on the three BASELINE backbones. */
+xfr_status xfr_chain_epilogue_stats(int64_t* compiled_launches, int64_t* interpreted_launches, int32_t* n_signatures);
+
+/* The planner without a device: the fused forward-only and backward schedules of a layer program for one subtree mode and
+ * seed tensor, as text (one launch per line; GEMM lines carry the signature of their fused chain and the index of its
+ * compiled epilogue, -1 if it would be interpreted).  Makes no HIP call, so it also runs where no GPU is visible:
+ * tools/gen_chain_sigs.py builds chain_sigs.inc from it and the CPU test-suite checks the table against it.
+ * `needed` (may be NULL) receives the full length including the terminator; `buf` gets at most `capacity` bytes. */
+xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_weights, int32_t in_c, int32_t in_h, int32_t in_w,
+                             int32_t batch, int32_t subtree_mode, int32_t seed_tensor, char* buf, size_t capacity, size_t* needed);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libxfr_amd.so')
 
 XFR_OK, XFR_INVALID_ARG, XFR_UNSUPPORTED_LAYER, XFR_OOM, XFR_HIP_ERROR, XFR_STATE_ERROR = range(6)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class TensorView(ctypes.Structure):
@@ -41,11 +41,13 @@ SYMBOLS = [
     ('xfr_contrastive_raw', _I, [_P, _P, _I, _I, _P, _F, _P, _P]),
     ('xfr_triplet_contrastive', _I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I]),
     ('xfr_engine_set_pipeline', _I, [_P, _I]),
+    ('xfr_engine_set_inputs_ready', _I, [_P, _I]),
     ('xfr_engine_set_tail_balance', _I, [_P, _I]),
     ('xfr_engine_hold_forward', _I, [_P, _I]),
     ('xfr_engine_set_epilogue_fusion', _I, [_P, _I]),
     ('xfr_mwp_to_saliency', _I, [_P, _P, _I, _I, _I, _P, _P]),
     ('xfr_firing_count', _I, [_P, _I, ctypes.POINTER(_I)]),
+    ('xfr_firing_kinds', _I, [_P, _I, ctypes.POINTER(_I), _I]),
     ('xfr_subtree_weights', _I, [_P, _P, _I, _I, _P, _I, ctypes.POINTER(_F), ctypes.POINTER(_I), _I, _P]),
     ('xfr_ebp_capture', _I, [_P, _P, _I, _P, ctypes.POINTER(_I), ctypes.POINTER(_F), _I, _P]),
     ('xfr_layerwise_ebp', _I, [_P, _P, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_F), _P, _P, _P]),
@@ -58,6 +60,10 @@ SYMBOLS = [
     ('xfr_engine_set_profile', _I, [_P, _I]),
     ('xfr_engine_get_profile', _I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                     ctypes.POINTER(ctypes.c_double)]),
+    ('xfr_engine_profile_csv', _I, [_P, ctypes.c_char_p]),
+    ('xfr_chain_epilogue_stats', _I, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_I)]),
+    ('xfr_plan_describe', _I, [ctypes.POINTER(OpDesc), _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, ctypes.c_size_t,
+                               ctypes.POINTER(ctypes.c_size_t)]),
 ]
 
 _lib = None

@@ -115,6 +115,59 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
     ld.nl = ld.lp[3] ? 4 : (ld.lp[2] ? 3 : (ld.lp[1] ? 2 : (ld.lp[0] ? 1 : 0)));   // slots in use form a prefix, except that 3 may follow a gap
 }
 
+// Compile-time signature of a planned chain: one 16-bit code per step that does anything.  The GEMM epilogue is
+// specialised per signature (conv_gemm.hip: the table chain_sigs.inc lists the signatures the three backbones produce;
+// chains outside the table run through the interpreter).  Code = op | s0 << 4 | s1 << 7 | store << 10 | step << 11 with
+// s0 / s1 the prefetch slot of p0 / p1 (0..3), 4 = load in place, 7 = none (a hook whose x is its a).
+enum { SIG_END = 0, SIG_HOOK_DIV = 1, SIG_HOOK_RELU = 2, SIG_HOOK_PASS = 3, SIG_RELU = 4, SIG_MASK = 5, SIG_SCALE_C = 6, SIG_SCALE = 7,
+       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11 };
+constexpr int sig_op(unsigned c) { return (int)(c & 15u); }
+constexpr int sig_s0(unsigned c) { return (int)((c >> 4) & 7u); }
+constexpr int sig_s1(unsigned c) { return (int)((c >> 7) & 7u); }
+constexpr bool sig_store(unsigned c) { return ((c >> 10) & 1u) != 0; }
+constexpr int sig_step(unsigned c) { return (int)((c >> 11) & 15u); }
+
+// codes[] of a chain whose prefetch slots are assigned (ew_plan_loads); returns the number of codes, or -1 if the chain
+// uses features only the interpreter has (priors, captures, traces)
+inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
+{
+    int n = 0;
+    auto slot = [](int ls) -> unsigned { return ls >= 0 ? (unsigned)ls : 4u; };
+    for (int i = 0; i < ch.n; ++i) {
+        const EwStep& st = ch.s[i];
+        unsigned op = 0, s0 = 7, s1 = 7, store = 0;
+        switch (st.type) {
+            case EW_HOOK:
+                if (st.trace || st.prior_sb >= 0 || st.cap_dst) return -1;
+                if (st.ls0 == -2) {                     // p unobserved: relu(g) or the identity
+                    if (st.action != HOOK_RELU) continue;
+                    op = SIG_RELU;
+                    break;
+                }
+                op = st.action == HOOK_DIV ? SIG_HOOK_DIV : (st.action == HOOK_RELU ? SIG_HOOK_RELU : SIG_HOOK_PASS);
+                s0 = slot(st.ls0);
+                if (st.action == HOOK_DIV && st.p1) s1 = slot(st.ls1);
+                store = st.pstore ? 1u : 0u;
+                break;
+            case EW_MASK: op = SIG_MASK; s0 = slot(st.ls0); break;
+            case EW_SCALE_C: op = SIG_SCALE_C; break;
+            case EW_SCALE: op = SIG_SCALE; break;
+            case EW_STORE: op = SIG_STORE; break;
+            case EW_ADDP: op = SIG_ADDP; s0 = slot(st.ls0); break;
+            case EW_AFFINE_C: op = SIG_AFFINE_C; break;
+            case EW_RELU: op = SIG_RELU; break;
+            case EW_FORK_POSBN: op = SIG_FORK_POSBN; break;
+            default: return -1;
+        }
+        codes[n++] = (uint16_t)(op | (s0 << 4) | (s1 << 7) | (store << 10) | ((unsigned)i << 11));
+    }
+    return n;
+}
+// index into the compiled-signature table, -1 if absent (conv_gemm.hip)
+int conv_gemm_chain_sig(const EwChain& planned_chain);
+int conv_gemm_num_chain_sigs();
+void conv_gemm_chain_launch_counts(long* compiled, long* interpreted);
+
 // ---- implicit-GEMM convolution -------------------------------------------------------------------------------
 struct ConvParams {
     const float* in;    // [Cin][NB][H][W]
@@ -128,9 +181,6 @@ struct ConvParams {
     int in_nb, out_nb;  // images per channel row of the input / output tensors (>= NB: a launch may cover a batch prefix)
     unsigned in_bytes;  // byte size of the input tensor (buffer descriptor range; < 2^31)
     int force_cfg;      // 0 = heuristic tile choice, else a configuration id (tuning / tests)
-    int ksplit;         // 0 = heuristic, 1 = no split, P > 1 = split K into P parts (partials via splitk_ws + reduce kernel)
-    float* splitk_ws;   // scratch for split-K partial sums (nullptr: never split)
-    size_t splitk_ws_bytes;
     // tail balancing (conv_gemm.hip): the last tiles % CUs tiles of a small grid are cut along K into tail_s parts
     // each, so that every CU gets the same share of the final round; parts meet in tail_ws, the last arriver reduces.
     float* tail_ws;     // scratch for the parts' accumulators (nullptr: never balance); one per stream in flight
@@ -150,7 +200,7 @@ struct ConvParams {
     float chain_eps;    // eps of the hook divide
     EwChain chain;      // epilogue micro-program applied to half 0 before the final store (n == 0: none)
     EwLoads chain_ld;   // its operand prefetch plan (set by launch_conv_gemm)
-    unsigned long long* dbg_ts;   // tuning: per-workgroup timestamps {start, first K-step ready, K loop done, end, XCC/CU id} (nullptr: off)
+    int chain_sig;      // index of the chain's compiled epilogue (chain_sigs.inc), -1: interpreted (set by launch_conv_gemm)
 };
 
 constexpr int XFR_TAIL_MAX_TILES = 256;

@@ -171,22 +171,19 @@ struct xfr_engine {
     // Measured on MI355X (bench.py, B=32): folding BatchNorm/ReLU(/residual) into the forward GEMM epilogue is 2-4 % SLOWER
     // than separate streaming kernels -- the HBM-bound elementwise kernels of one stream overlap the MFMA-bound GEMMs of
     // the other for free, while extra epilogue stores stretch every workgroup of a lock-step grid.  Kept for experiments.
-    float* splitk_buf[3] = {nullptr, nullptr, nullptr};   // split-K partial-sum slabs: caller stream, internal stream a, b
-    size_t splitk_bytes = 0;
     // tail-balancing scratch (conv_gemm.hip), one per stream that launches GEMMs; kernels on one stream serialise,
     // so consecutive launches share it
     struct TailWs { hipStream_t s; float* ws; unsigned* cnt; };
     TailWs tail_ws[8];
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
-    bool use_splitk = false;            // XFR_SPLITK=1
-    bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue; XFR_NO_ENC_FUSE=1: own kernels
-    bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue; XFR_NO_FUSE_GEMM=1:
-                                       // stand-alone launches (DESIGN.md section 6 has both measurements)
-    bool no_fuse = false;          // XFR_NO_FUSE=1: one launch per schedule step (A/B and debugging)
+    bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
+    bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
+                                       // (both: xfr_engine_set_epilogue_fusion; DESIGN.md section 6 has the measurements)
     int last_trace_firings = 0, last_trace_sb = 0;
     std::vector<int> last_trace_kinds;
     int profile_on = 0;
+    std::string profile_csv;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<ConvParams> ev_params;
     size_t ev_used = 0;
@@ -203,7 +200,8 @@ struct xfr_engine {
     // cross-step pipelining (xfr_engine_set_pipeline): two forward slots (T, Pv, norms, argmax) so that the forward of
     // triplet call i+1 may run while the backward sweep of call i still reads slot i%2
     bool pipeline = false;
-    bool pipeline_all = false;     // level 2: xfr_ebp / xfr_contrastive calls are pipelined too (their inputs must be ready)
+    bool pipeline_all = false;     // level 2: xfr_ebp / xfr_contrastive calls are pipelined too
+    bool inputs_ready = false;     // xfr_engine_set_inputs_ready: level-2 calls may read x_dev without waiting for the caller's stream
     int cur_slot = 0;
     long seq = 0;
     float* ws2 = nullptr;
@@ -349,6 +347,13 @@ xfr_status build(xfr_engine* e, const xfr_op_desc* ops, int n_ops)
         }
         if (t.nonneg && t.pstate == PS_RELU) t.pstate = PS_EQ;
     }
+    // an in-place ReLU overwrites its input: nothing else may read that tensor, before or after the ReLU in call order
+    for (int k = 0; k < n_ops; ++k) {
+        const xfr_op_desc& d = e->ops[k].d;
+        if (d.kind == XFR_OP_RELU && d.inplace && e->tens[d.in0].consumers.size() != 1)
+            return fail(XFR_UNSUPPORTED_LAYER, "op %d: in-place ReLU on tensor %d, which op %d also reads", k, d.in0,
+                        e->tens[d.in0].consumers[e->tens[d.in0].consumers[0] == k ? 1 : 0]);
+    }
     // hook table (registration order == call order)
     for (int k = 0; k < n_ops; ++k) {
         const xfr_op_desc& d = e->ops[k].d;
@@ -416,7 +421,7 @@ void compute_need(xfr_engine* e)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-xfr_status allocate(xfr_engine* e)
+xfr_status layout_workspace(xfr_engine* e)
 {
     const size_t B = (size_t)e->max_batch;
     for (auto& x : e->tens)
@@ -459,6 +464,14 @@ xfr_status allocate(xfr_engine* e)
     take(4096);   // slack: vector loads of a tile's dead columns may run past the last tensor
     e->ws_floats = off;
     e->idx_bytes = std::max<size_t>(idxb, 256);
+    return XFR_OK;
+}
+
+xfr_status allocate(xfr_engine* e)
+{
+    xfr_status st = layout_workspace(e);
+    if (st != XFR_OK) return st;
+    const size_t B = (size_t)e->max_batch;
     HIP_TRY(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
     HIP_TRY(hipMalloc(&e->idx_ws, e->idx_bytes));
     size_t hooks = 0;
@@ -470,7 +483,7 @@ xfr_status allocate(xfr_engine* e)
 }
 
 // parameter arena layout
-xfr_status layout_arena(xfr_engine* e)
+xfr_status layout_arena(xfr_engine* e, bool device = true)
 {
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return (long)o; };
@@ -495,7 +508,7 @@ xfr_status layout_arena(xfr_engine* e)
         }
     }
     e->arena_floats = std::max<size_t>(off, 64);
-    HIP_TRY(hipMalloc(&e->arena, e->arena_floats * sizeof(float)));
+    if (device) HIP_TRY(hipMalloc(&e->arena, e->arena_floats * sizeof(float)));
     return XFR_OK;
 }
 
@@ -503,17 +516,6 @@ xfr_status layout_arena(xfr_engine* e)
 xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
-    p.ksplit = 1;
-    if (e->use_splitk && p.kh * p.kw > 1) {      // only the deep-K KxK convolutions profit
-        const int which = (s == e->s_a && e->s_a) ? 1 : ((s == e->s_b && e->s_b) ? 2 : 0);
-        if (!e->splitk_buf[which]) {
-            e->splitk_bytes = (size_t)96 << 20;
-            HIP_TRY(hipMalloc(&e->splitk_buf[which], e->splitk_bytes));
-        }
-        p.splitk_ws = e->splitk_buf[which];
-        p.splitk_ws_bytes = e->splitk_bytes;
-        p.ksplit = 0;                           // heuristic
-    }
     p.tail_force = 1;
     if (e->tail_balance) {
         p.tail_force = 0;
@@ -645,7 +647,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
                 p.out1 = e->Pv(d.out);
                 p.nhalves = 2;
             } else p.nhalves = 1;
-            if (!want_pos && !e->no_fuse && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p);
+            if (!want_pos && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p);
             return run_conv(e, p, s);
         }
         case XFR_OP_BATCHNORM:
@@ -1082,16 +1084,6 @@ xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out, bool plain = 
     xfr_status st = make_plan(e, seed_tensor, e->plans.back(), plain);
     if (st != XFR_OK) { e->plans.pop_back(); return st; }
     if (!plain) fuse_plan(e, e->plans.back());
-    if (getenv("XFR_PLAN_DUMP")) {   // debug: the fused backward schedule, one line per launch
-        static const char* kn[] = {"EW", "CONV_BWD", "MAXPOOL_BWD", "AVGPOOL_BWD", "COPY", "MAXHALVES_BWD", "NORMALIZE_BWD", "ZERO"};
-        for (const BwdStep& st : (e->fuse_gemm_epilogue ? e->plans.back().fused_gemm : e->plans.back().fused)) {
-            const int tt = st.kind == ST_EW ? st.ew_t : st.dst_t;
-            fprintf(stderr, "plan %-13s src %3d dst %3d acc %d", kn[st.kind], st.src_t, st.dst_t, st.accumulate);
-            if (tt >= 0) fprintf(stderr, " [%d x %d x %d]", e->tens[tt].C, e->tens[tt].H, e->tens[tt].W);
-            for (const auto& sy : st.chain) fprintf(stderr, " (%d:%d t%d x%d)", sy.type, sy.action, sy.t0, sy.x_t);
-            fprintf(stderr, "\n");
-        }
-    }
     *out = &e->plans.back();
     return XFR_OK;
 }
@@ -1158,8 +1150,7 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
         e->last_trace_kinds = plan.firing_kinds;
     }
     const bool special = !e->rc_prior_sb.empty() || !e->rc_cap_idx.empty() || e->store_slot >= 0;
-    static const bool fuse_special = getenv("XFR_NO_FUSE_SPECIAL") == nullptr;
-    const bool use_fused = !e->trace_on && !e->no_fuse && !plan.fused.empty() && !plan.plain && (!special || fuse_special);
+    const bool use_fused = !e->trace_on && !plan.fused.empty() && !plan.plain;
     // Layerwise sweeps sorted by firing (rc_active): stream j is identically zero until the step that holds its prior
     // hook, so the GEMMs and hook chains before that step leave it out (the gradient region was zero-filled; the small
     // pool / copy kernels still run over all streams and move zeros).  SBa = streams alive at this step.
@@ -1283,8 +1274,7 @@ xfr_status prof_end(xfr_engine* e, hipStream_t s)
     if (!e->profile_on) return XFR_OK;
     HIP_TRY(hipStreamSynchronize(s));
     double ms = 0.0;
-    const char* dump = getenv("XFR_PROFILE_DUMP");   // debug: per-launch GEMM records appended as CSV
-    FILE* f = dump ? fopen(dump, "a") : nullptr;
+    FILE* f = e->profile_csv.empty() ? nullptr : fopen(e->profile_csv.c_str(), "a");   // per-launch GEMM records (xfr_engine_profile_csv)
     for (size_t i = 0; i < e->ev_used; ++i) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, e->ev_pool[i].first, e->ev_pool[i].second));
@@ -1328,6 +1318,12 @@ xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_te
     e->cur_slot = pipe ? (int)(e->seq++ & 1) : 0;
     const int slot = e->cur_slot;
     if (pipe && e->slot_pending[slot]) HIP_TRY(hipStreamWaitEvent(sf, e->ev_slot_done[slot], 0));
+    if (pipe && !e->inputs_ready) {
+        // x_dev may still be pending on the caller's stream (a cast, a copy): order the internal forward after it.  Callers
+        // whose inputs are resident declare it with xfr_engine_set_inputs_ready and keep the cross-call overlap.
+        HIP_TRY(hipEventRecord(e->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(sf, e->ev_fork, 0));
+    }
     st = forward_all(e, x_dev, n, seed_tensor, true, sf);
     if (st != XFR_OK) { e->cur_slot = 0; return st; }
     if (pipe) {
@@ -1369,10 +1365,6 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     if (ops[0].kind != XFR_OP_CONV || ops[0].in0 != 0)
         return fail(XFR_UNSUPPORTED_LAYER, "the first layer must be a convolution on the input image");
     xfr_engine* e = new xfr_engine();
-    e->no_fuse = getenv("XFR_NO_FUSE") != nullptr;
-    e->fuse_gemm_epilogue = getenv("XFR_NO_FUSE_GEMM") == nullptr;
-    e->fuse_fwd_only = getenv("XFR_NO_ENC_FUSE") == nullptr;
-    e->use_splitk = getenv("XFR_SPLITK") != nullptr;
     e->device = device; e->max_batch = max_batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
     xfr_status st = build(e, ops, n_ops);
     if (st == XFR_OK) st = layout_arena(e);
@@ -1392,7 +1384,6 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->dbl_ws) (void)hipFree(e->dbl_ws);
     if (e->trunc_ws) (void)hipFree(e->trunc_ws);
     if (e->ws_enc) (void)hipFree(e->ws_enc);
-    for (int i = 0; i < 3; ++i) if (e->splitk_buf[i]) (void)hipFree(e->splitk_buf[i]);
     for (int i = 0; i < e->n_tail_ws; ++i) (void)hipFree(e->tail_ws[i].ws);
     if (e->ws2) (void)hipFree(e->ws2);
     if (e->cap_dev) (void)hipFree(e->cap_dev);
@@ -1653,6 +1644,8 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     const bool fork = !e->profile_on;
     const bool pipe = fork && e->pipeline;
     hipStream_t sa = fork ? e->s_a : s, sb = fork ? e->s_b : s;
+    // every exit path (errors included) leaves the engine on slot 0 / the main bank: the non-pipelined entry points assume it
+    struct SlotGuard { xfr_engine* e; ~SlotGuard() { e->cur_slot = 0; e->t_bank = nullptr; } } slot_guard{e};
     e->cur_slot = pipe ? (int)(e->seq++ & 1) : 0;
     const int slot = e->cur_slot;
     if (fork) {
@@ -1888,8 +1881,7 @@ xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n_sweeps
     e->rc_active.clear();
     bool ascending = n_sweeps > 1;
     for (int j = 1; j < n_sweeps; ++j) ascending = ascending && firing_host[j] > firing_host[j - 1];
-    static const bool no_prefix = getenv("XFR_NO_SWEEP_PREFIX") != nullptr;
-    if (ascending && !no_prefix && !e->trace_on) e->rc_active.assign(firing_host, firing_host + n_sweeps);
+    if (ascending && !e->trace_on) e->rc_active.assign(firing_host, firing_host + n_sweeps);
     // one forward for all sweeps (whitebox.py:581 runs ebp(img, 0*P0) again for every layer); zero seeds: all the
     // gradient enters through the priors
     st = forward_all(e, x_dev, 1, seed_tensor, true, s);
@@ -1935,6 +1927,25 @@ xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, in
     if (st != XFR_OK) return st;
     launch_cnhw_to_nchw(is_tap ? e->ws + e->tap_off : e->store_dev, out_dev, n, x.C, x.HW(), s);
     HIP_TRY(hipGetLastError());
+    return XFR_OK;
+}
+
+xfr_status xfr_firing_kinds(xfr_engine* e, int32_t seed_tensor, int32_t* kinds, int32_t capacity)
+{
+    if (!e || !kinds) return fail(XFR_INVALID_ARG, "null argument");
+    if (e->need_dirty) compute_need(e);
+    BwdPlan* plan = nullptr;
+    xfr_status st = get_plan(e, seed_tensor, &plan);
+    if (st != XFR_OK) return st;
+    if (capacity < plan->n_firings) return fail(XFR_INVALID_ARG, "need room for %d kinds", plan->n_firings);
+    for (int i = 0; i < plan->n_firings; ++i) kinds[i] = plan->firing_kinds[i];
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->inputs_ready = ready != 0;
     return XFR_OK;
 }
 
@@ -1996,40 +2007,17 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     p.K = K; p.M = nb * p.OH * p.OW; p.CoutTot = cout; p.nhalves = 1; p.ldw = ldw;
     p.relu_in = relu_in; p.out_H = p.OH; p.out_W = p.OW; p.out_stride = 1;
     p.in_bytes = (unsigned)((size_t)cin * nb * h * w * sizeof(float));
-    p.tap_major = tap ? 1 : 0; p.force_cfg = cfg % 100; p.ksplit = (cfg % 10000 >= 100) ? (cfg % 10000) / 100 : 1;
+    p.tap_major = tap ? 1 : 0; p.force_cfg = cfg % 100;
     float* tws = nullptr;
     HIP_TRY(hipMalloc(&tws, XFR_TAIL_WS_BYTES + XFR_TAIL_MAX_TILES * sizeof(unsigned)));
     p.tail_ws = tws; p.tail_ws_bytes = XFR_TAIL_WS_BYTES;
     p.tail_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tws) + XFR_TAIL_WS_BYTES);
     HIP_TRY(hipMemset(p.tail_cnt, 0, XFR_TAIL_MAX_TILES * sizeof(unsigned)));
     p.tail_force = cfg / 10000;          // 0 heuristic, 1 off, S >= 2 forced
-    float* skws = nullptr;
-    const size_t skbytes = (size_t)8 * cout * p.M * sizeof(float);
-    HIP_TRY(hipMalloc(&skws, skbytes));
-    p.splitk_ws = skws; p.splitk_ws_bytes = skbytes;
-    if (cfg % 10000 >= 9900) p.ksplit = 0;   // heuristic
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     launch_conv_gemm(p, 0);
-    if (const char* tsf = getenv("XFR_CONV_TS")) {     // tuning: per-workgroup phase timestamps of one launch -> csv
-        const size_t nblk = 8192;
-        unsigned long long* ts = nullptr;
-        HIP_TRY(hipMalloc(&ts, nblk * 5 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(ts, 0, nblk * 5 * sizeof(unsigned long long)));
-        ConvParams q = p;
-        q.dbg_ts = ts;
-        launch_conv_gemm(q, 0);
-        HIP_TRY(hipDeviceSynchronize());
-        std::vector<unsigned long long> h(nblk * 5);
-        HIP_TRY(hipMemcpy(h.data(), ts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(tsf, "a")) {
-            for (size_t i = 0; i < nblk && h[i * 5 + 3]; ++i)
-                fprintf(f, "%d,%d,%zu,%llu,%llu,%llu,%llu,%llu\n", K, p.M, i, h[i * 5], h[i * 5 + 1], h[i * 5 + 2], h[i * 5 + 3], h[i * 5 + 4]);
-            fclose(f);
-        }
-        (void)hipFree(ts);
-    }
     HIP_TRY(hipEventRecord(a, 0));
     for (int r = 0; r < reps; ++r) launch_conv_gemm(p, 0);
     HIP_TRY(hipEventRecord(b, 0));
@@ -2039,10 +2027,109 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     if (ms_out) *ms_out = ms / reps;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     (void)hipFree(wd);
-    (void)hipFree(skws);
     (void)hipFree(tws);
     if (bd) (void)hipFree(bd);
     HIP_TRY(hipGetLastError());
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_profile_csv(xfr_engine* e, const char* path)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->profile_csv = path ? path : "";
+    return XFR_OK;
+}
+
+xfr_status xfr_chain_epilogue_stats(int64_t* compiled_launches, int64_t* interpreted_launches, int32_t* n_signatures)
+{
+    long c = 0, i = 0;
+    conv_gemm_chain_launch_counts(&c, &i);
+    if (compiled_launches) *compiled_launches = c;
+    if (interpreted_launches) *interpreted_launches = i;
+    if (n_signatures) *n_signatures = conv_gemm_num_chain_sigs();
+    return XFR_OK;
+}
+
+// Device-free: builds the planner state of an engine (no HIP call, fake base addresses that are never dereferenced) and
+// writes the fused schedules as text.
+xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_weights, int32_t in_c, int32_t in_h, int32_t in_w,
+                             int32_t batch, int32_t subtree_mode, int32_t seed_tensor, char* buf, size_t capacity, size_t* needed)
+{
+    if (!ops || n_ops < 2 || in_c < 1 || in_h < 1 || in_w < 1 || batch < 1 || n_weights < 0)
+        return fail(XFR_INVALID_ARG, "xfr_plan_describe: bad arguments");
+    if (subtree_mode < 0 || subtree_mode > 3) return fail(XFR_INVALID_ARG, "Invalid subtree mode %d", subtree_mode);
+    if (ops[0].kind != XFR_OP_CONV || ops[0].in0 != 0)
+        return fail(XFR_UNSUPPORTED_LAYER, "the first layer must be a convolution on the input image");
+    xfr_engine* e = new xfr_engine();
+    struct Del { xfr_engine* e; ~Del() { delete e; } } del{e};
+    e->max_batch = batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
+    e->mode = subtree_mode;
+    xfr_status st = build(e, ops, n_ops);
+    if (st == XFR_OK) st = layout_arena(e, false);
+    if (st == XFR_OK) st = layout_workspace(e);
+    if (st != XFR_OK) return st;
+    if (seed_tensor < 2 || seed_tensor >= (int)e->tens.size()) return fail(XFR_INVALID_ARG, "bad seed tensor %d", seed_tensor);
+    e->ws = reinterpret_cast<float*>((uintptr_t)1 << 40);
+    e->arena = reinterpret_cast<float*>((uintptr_t)2 << 40);
+    compute_need(e);
+    BwdPlan* plan = nullptr;
+    st = get_plan(e, seed_tensor, &plan);
+    if (st != XFR_OK) return st;
+    std::string out;
+    char line[512];
+    auto emit_sig = [&](const EwChain& ch) {
+        uint16_t codes[XFR_MAX_EW_STEPS];
+        const int n = ew_chain_codes(ch, codes);
+        out += " SIG";
+        for (int i = 0; i < n; ++i) { snprintf(line, sizeof(line), " %04x", codes[i]); out += line; }
+        snprintf(line, sizeof(line), " compiled=%d", n > 0 ? conv_gemm_chain_sig(ch) : -1);
+        out += line;
+    };
+    snprintf(line, sizeof(line), "plan seed_tensor %d mode %d firings %d launches %zu (unfused %zu)\n", seed_tensor, subtree_mode,
+             plan->n_firings, plan->fused_gemm.size(), plan->steps.size());
+    out += line;
+    // forward-only runs (encode / the gallery of a triplet step): Conv -> BatchNorm [-> Add] [-> ReLU] epilogues
+    const int last_op = e->tens[seed_tensor].producer;
+    e->fwd_done.assign(e->ops.size(), 0);
+    e->fwd_last_op = last_op;
+    for (int k = 0; k <= last_op; ++k) {
+        const xfr_op_desc& d = e->ops[k].d;
+        if (e->fwd_done[k] || (d.kind != XFR_OP_CONV && d.kind != XFR_OP_LINEAR)) continue;
+        ConvParams p;
+        conv_geometry(e, k, batch, p);
+        p.out0 = e->T(d.out);
+        fuse_forward_only(e, k, batch, p);
+        if (p.chain.n == 0) continue;
+        EwLoads ld;
+        ew_plan_loads(p.chain, p.out0, ld);
+        snprintf(line, sizeof(line), "fwd CONV op %d [%d x %d x %d] K %d", k, e->tens[d.out].C, e->tens[d.out].H, e->tens[d.out].W, e->ops[k].K);
+        out += line;
+        emit_sig(p.chain);
+        out += "\n";
+    }
+    static const char* kn[] = {"EW", "CONV_BWD", "MAXPOOL_BWD", "AVGPOOL_BWD", "COPY", "MAXHALVES_BWD", "NORMALIZE_BWD", "ZERO"};
+    for (const BwdStep& b : plan->fused_gemm) {
+        const int tt = b.kind == ST_EW ? b.ew_t : b.dst_t;
+        snprintf(line, sizeof(line), "bwd %s src %d dst %d acc %d", kn[b.kind], b.src_t, b.dst_t, b.accumulate);
+        out += line;
+        if (tt >= 0) { snprintf(line, sizeof(line), " [%d x %d x %d]", e->tens[tt].C, e->tens[tt].H, e->tens[tt].W); out += line; }
+        if (b.kind == ST_CONV_BWD) { snprintf(line, sizeof(line), " K %d", e->ops[b.op].Kb); out += line; }
+        if (!b.chain.empty()) {
+            EwChain ch;
+            EwLoads ld;
+            resolve_chain(e, b.chain, ch, nullptr, 2 * batch);
+            ew_plan_loads(ch, e->G(b.dst_t), ld);
+            if (b.kind == ST_CONV_BWD) emit_sig(ch);
+            else { snprintf(line, sizeof(line), " steps %d", ch.n); out += line; }
+        }
+        out += "\n";
+    }
+    if (needed) *needed = out.size() + 1;
+    if (buf && capacity > 0) {
+        const size_t n = std::min(out.size(), capacity - 1);
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
     return XFR_OK;
 }
 

@@ -129,5 +129,18 @@ class Program(object):
             arr[i] = o
         return arr
 
+    def describe(self, mode, seed_tensor, batch=32):
+        """The planner's fused schedules for this program as text (xfr_plan_describe: no device needed)."""
+        from . import _lib
+        from .engine import MODES
+        lib = _lib.load()
+        c, h, w = self.in_shape
+        need = ctypes.c_size_t()
+        args = (self.op_array(), len(self.ops), len(self.weight_names), c, h, w, int(batch), MODES[mode], int(seed_tensor))
+        _lib.check(lib.xfr_plan_describe(*args, None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        _lib.check(lib.xfr_plan_describe(*args, buf, need.value, None))
+        return buf.value.decode()
+
     def hooked_kinds(self):
         return [OpKind(o.kind) for o in self.ops if o.kind < OpKind.G_ADD]
