@@ -579,7 +579,7 @@ class OracleWhitebox(object):
 
     def weighted_subtree_ebp(self, x, k_poschannel, k_negchannel, topk=1, do_max_subtree=False,
                              do_mated_similarity_gating=True, subtree_mode='norelu', do_mwp_to_saliency=True):
-        """whitebox.py:647-737 (ebp_ver 6 branches)."""
+        """whitebox.py:647-737."""
         self.mode = subtree_mode
         tape, out = self._run(x, 'classify')
         C = tape.T[out].shape[1]
@@ -614,7 +614,10 @@ class OracleWhitebox(object):
         P_subtree_valid_norm = sn if not np.sum(sn) == 0 else np.ones_like(P_subtree_valid)
         stack = np.dstack([float(w) * np.array(P) * (1.0 / (np.max(P) + 1E-12)) for (w, P) in zip(P_subtree_valid_norm, P_img_valid)])
         smap = np.max(stack, axis=2) if do_max_subtree else np.sum(stack, axis=2)
-        smap /= max(smap.sum(), self.eps)
-        return (mwp_to_saliency(smap, self.eps) if do_mwp_to_saliency else smap,
-                [mwp_to_saliency(P, self.eps) if do_mwp_to_saliency else P for P in P_img_valid],
+        if self.ebp_ver != 6:                                # whitebox.py:726-727 (convert_saliency_uint8)
+            smap = np.uint8(255 * ((smap - np.min(smap)) / (self.eps + (np.max(smap) - np.min(smap)))))
+        else:
+            smap /= max(smap.sum(), self.eps)
+        return (self._sal(smap) if do_mwp_to_saliency else smap,
+                [self._sal(P) if do_mwp_to_saliency else P for P in P_img_valid],
                 P_subtree_valid, k_subtree_valid)

@@ -38,14 +38,7 @@ torch.set_num_threads(int(os.environ.get('XFR_THREADS', '8')))
 CPU = torch.device('cpu')
 
 
-def c2_images():
-    """(im_mates, im_nonmates, probe_im) of the C2 fixtures: 3 mates, 3 non-mates, one probe."""
-    j = GC.jpegs()
-    J = [j[f] for f in GC.JPEGS]                       # demo_face, probe, non-mate, mate
-    f64 = lambda a: a.astype(float) / 255              # noqa: E731   image_loader's file branch (xfr/utils.py:88-90)
-    im_mates = [f64(J[3]), f64(J[3][:, ::-1].copy()), J[1][:, ::-1].copy()]          # last one stays uint8
-    im_nonmates = [f64(J[2]), f64(J[2][:, ::-1].copy()), J[0].copy()]
-    return im_mates, im_nonmates, J[1].copy()
+c2_images = GC.c2_images
 
 
 def spy_encodings(wb, store, key):

@@ -42,6 +42,18 @@ def net_inputs(arch):
     return tuple(conv(j[f]) for f in JPEGS)
 
 
+def c2_images():
+    """(im_mates, im_nonmates, probe_im) of the C2 fixtures (tests/golden/make_golden_c2.py): three mates, three non-mates
+    and a probe built from the bundled JPEGs, as image_loader would hand them over (float64 RGB in [0, 1], xfr/utils.py:88-90)
+    or as uint8."""
+    j = jpegs()
+    J = [j[f] for f in JPEGS]                          # demo_face, probe, non-mate, mate
+    f64 = lambda a: a.astype(float) / 255              # noqa: E731
+    im_mates = [f64(J[3]), f64(J[3][:, ::-1].copy()), J[1][:, ::-1].copy()]
+    im_nonmates = [f64(J[2]), f64(J[2][:, ::-1].copy()), J[0].copy()]
+    return im_mates, im_nonmates, J[1].copy()
+
+
 class Subject(object):
     """Uniform handle: `wb` has ebp / contrastive_ebp / truncated_contrastive_ebp; `enc` encodes; `set_cls` installs the
     triplet classifier; `trace()` returns (sums, names) of the last ebp sweep or None.

@@ -34,6 +34,8 @@ class Engine(object):
                                               self.max_batch, self.device.index, ctypes.byref(self._h)))
         self._mode = None
         self.loaded_version = None
+        self._pipeline = 0
+        self.options = {}          # engine-level switches set through this handle (re-applied when a wrapper rebuilds the engine)
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
@@ -98,14 +100,25 @@ class Engine(object):
 
     # ------------------------------------------------------------------------------------------------
     def _prep(self, x):
+        """-> (device tensor, fresh).  fresh: the tensor was produced here (host-to-device copy, cast, .contiguous()), i.e. it
+        is still pending on the current stream; such an input must never be declared inputs_ready to the engine, whose
+        pipelined forwards run on internal streams that do not wait for the caller's stream."""
         if x.dim() != 4 or tuple(x.shape[1:]) != tuple(self.program.in_shape):
             raise ValueError('expected input N x %s, got %s' % (self.program.in_shape, tuple(x.shape)))
         if x.shape[0] > self.max_batch:
             raise ValueError('batch %d exceeds the engine max_batch %d' % (x.shape[0], self.max_batch))
-        return x.detach().to(self.device, torch.float32).contiguous()
+        y = x.detach().to(self.device, torch.float32).contiguous()
+        fresh = (not x.is_cuda) or y.data_ptr() != x.data_ptr()
+        return y, fresh
+
+    def _declare_ready(self, ready):
+        """Pipeline level 2: tell the engine whether the next ebp / contrastive call may read x without waiting for the
+        caller's stream (xfr_engine_set_inputs_ready)."""
+        if self._pipeline >= 2:
+            _lib.check(self.lib.xfr_engine_set_inputs_ready(self._h, 1 if ready else 0))
 
     def forward(self, x, tensor_id):
-        x = self._prep(x)
+        x, _ = self._prep(x)
         c, h, w = self.tensor_shape(tensor_id)
         out = torch.empty((x.shape[0], c, h, w), device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
@@ -113,9 +126,11 @@ class Engine(object):
                                             _stream_ptr(self.device)))
         return out
 
-    def ebp(self, x, seed_tensor, seed, want_mwp=False, want_pooled=True):
-        """seed: S x N x D.  Returns (mwp S x N x C1 x H1 x W1 or None, pooled S x N x H1 x W1 or None)."""
-        x = self._prep(x)
+    def ebp(self, x, seed_tensor, seed, want_mwp=False, want_pooled=True, inputs_ready=False):
+        """seed: S x N x D.  Returns (mwp S x N x C1 x H1 x W1 or None, pooled S x N x H1 x W1 or None).
+        inputs_ready (pipeline level 2 only): x is resident and valid on the device, see set_pipeline."""
+        x, fresh = self._prep(x)
+        self._declare_ready(inputs_ready and not fresh)
         n = x.shape[0]
         seed = seed.detach().to(self.device, torch.float32).contiguous()
         S = seed.shape[0]
@@ -131,10 +146,11 @@ class Engine(object):
                                         pooled.data_ptr() if want_pooled else None, _stream_ptr(self.device)))
         return mwp, pooled
 
-    def contrastive(self, x, seed_tensor, seed, percentile=None, raw=False):
+    def contrastive(self, x, seed_tensor, seed, percentile=None, raw=False, inputs_ready=False):
         """seed: 2 x N x D (mate, non-mate).  Returns N x H1 x W1 saliency maps (raw=True: the contrastive MWP before
         _mwp_to_saliency)."""
-        x = self._prep(x)
+        x, fresh = self._prep(x)
+        self._declare_ready(inputs_ready and not fresh)
         n = x.shape[0]
         seed = seed.detach().to(self.device, torch.float32).contiguous()
         d = int(np.prod(self.tensor_shape(seed_tensor)))
@@ -152,9 +168,12 @@ class Engine(object):
         """probes N x C x H x W, gallery 2N x C x H x W (mates then non-mates) -> N x H1 x W1 saliency maps.
         inputs_ready=True: both tensors are already valid on the device (not pending on the current stream) and will not be
         modified or freed until the result has been consumed -- required for cross-call pipelining (set_pipeline)."""
-        probes = self._prep(probes)
+        probes, fresh = self._prep(probes)
         n = probes.shape[0]
+        g_in = gallery
         gallery = gallery.detach().to(self.device, torch.float32).contiguous()
+        if fresh or (not g_in.is_cuda) or gallery.data_ptr() != g_in.data_ptr():
+            inputs_ready = False          # a copy made here is still pending on the current stream
         if tuple(gallery.shape) != (2 * n,) + tuple(self.program.in_shape):
             raise ValueError('gallery must be %d x %s, got %s' % (2 * n, self.program.in_shape, tuple(gallery.shape)))
         c1, h1, w1 = self.tensor_shape(1)
@@ -169,10 +188,13 @@ class Engine(object):
     def set_pipeline(self, on):
         """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
         _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call
+        self._pipeline = int(on)
+        self.options['pipeline'] = int(on)
 
     def set_epilogue_fusion(self, on):
         """Hook chains / BatchNorm+add+ReLU inside the GEMM epilogue (default on) or as their own launches."""
         _lib.check(self.lib.xfr_engine_set_epilogue_fusion(self._h, int(bool(on))))
+        self.options['epilogue_fusion'] = bool(on)
 
     def hold_forward(self, on):
         """Consecutive calls on the same input tensor share one forward pass while held (include/xfr_amd.h)."""
@@ -181,6 +203,16 @@ class Engine(object):
     def set_tail_balance(self, on):
         """GEMM tail balancing (default on); off = batch-invariant fp32 arithmetic (include/xfr_amd.h)."""
         _lib.check(self.lib.xfr_engine_set_tail_balance(self._h, int(bool(on))))
+        self.options['tail_balance'] = bool(on)
+
+    def apply_options(self, options):
+        """Re-apply switches recorded by another Engine handle (WhiteboxNetwork.engine rebuilds engines that are too small)."""
+        if 'tail_balance' in options:
+            self.set_tail_balance(options['tail_balance'])
+        if 'epilogue_fusion' in options:
+            self.set_epilogue_fusion(options['epilogue_fusion'])
+        if options.get('pipeline'):
+            self.set_pipeline(options['pipeline'])
 
     def mwp_to_saliency(self, pooled):
         pooled = pooled.detach().to(self.device, torch.float32).contiguous()
@@ -197,9 +229,16 @@ class Engine(object):
         _lib.check(self.lib.xfr_firing_count(self._h, int(seed_tensor), ctypes.byref(n)))
         return n.value
 
+    def firing_names(self, seed_tensor):
+        """Class names of the hooked modules in firing order (Whitebox.P_layername without the argument lists)."""
+        nf = self.firing_count(seed_tensor)
+        kinds = (ctypes.c_int32 * max(nf, 1))()
+        _lib.check(self.lib.xfr_firing_kinds(self._h, int(seed_tensor), kinds, nf))
+        return [LAYER_NAMES[OpKind(k)] for k in list(kinds)[:nf]]
+
     def subtree_weights(self, x, seed_tensor, seed, gate_ge0=True):
         """seed 2 x N x D -> (w [n_firings, N] float32, idx [n_firings, N] int32)."""
-        x = self._prep(x)
+        x, _ = self._prep(x)
         n = x.shape[0]
         seed = seed.detach().to(self.device, torch.float32).contiguous()
         nf = self.firing_count(seed_tensor)
@@ -212,7 +251,7 @@ class Engine(object):
 
     def ebp_capture(self, x, seed_tensor, seed, elems):
         """One image, seed 1 x 1 x D; elems[k] = flattened (c,h,w) element of firing k -> P[k].flatten()[elems[k]]."""
-        x = self._prep(x)
+        x, _ = self._prep(x)
         seed = seed.detach().to(self.device, torch.float32).contiguous()
         nf = self.firing_count(seed_tensor)
         el = (ctypes.c_int32 * nf)(*[int(v) for v in elems])
@@ -225,7 +264,7 @@ class Engine(object):
     def layerwise(self, x, seed_tensor, firings, elems=None, vals=None, dense_prior=None):
         """Batch of layerwise sweeps of one image -> J x H1 x W1 pooled P[-2] (in the order of `firings`).  The sweeps are
         handed to the engine in ascending firing order: each then joins the backward pass at its own firing."""
-        x = self._prep(x)
+        x, _ = self._prep(x)
         J = len(firings)
         order = sorted(range(J), key=lambda j: int(firings[j]))
         if order != list(range(J)) and dense_prior is None:
@@ -249,7 +288,7 @@ class Engine(object):
 
     def ebp_firing(self, x, seed_tensor, seed, firing):
         """Whitebox.P[firing] of a standard sweep: N x C x H x W."""
-        x = self._prep(x)
+        x, _ = self._prep(x)
         n = x.shape[0]
         seed = seed.detach().to(self.device, torch.float32).contiguous()
         c, h, w = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()

@@ -11,6 +11,8 @@ Not provided (outside the hot path): layerwise_contrastive_ebp (d
 whitebox.py:587-588), Whitebox_senet50_256 (unsupported by the reference itself:
 whitebox.py:402-403), DataFrame / image_loader inputs of `embeddings`.
 """
+import warnings
+
 import numpy as np
 import PIL
 import PIL.Image
@@ -51,10 +53,16 @@ class WhiteboxNetwork(object):
         want = max(int(min_batch), self.default_max_batch)
         key = (str(dev), id(self.net))
         if self._engine is None or self._engine_key != key or self._engine.max_batch < min_batch:
+            options = {}
             if self._engine is not None:
+                if self._engine_key == key:
+                    options = dict(self._engine.options)     # set_pipeline / set_tail_balance / set_epilogue_fusion survive
+                    warnings.warn('xfr_amd: rebuilding the engine for batch %d (it was sized for %d): the weights are packed and '
+                                  'uploaded again; size it once with default_max_batch' % (want, self._engine.max_batch))
                 self._engine.close()
             self._program = self.net.build_program()
             self._engine = Engine(self._program, want, dev)
+            self._engine.apply_options(options)
             self._engine_key = key
         if self._engine.loaded_version != self.net.version:
             self._engine.load_weights(self.net.state_dict())
@@ -187,20 +195,31 @@ class Whitebox_resnet50_128(WhiteboxNetwork):
 
 
 class _PList(object):
-    """`Whitebox.P` (whitebox.py:294,394): the reference keeps all MWP tensors of the last sweep; the engine keeps
-    the one the callers use, P[-2] (MWP at the first convolution's output, whitebox.py:499,524)."""
+    """`Whitebox.P` (whitebox.py:294,394): the MWP tensors of the last sweep in firing order.  The reference clones every one
+    of them on every sweep; the engine keeps P[-2] (the only entry its callers read, whitebox.py:499,524) and recomputes any
+    other entry on demand with one more sweep that stores that firing (xfr_ebp_store_firing).  len(P) counts the image hook
+    P[-1] like the reference does; its tensor needs the first layer's backward-data pass, which the engine does not run."""
 
-    def __init__(self, p_minus2, n_firings):
-        self._p2 = p_minus2
-        self._n = n_firings
+    def __init__(self, wb, x, seed_tensor, seed, p_minus2, n_firings):
+        self._wb, self._x, self._seed_tensor, self._seed = wb, x, seed_tensor, seed
+        self._cache = {n_firings - 1: p_minus2}
+        self._n = n_firings + 1
 
     def __len__(self):
         return self._n
 
     def __getitem__(self, i):
-        if i == -2 or (self._n and i == self._n - 2):
-            return self._p2
-        raise IndexError('xfr_amd keeps only P[-2] of the MWP sweep (enable the engine trace for per-layer sums)')
+        k = int(i)
+        if k < 0:
+            k += self._n
+        if not (0 <= k < self._n):
+            raise IndexError('P index %d out of range (%d entries)' % (i, self._n))
+        if k == self._n - 1:
+            raise IndexError('xfr_amd does not compute P[-1] (the MWP at the image): nothing on the path reads it')
+        if k not in self._cache:
+            eng = self._wb._engine(self._x.shape[0])
+            self._cache[k] = eng.ebp_firing(self._x, self._seed_tensor, self._seed, k)
+        return self._cache[k]
 
 
 class Whitebox(object):
@@ -289,12 +308,13 @@ class Whitebox(object):
         if self.debug_trace:
             eng.set_trace(True)
         mwp_full, pooled = eng.ebp(x, seed_tensor, seed.unsqueeze(0), want_mwp=True, want_pooled=True)
+        self.P_layername = eng.firing_names(seed_tensor)         # whitebox.py:393 (class names; the image hook has no entry here)
         if self.debug_trace:
             sums, names, nf = eng.get_trace()
-            self.P_layername = names
+            assert names == self.P_layername
             self.P_trace = sums[:nf * n].reshape(nf, n).copy()
             eng.set_trace(False)
-        self.P = _PList(mwp_full[0], len(self.P_layername) + 1 if self.P_layername else 0)
+        self.P = _PList(self, x, seed_tensor, seed.unsqueeze(0), mwp_full[0], len(self.P_layername))
         P = np.squeeze(pooled[0].cpu().numpy()).astype(np.float32)
         return self._mwp_to_saliency(P) if not mwp else P
 
@@ -371,8 +391,16 @@ class Whitebox(object):
         P0[0][k_poschannel] = 1.0
         seed_tensor, seed = self.net.seed_for(P0, 1)
         nf = eng.firing_count(seed_tensor)
-        if not (0 <= int(k_layer) < nf):
-            raise IndexError('k_layer %d outside the %d computed firings' % (k_layer, nf))
+        k_layer = int(k_layer)
+        if k_layer < 0:
+            k_layer += nf + 1                                      # Python indexing into P, which has nf + 1 entries (:570)
+        if not (0 <= k_layer <= nf):
+            raise IndexError('list index out of range')
+        if k_layer == nf:
+            # the image hook fires after P[-2] has been recorded: with a zero seed nothing reaches P[-2] (:581 -> :499)
+            c1, h1, w1 = eng.tensor_shape(1)
+            P = np.zeros((h1, w1), dtype=np.float32)
+            return self._mwp_to_saliency(P) if not mwp else P
         if mode == 'argmax':
             Pk = eng.ebp_firing(img_probe, seed_tensor, seed.unsqueeze(0), int(k_layer))
             prior = Pk * (1.0 - torch.ne(Pk, torch.max(Pk)).float())          # whitebox.py:572
@@ -410,7 +438,7 @@ class Whitebox(object):
             g = torch.softmax(y, dim=1)
             g[0, 0] -= 1.0                                                      # d cross_entropy(y,[0])/dy  (:657,:664)
             _, s0 = self.net.seed_for(g, 1)
-        img_probe = eng._prep(img_probe)                                       # one device tensor for all phases
+        img_probe, _ = eng._prep(img_probe)                                    # one device tensor for all phases
         eng.hold_forward(True)                                                  # ... which share its forward pass
         try:
             return self._weighted_subtree_held(eng, img_probe, seed_tensor, s0, s1, k_poschannel, topk, verbose, do_max_subtree,
@@ -489,3 +517,17 @@ class Whitebox(object):
             embeds = (embeds.reshape((embeds.shape[0], -1)) /
                       np.linalg.norm(embeds.reshape((embeds.shape[0], -1)), axis=1, keepdims=True)).reshape(embeds.shape)
         return embeds
+
+    def convert_from_numpy(self, img):
+        """whitebox.py:787-806: float RGB image (H x W x 3, range 0..1 or 0..255) or uint8 image -> network input tensor.
+        Where the reference drops into pdb for out-of-range data (:797-800) this raises ValueError."""
+        from ..saliency_io import resize_linear
+        if img.dtype == np.uint8:
+            img = img.astype(np.float32) / 255
+        if img.max() > 1 + 1e-6 and img.min() > 0 - 1e-6:
+            img = img / 255
+        if img.max() > 1 + 1e-6 or img.min() < 0 - 1e-6:
+            raise ValueError('convert_from_numpy: image values outside [0, 1] / [0, 255]')
+        img = resize_linear(img, (224, 224))
+        img = (img * 255).astype(np.uint8)
+        return self.net.preprocess(PIL.Image.fromarray(img).convert('RGB'))

@@ -20,7 +20,7 @@ import os
 import numpy as np
 import scipy.ndimage as ndi
 
-__all__ = ['processSaliency', 'blend_saliency_map', 'create_save_smap', 'load_smap', 'shorten_subtree_mode', 'method_name',
+__all__ = ['processSaliency', 'resize_linear', 'blend_saliency_map', 'create_save_smap', 'load_smap', 'shorten_subtree_mode', 'method_name',
            'saliency_paths', 'jet']
 
 
@@ -43,6 +43,32 @@ def _resize_cubic(img, out_shape):
         out = fixed
     lo, hi = min(img.min(), 0.0), max(img.max(), 0.0)        # clip=True with mode='constant', cval=0
     return np.clip(out, lo, hi)
+
+
+def resize_linear(img, out_shape):
+    """skimage.transform.resize(img, out_shape, preserve_range=True) as Whitebox.convert_from_numpy calls it
+    (whitebox.py:802: order 1, mode 'reflect', anti_aliasing on).  Same spatial size: the identity, in every skimage version
+    (zoom factor 1 = no pre-filter and interpolation at integer coordinates) -- the case the golden fixtures pin.  Other sizes
+    restate skimage >= 0.19 (`scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True)` after a gaussian pre-filter of
+    sigma (f - 1) / 2 when shrinking) and are parity-unpinned like _resize_cubic."""
+    out_shape = tuple(int(v) for v in out_shape[:2])
+    if tuple(img.shape[:2]) == out_shape:
+        return img if img.dtype.char in 'df' else img.astype(float)
+    src = np.asarray(img, dtype=np.float64)
+    factors = np.divide(src.shape[:2], out_shape)
+    chans = src[..., None] if src.ndim == 2 else src
+    outs = []
+    for c in range(chans.shape[2]):
+        a = chans[..., c]
+        if np.any(factors > 1):
+            a = ndi.gaussian_filter(a, np.maximum(0, (factors - 1) / 2), mode='mirror')
+        z = ndi.zoom(a, 1.0 / factors, order=1, mode='mirror', grid_mode=True)
+        fixed = np.zeros(out_shape, dtype=z.dtype)
+        h, w = min(z.shape[0], out_shape[0]), min(z.shape[1], out_shape[1])
+        fixed[:h, :w] = z[:h, :w]
+        outs.append(np.clip(fixed, src.min(), src.max()))
+    out = np.stack(outs, axis=2)
+    return out[..., 0] if src.ndim == 2 else out
 
 
 def processSaliency(img, attMap):
