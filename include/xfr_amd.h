@@ -36,7 +36,8 @@ typedef enum {
     XFR_UNSUPPORTED_LAYER = 2,  /* -> ValueError (whitebox.py:403 Sigmoid/ELU/Tanh, unknown kinds) */
     XFR_OOM = 3,
     XFR_HIP_ERROR = 4,
-    XFR_STATE_ERROR = 5         /* e.g. weights not loaded */
+    XFR_STATE_ERROR = 5,        /* e.g. weights not loaded */
+    XFR_RCCL_ERROR = 6          /* librccl missing, or a collective failed */
 } xfr_status;
 
 /* Layer program op kinds.  "Hooked" kinds are leaf nn.Module calls of the reference (they receive the
@@ -126,6 +127,22 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* weights
  * engine that never called xfr_engine_load_weights, call xfr_engine_mark_weights_loaded. */
 xfr_status xfr_engine_weight_arena(xfr_engine* e, void** dev_ptr, size_t* bytes);
 xfr_status xfr_engine_mark_weights_loaded(xfr_engine* e);
+
+/* Multi-GPU for hosts that are not Python (the Python mirror uses torch.distributed for the same broadcast): one process
+ * per GPU, one RCCL communicator, ONE collective -- the broadcast of the packed parameter arena from `root`, which replaces
+ * the per-job torch.load of the 298 MB checkpoint in every worker (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:74,
+ * 193-216).  The steady state has no exchange: triplets are independent.
+ *   xfr_comm_unique_id   rank 0 fills 128 bytes (an ncclUniqueId) and hands them to the other ranks by any out-of-band means
+ *   xfr_comm_init        collective over all `world` ranks; `device` is this rank's HIP device
+ *   xfr_broadcast_weights  collective; the root must have called xfr_engine_load_weights, the others need not: their engines
+ *                        are marked loaded on return.  Synchronises `stream`.
+ * librccl is bound on first use; without it these four calls fail with XFR_RCCL_ERROR and nothing else is affected. */
+#define XFR_COMM_ID_BYTES 128
+typedef struct xfr_comm xfr_comm;
+xfr_status xfr_comm_unique_id(void* id_out);
+xfr_status xfr_comm_init(int32_t rank, int32_t world, const void* unique_id, int32_t device, xfr_comm** out);
+xfr_status xfr_broadcast_weights(xfr_engine* e, xfr_comm* comm, int32_t root, void* stream);
+xfr_status xfr_comm_destroy(xfr_comm* comm);
 
 /* Whitebox(..., with_bias, eps, ebp_subtree_mode) -- whitebox.py:262-304. */
 xfr_status xfr_engine_set_mode(xfr_engine* e, int32_t subtree_mode, float eps, int32_t with_bias);

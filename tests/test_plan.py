@@ -1,0 +1,105 @@
+"""Host logic of the engine that needs no GPU: the planner (xfr_plan_describe) on the three backbones, and the compiled-epilogue
+signature table (xfr_amd/csrc/chain_sigs.inc) against it."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from xfr_amd import _lib
+from xfr_amd.models import lightcnn, resnet, resnet50_128
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODES = ('affineonly', 'affineonly_with_prior', 'norelu', 'all')
+
+
+def _programs():
+    return {'stresnet101': resnet.ResNet([3, 4, 23, 3], num_classes=65359).build_program(),
+            'stresnet_mini': resnet.ResNet([1, 1, 1, 1], num_classes=5).build_program(),
+            'resnet50_128': resnet50_128.Resnet50_128().build_program(),
+            'lightcnn29v2': lightcnn.LightCNN_29Layers_v2(num_classes=80013).build_program()}
+
+
+PROGRAMS = _programs()
+
+
+@pytest.mark.parametrize('arch', sorted(PROGRAMS))
+def test_every_fused_chain_has_a_compiled_epilogue(arch):
+    """Every elementwise chain the planner fuses behind a GEMM -- all four subtree modes, hooked and triplet seed -- is in the
+    committed signature table, i.e. no launch of the three BASELINE backbones falls back to the interpreted epilogue."""
+    prog = PROGRAMS[arch]
+    n_sig = 0
+    for mode in MODES:
+        for mark in ('encode', 'classify'):
+            if mark not in prog.marks:
+                continue
+            text = prog.describe(mode, prog.marks[mark])
+            sig_lines = [ln for ln in text.splitlines() if ' SIG ' in ln]
+            missing = [ln for ln in sig_lines if ln.endswith('compiled=-1')]
+            assert not missing, '%s/%s/%s: run tools/gen_chain_sigs.py and rebuild\n%s' % (arch, mode, mark, '\n'.join(missing[:5]))
+            n_sig += len(sig_lines)
+    assert n_sig > 0
+
+
+def test_signature_table_is_what_the_generator_produces(tmp_path):
+    """chain_sigs.inc is generated: regenerating it from the current planner gives the committed file."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import gen_chain_sigs as G
+    committed = open(G.OUT).read()
+    old = G.OUT
+    try:
+        G.OUT = str(tmp_path / 'chain_sigs.inc')
+        G.main()
+        assert open(G.OUT).read() == committed
+    finally:
+        G.OUT = old
+
+
+def test_plan_shapes_resnet101():
+    """Firing count and schedule size of the ResNet-101 triplet sweep (378 entries of Whitebox.P, the image hook
+    is not computed); fusion brings the 321 backward launches of the literal schedule down to 135."""
+    prog = PROGRAMS['stresnet101']
+    text = prog.describe('affineonly_with_prior', prog.marks['encode'])
+    m = re.match(r'plan seed_tensor (\d+) mode 1 firings (\d+) launches (\d+) \(unfused (\d+)\)', text)
+    assert m and int(m.group(2)) == 377
+    assert int(m.group(3)) < int(m.group(4)) // 2
+    assert sum(ln.startswith('fwd CONV') for ln in text.splitlines()) == 100          # every convolution takes its BatchNorm (the fc has none)
+    assert sum(ln.startswith('bwd CONV_BWD') for ln in text.splitlines()) == 100       # 100 convs + fc, minus the first layer's backward-data GEMM
+
+
+def test_plan_describe_argument_checks():
+    lib = _lib.load()
+    prog = PROGRAMS['stresnet_mini']
+    need = ctypes.c_size_t()
+    ops = prog.op_array()
+    assert lib.xfr_plan_describe(None, 0, 0, 3, 224, 224, 1, 1, 5, None, 0, ctypes.byref(need)) == _lib.XFR_INVALID_ARG
+    assert lib.xfr_plan_describe(ops, len(prog.ops), len(prog.weight_names), 3, 224, 224, 1, 9, 5, None, 0, ctypes.byref(need)) == _lib.XFR_INVALID_ARG
+    assert b'Invalid subtree mode' in lib.xfr_last_error()
+    assert lib.xfr_plan_describe(ops, len(prog.ops), len(prog.weight_names), 3, 224, 224, 1, 1, 10 ** 6, None, 0, ctypes.byref(need)) == _lib.XFR_INVALID_ARG
+    st = lib.xfr_plan_describe(ops, len(prog.ops), len(prog.weight_names), 3, 224, 224, 4, 1, prog.marks['encode'], None, 0, ctypes.byref(need))
+    assert st == _lib.XFR_OK and need.value > 100
+    buf = ctypes.create_string_buffer(32)          # truncation is safe and terminated
+    assert lib.xfr_plan_describe(ops, len(prog.ops), len(prog.weight_names), 3, 224, 224, 4, 1, prog.marks['encode'], buf, 32, None) == _lib.XFR_OK
+    assert len(buf.value) == 31
+
+
+def test_inplace_relu_with_second_reader_is_rejected():
+    """An in-place ReLU may not share its input with another consumer, whichever comes first in call order."""
+    from xfr_amd.program import Program
+    p = Program((3, 8, 8))
+    c = p.conv(0, 'c1', 4, 3, pad=1)
+    r = p.relu_(c)
+    p.add(r, c)                     # reads the pre-ReLU tensor AFTER the in-place ReLU overwrote it
+    need = ctypes.c_size_t()
+    st = _lib.load().xfr_plan_describe(p.op_array(), len(p.ops), len(p.weight_names), 3, 8, 8, 1, 1, 2, None, 0, ctypes.byref(need))
+    assert st == _lib.XFR_UNSUPPORTED_LAYER and b'in-place ReLU' in _lib.load().xfr_last_error()
+
+
+def test_comm_entry_points_check_arguments():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.xfr_comm_init(0, 0, None, 0, ctypes.byref(h)) == _lib.XFR_INVALID_ARG
+    assert lib.xfr_broadcast_weights(None, None, 0, None) == _lib.XFR_INVALID_ARG
+    assert lib.xfr_comm_destroy(None) == _lib.XFR_OK

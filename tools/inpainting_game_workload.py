@@ -32,11 +32,12 @@ def main():
                     help='write {mask_id}-{method}-saliency.npz + overlay PNG per job and method (show.py:196-232); '
                          'methods whose files exist are skipped unless --overwrite (the generator\'s resume)')
     ap.add_argument('--overwrite', action='store_true')
+    ap.add_argument('--numpy-inputs', action='store_true', help='uint8 H x W x 3 images through convert_from_numpy (PIL) per call, like the reference')
     args = ap.parse_args()
     import numpy as np
     import torch
     import torch.distributed as dist
-    from xfr_amd import saliency_io as SIO, shard, synth
+    from xfr_amd import inpainting_game as IG, saliency_io as SIO, shard, synth
     from xfr_amd.models import resnet, whitebox as WB
 
     rank, world, local = shard.init_process_group()
@@ -50,45 +51,46 @@ def main():
     wbn._program = bb.build_program()
     wbn._engine = Engine(wbn._program, 32, dev)
     wbn._engine_key = (str(bb.device), id(bb))
-    shard.load_and_broadcast(wbn._engine, lambda: synth.synth_state_dict(bb, seed=0), src=0)     # one load, one broadcast
+    packed = {'n': 0}
+
+    def make_sd():
+        packed['n'] += 1
+        return synth.synth_state_dict(bb, seed=0)
+    shard.load_and_broadcast(wbn._engine, make_sd, src=0)     # one load, one broadcast
     wbn._engine.loaded_version = bb.version
 
     lo, hi = shard.shard_range(args.jobs, rank, world)
     k = args.mates
     done, t_methods, written, probe_u8 = 0, np.zeros(4), 0, None
-    # synthetic stand-ins for the aligned IJB-C crops (git-LFS pointers in the reference): a small pool, generated up front
-    pool = [synth.synth_smooth_images(2 * k + 1, (3, 224, 224), seed=10000 + j, mean=resnet.MEAN_RGB).to(dev) for j in range(8)]
+    # synthetic stand-ins for the aligned IJB-C crops (git-LFS pointers in the reference): a small pool, generated up front.
+    # Default: device-resident network-format tensors (Whitebox.convert_from_numpy passes tensors through); --numpy-inputs hands
+    # the callers uint8 H x W x 3 arrays like the reference's image_loader does, so PIL preprocessing and the host-to-device
+    # copies are inside the timed loop.
+    pool = [synth.synth_smooth_images(2 * k + 1, (3, 224, 224), seed=10000 + j, mean=resnet.MEAN_RGB) for j in range(8)]
+    if args.numpy_inputs:
+        mean = np.asarray(resnet.MEAN_RGB, dtype=np.float32).reshape(1, 3, 1, 1)
+        pool = [np.clip(p.numpy() + mean, 0, 255).astype(np.uint8).transpose(0, 2, 3, 1) for p in pool]
+    else:
+        pool = [p.to(dev) for p in pool]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for job in range(lo, hi):
         imgs = pool[job % len(pool)]
-        probe, mates, nonmates = imgs[:1], imgs[1:1 + k], imgs[1 + k:]
-        state = {'cls': False}
-
-        def ensure_cls():
-            # run_contrastive_triplet_ebp (generate_whitebox_saliency.py:79-104): averaged, unit-normalised encodings / 2500
-            if not state['cls']:
-                x_m = wb.encode(mates).mean(dim=0, keepdim=True)
-                x_n = wb.encode(nonmates).mean(dim=0, keepdim=True)
-                wb.net.set_triplet_classifier((1.0 / 2500.0) * (x_m / x_m.norm()).cpu(), (1.0 / 2500.0) * (x_n / x_n.norm()).cpu())
-                state['cls'] = True
+        probe, mates, nonmates = imgs[0], list(imgs[1:1 + k]), list(imgs[1 + k:])
+        net_name, ver = 'resnetv4_pytorch', 6
 
         def f_mean():
-            wbn._classifier = None                              # the checkpoint's hooked 65359-way fc2 for meanEBP
-            state['cls'] = False
-            return wb.ebp(probe, torch.ones((1, args.num_classes)))
+            wbn._classifier = None                              # the checkpoint's hooked 65359-way fc2 (a fresh wb per job in the reference)
+            return IG.mean_ebp(wb, probe, net_name, ver, dev)
 
         def f_con():
-            ensure_cls()
-            return wb.contrastive_ebp(probe, 0, 1)
+            return IG.run_contrastive_triplet_ebp(wb, mates, nonmates, probe, net_name, ver, None, dev)
 
         def f_tru():
-            ensure_cls()
-            return wb.truncated_contrastive_ebp(probe, 0, 1, percentile=20)
+            return IG.run_contrastive_triplet_ebp(wb, mates, nonmates, probe, net_name, ver, 20, dev)
 
         def f_sub():
-            ensure_cls()
-            return wb.weighted_subtree_ebp(probe, 0, 1, topk=args.topk, verbose=False, subtree_mode='norelu')[0]
+            return IG.run_weighted_subtree_triplet_ebp(wb, mates, nonmates, probe, net_name, 'norelu', ver, dev, topk=args.topk)
 
         mode = wb.ebp_subtree_mode()
         methods = [(SIO.method_name('meanEBP', mode, 6, 'cuda'), f_mean),
@@ -103,7 +105,7 @@ def main():
                 return m
             if args.output_dir:
                 if probe_u8 is None:          # displayable stand-in for the aligned crop: min-max scaled to [0, 1]
-                    disp = probe[0].permute(1, 2, 0).cpu().numpy().astype(np.float64)
+                    disp = (probe.astype(np.float64) if args.numpy_inputs else probe.permute(1, 2, 0).cpu().numpy().astype(np.float64))
                     probe_u8 = (disp - disp.min()) / (disp.max() - disp.min() + 1e-9)
                 written += int(SIO.create_save_smap(name, os.path.join(args.output_dir, 'subject_ID_%d' % (job % len(pool))), args.overwrite,
                                                     checked, '%05d' % job, probe_u8))
@@ -124,6 +126,10 @@ def main():
         dt, total = float(tmax[0]), int(stats[1])
     else:
         total = done
+    if args.output_dir:        # what this rank did, for the multi-rank test: rank 0 alone packs the parameters
+        os.makedirs(args.output_dir, exist_ok=True)
+        with open(os.path.join(args.output_dir, 'rank%d.json' % rank), 'w') as f:
+            json.dump({'rank': rank, 'world': world, 'jobs': [lo, hi], 'packed_weights': bool(packed['n']), 'maps_written': written}, f)
     if rank == 0:
         per = (t_methods / max(done, 1) * 1e3).round(1).tolist()
         print(json.dumps({'workload': 'inpainting-game whitebox saliency generation shape, ResNet-101, synthetic', 'jobs': total,

@@ -7,7 +7,7 @@ from .program import OpDesc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libxfr_amd.so')
 
-XFR_OK, XFR_INVALID_ARG, XFR_UNSUPPORTED_LAYER, XFR_OOM, XFR_HIP_ERROR, XFR_STATE_ERROR = range(6)
+XFR_OK, XFR_INVALID_ARG, XFR_UNSUPPORTED_LAYER, XFR_OOM, XFR_HIP_ERROR, XFR_STATE_ERROR, XFR_RCCL_ERROR = range(7)
 ABI_VERSION = 2
 
 
@@ -33,6 +33,10 @@ SYMBOLS = [
     ('xfr_engine_load_weights', _I, [_P, ctypes.POINTER(TensorView), _I]),
     ('xfr_engine_weight_arena', _I, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_size_t)]),
     ('xfr_engine_mark_weights_loaded', _I, [_P]),
+    ('xfr_comm_unique_id', _I, [_P]),
+    ('xfr_comm_init', _I, [_I, _I, _P, _I, ctypes.POINTER(_P)]),
+    ('xfr_broadcast_weights', _I, [_P, _P, _I, _P]),
+    ('xfr_comm_destroy', _I, [_P]),
     ('xfr_engine_set_mode', _I, [_P, _I, _F, _I]),
     ('xfr_engine_tensor_shape', _I, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     ('xfr_forward', _I, [_P, _P, _I, _I, _P, _P]),

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -2030,6 +2031,101 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     (void)hipFree(tws);
     if (bd) (void)hipFree(bd);
     HIP_TRY(hipGetLastError());
+    return XFR_OK;
+}
+
+// ---- multi-GPU: RCCL behind the C ABI -----------------------------------------------------------
+// One process per GPU; the only collective of the path is the one-off broadcast of the packed parameter arena.  librccl is
+// bound at first use (dlopen), so the library loads -- and every other entry point works -- where RCCL is absent.
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, const void* /* ncclUniqueId by value: 128 bytes, passed in memory */, int) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+struct UniqueId { char b[128]; };     // layout of ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+Rccl g_rccl;
+
+xfr_status rccl_bind()
+{
+    if (g_rccl.h) return XFR_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(XFR_RCCL_ERROR, "cannot load librccl: %s", dlerror());
+    Rccl r;
+    r.h = h;
+    r.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(h, "ncclBroadcast"));
+    r.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.Broadcast || !r.CommDestroy || !r.GetErrorString)
+        return fail(XFR_RCCL_ERROR, "librccl lacks an expected symbol");
+    g_rccl = r;
+    return XFR_OK;
+}
+#define RCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        int _r = (expr);                                                                                        \
+        if (_r != 0) return fail(XFR_RCCL_ERROR, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));           \
+    } while (0)
+}  // namespace
+
+struct xfr_comm {
+    void* comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+xfr_status xfr_comm_unique_id(void* id_out)
+{
+    if (!id_out) return fail(XFR_INVALID_ARG, "null argument");
+    xfr_status st = rccl_bind();
+    if (st != XFR_OK) return st;
+    RCCL_TRY(g_rccl.GetUniqueId(id_out));
+    return XFR_OK;
+}
+
+xfr_status xfr_comm_init(int32_t rank, int32_t world, const void* unique_id, int32_t device, xfr_comm** out)
+{
+    if (!unique_id || !out || world < 1 || rank < 0 || rank >= world) return fail(XFR_INVALID_ARG, "xfr_comm_init: bad arguments");
+    xfr_status st = rccl_bind();
+    if (st != XFR_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    xfr_comm* c = new xfr_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    UniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    // ncclCommInitRank takes the 128-byte id BY VALUE; on x86-64 a struct of that size is passed in memory, which is what
+    // a function pointer declared with the same struct type produces
+    typedef int (*init_fn)(void**, int, UniqueId, int);
+    const int r = reinterpret_cast<init_fn>(reinterpret_cast<void*>(g_rccl.CommInitRank))(&c->comm, world, id, rank);
+    if (r != 0) { delete c; return fail(XFR_RCCL_ERROR, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+    *out = c;
+    return XFR_OK;
+}
+
+xfr_status xfr_broadcast_weights(xfr_engine* e, xfr_comm* c, int32_t root, void* stream)
+{
+    if (!e || !c) return fail(XFR_INVALID_ARG, "null argument");
+    if (root < 0 || root >= c->world) return fail(XFR_INVALID_ARG, "root %d outside [0, %d)", root, c->world);
+    if (c->rank == root && !e->weights_loaded) return fail(XFR_STATE_ERROR, "the root rank has no weights loaded");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t bytes = e->arena_floats * sizeof(float);
+    RCCL_TRY(g_rccl.Broadcast(e->arena, e->arena, bytes, /* ncclChar */ 0, root, c->comm, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    e->weights_loaded = true;
+    e->held_x = nullptr;
+    return XFR_OK;
+}
+
+xfr_status xfr_comm_destroy(xfr_comm* c)
+{
+    if (!c) return XFR_OK;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
     return XFR_OK;
 }
 

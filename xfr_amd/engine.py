@@ -319,6 +319,10 @@ class Engine(object):
     def set_profile(self, on):
         _lib.check(self.lib.xfr_engine_set_profile(self._h, 1 if on else 0))
 
+    def profile_csv(self, path):
+        """Append one CSV record per GEMM launch to `path` while profiling is on (None: stop)."""
+        _lib.check(self.lib.xfr_engine_profile_csv(self._h, path.encode() if path else None))
+
     def get_profile(self):
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
         _lib.check(self.lib.xfr_engine_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))

@@ -522,6 +522,8 @@ class Whitebox(object):
         """whitebox.py:787-806: float RGB image (H x W x 3, range 0..1 or 0..255) or uint8 image -> network input tensor.
         Where the reference drops into pdb for out-of-range data (:797-800) this raises ValueError."""
         from ..saliency_io import resize_linear
+        if isinstance(img, torch.Tensor):        # additive: a tensor is taken to be in network format already (1|N x C x U x V)
+            return img if img.dim() == 4 else img.unsqueeze(0)
         if img.dtype == np.uint8:
             img = img.astype(np.float32) / 255
         if img.max() > 1 + 1e-6 and img.min() > 0 - 1e-6:

@@ -102,6 +102,30 @@ def synth_smooth_images(n, shape, seed=1234, mean=None, scale255=True):
     return out
 
 
+def bench_images(batch, shape, seed=1234, mean=None):
+    """The 3*batch images of one bench.py step: [mates | non-mates | probes].  Smooth seeded images (see synth_smooth_images):
+    the maps the benchmark produces are then meaningful saliency maps, and sample 0 can be checked against the map the
+    reference computes for the same triplet (tests/golden/golden_bench.npz).  Only the first 3 images of each third are
+    generated one by one; the rest are seeded mixtures of those and of per-image noise -- distinct inputs at a fraction of the
+    generation cost (the benchmark's time does not depend on the pixel values)."""
+    base = synth_smooth_images(9, shape, seed=seed, mean=None)            # values in [0, 255]
+    g = torch.Generator().manual_seed(int(seed) + 7)
+    out = torch.empty((3 * batch,) + tuple(shape))
+    for third in range(3):
+        b3 = base[3 * third:3 * third + 3]
+        for i in range(batch):
+            if i < 3:
+                img = b3[i]
+            else:
+                w = torch.rand(3, generator=g)
+                w = w / w.sum()
+                img = torch.floor((w.view(3, 1, 1, 1) * b3).sum(dim=0) * 0.9 + 25.5 * torch.rand(tuple(shape), generator=g))
+            out[third * batch + i] = img
+    if mean is not None:
+        out = out - torch.tensor(mean, dtype=torch.float32).view(1, shape[0], 1, 1)
+    return out
+
+
 def unit_rows(n, d, seed=7):
     g = torch.Generator().manual_seed(int(seed))
     x = torch.randn((n, d), generator=g)
