@@ -56,9 +56,9 @@ def test_benchmarked_entry_point_full_batch(gpu_device, arch, mode, B, pct, gkey
     (a) the gallery encodings of row 0 equal the reference's golden encodings (1e-4);
     (b) every checked row equals the per-sample CPU oracle run with THAT row's classifier (contrastive tolerance): the whole
         EBP half -- probe forward with W and relu(W), fused hook-chain epilogues, two gradient streams, tail;
-    (c) row 0 against the reference's golden map.  Mate / non-mate encodings under seeded random weights are nearly parallel
-        (cosine printed below), and contrastive EBP amplifies last-bit differences of the classifier rows accordingly
-        (tests/test_c2.py measures 2e-8 -> 1e-3 on the reference itself), so (c) holds to cosine >= 0.999, not to 5e-3;
+    (c) row 0 against the reference's golden map, classifier rows from the engine's own gallery forward (contrastive
+        tolerance; mate / non-mate encodings under seeded random weights are nearly parallel -- cosine printed below -- which
+        is what that tolerance is stated for);
     (d) calls pipelined across different batches return what the same calls return one by one, bit for bit."""
     from oracle import ebp_oracle as O
     from xfr_amd.engine import Engine
@@ -113,7 +113,8 @@ def test_benchmarked_entry_point_full_batch(gpu_device, arch, mode, B, pct, gkey
     rel, cos = map_metrics(sal[0], gold[gkey + '/map'])
     cmn = float(torch.nn.functional.cosine_similarity(gm, gn).item())
     print('%s row 0 vs golden: max|d|/max %.2e, cosine %.7f (cosine(mate, non-mate) = %.5f)' % (arch, rel, cos, cmn))
-    assert cos >= 0.999
+    # measured on MI355X: 1.0e-3 / 0.9999998 (ResNet-101), 2.7e-4 / 1.0000000 (ResNet-50-128d)
+    (assert_map_close if pct is None else assert_map_close_robust)(sal[0], gold[gkey + '/map'], '%s row 0 vs golden' % arch, rtol=MAP_RTOL_CONTRAST)
     eng.close()
 
 

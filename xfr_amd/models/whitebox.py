@@ -218,7 +218,11 @@ class _PList(object):
             raise IndexError('xfr_amd does not compute P[-1] (the MWP at the image): nothing on the path reads it')
         if k not in self._cache:
             eng = self._wb._engine(self._x.shape[0])
-            self._cache[k] = eng.ebp_firing(self._x, self._seed_tensor, self._seed, k)
+            P = eng.ebp_firing(self._x, self._seed_tensor, self._seed, k)
+            # the reference flattens before its Linear layers (resnet.py:245, lightcnn.py:258): those entries are N x D
+            if self._wb.P_layername[k] == 'Linear' or (P.shape[2] == 1 and P.shape[3] == 1):
+                P = P.reshape(P.shape[0], -1)
+            self._cache[k] = P
         return self._cache[k]
 
 
