@@ -48,6 +48,41 @@ def test_process_saliency_resize_semantics():
     assert down.shape == (56, 56) and down.min() >= 0.0 and down.max() <= sm.max()
 
 
+def test_jet_equals_matplotlib_everywhere():
+    """The overlay colormap against the library the reference uses (show.py:13,94: matplotlib's 'jet'), on a dense grid."""
+    mpl = pytest.importorskip('matplotlib')
+    import matplotlib.cm  # noqa: F401
+    try:
+        cmap = mpl.colormaps['jet']
+    except AttributeError:
+        cmap = mpl.cm.get_cmap('jet')
+    x = np.linspace(0.0, 1.0, 4097)
+    np.testing.assert_allclose(SIO.jet(x), cmap(x)[:, :3], atol=1e-12)
+
+
+def test_resize_edge_cases():
+    """processSaliency's resize (show.py:136) on the shapes the generator meets besides 112 -> 224: non-square probes, shrinking
+    (IJB-C crops smaller than the map), identity, a constant map; and resize_linear (whitebox.py:802) on non-224 inputs."""
+    rng = np.random.default_rng(3)
+    sm = rng.random((112, 112))
+    for shape in ((160, 128), (96, 300), (56, 56), (33, 71)):
+        out = SIO._resize_cubic(sm, shape)
+        assert out.shape == shape and np.isfinite(out).all()
+        assert out.min() >= min(sm.min(), 0.0) - 1e-12 and out.max() <= sm.max() + 1e-12          # clip=True semantics
+    np.testing.assert_array_equal(SIO._resize_cubic(sm, (112, 112)), sm)
+    c = SIO._resize_cubic(np.full((20, 30), 0.7), (40, 45))
+    np.testing.assert_allclose(c[8:-8, 8:-8], 0.7, atol=2e-3)                                      # away from the zero border
+    # mean-preserving away from the border: the up-sampled map integrates like the original
+    up = SIO._resize_cubic(sm, (224, 224))
+    assert abs(up[16:-16, 16:-16].mean() - sm[8:-8, 8:-8].mean()) < 2e-3
+    img = rng.random((100, 80, 3))
+    lin = SIO.resize_linear(img, (224, 224))
+    assert lin.shape == (224, 224, 3) and lin.min() >= img.min() - 1e-12 and lin.max() <= img.max() + 1e-12
+    assert SIO.resize_linear(img, (100, 80)) is img                                                # same size: the identity
+    small = SIO.resize_linear(rng.random((448, 448, 3)), (224, 224))                                # shrinking pre-smooths
+    assert small.shape == (224, 224, 3) and small.std() < 0.2
+
+
 def test_blend_properties():
     img = np.full((64, 48, 3), 0.25)
     sm = np.zeros((16, 12)); sm[8, 6] = 1.0

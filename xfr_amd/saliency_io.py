@@ -9,11 +9,16 @@ Mirrors, by name and argument meaning:
 
 Host-side glue around the device maps (numpy/scipy/PIL); nothing here is on the EBP hot path.
 
-Resize note -- parity unpinned: the reference calls `skimage.transform.resize(order=3, mode='constant')`, and skimage is not
-installed in this image.  This module restates what skimage >= 0.19 does for that call on a float image that is being
-enlarged: `scipy.ndimage.zoom(order=3, mode='grid-constant', cval=0, grid_mode=True)` followed by a clip to the input's
-value range extended by cval.  (skimage < 0.19 went through `warp`, whose border handling differs.)  When a saliency map is
-reduced in size skimage additionally pre-smooths (anti_aliasing); that branch is restated too.
+Resize note -- parity unpinned, restatement stated precisely: the reference calls `skimage.transform.resize(attMap,
+img.shape[:2], order=3, mode='constant')` (show.py:136) and skimage is not installed in this image, so there is nothing to
+run it against.  This module restates scikit-image 0.19-0.22 (`skimage/transform/_warps.py: resize`): for a 2-D float image
+that release computes `factors = in_shape / out_shape`; when any factor > 1 and anti_aliasing (default True) it pre-filters with
+`ndi.gaussian_filter(image, (factors - 1) / 2, cval=0, mode='constant')`; then `ndi.zoom(image, 1 / factors, order=3,
+mode='grid-constant' (_to_ndimage_mode('constant')), cval=0, grid_mode=True)`; then `_clip_warp_output`: clip to
+[min(in.min, cval), max(in.max, cval)].  (skimage < 0.19 went through `warp`, whose border handling differs; README.md:37 of
+the reference only asks for >= 0.17.2, so the reference itself is not pinned to one behaviour here.)  tests/test_saliency_io.py
+checks the stated properties (identity, pixel-centre mapping, clipping, shrinking, non-square outputs); the jet table is
+checked against matplotlib itself.
 """
 import os
 
