@@ -265,17 +265,21 @@ xfr_status xfr_firing_kinds(xfr_engine* e, int32_t seed_tensor, int32_t* kinds, 
 xfr_status xfr_subtree_weights(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
                                int32_t gate_ge0, float* w_host, int32_t* idx_host, int32_t capacity, void* stream);
 
-/* One standard EBP sweep (whitebox.py:567) of ONE image that returns P[k].flatten()[elem[k]] for every firing k
- * (elem_host[k] < 0: skip) -- the values layerwise_ebp(mode='elementwise') turns into priors (:575-577).  Synchronises. */
-xfr_status xfr_ebp_capture(xfr_engine* e, const float* x_dev, int32_t seed_tensor, const float* seed_dev, const int32_t* elem_host,
-                           float* p_host, int32_t n_firings, void* stream);
+/* One standard EBP sweep (whitebox.py:567) over N independent images that returns, for image b and firing k,
+ * P[k][b].flatten()[elem[k][b]] (elem < 0: skip) -- the values layerwise_ebp(mode='elementwise') turns into priors
+ * (:575-577).  seed_dev: 1 x N x D; elem_host / p_host: n_firings x N host arrays.  Synchronises. */
+xfr_status xfr_ebp_capture(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                           const int32_t* elem_host, float* p_host, int32_t n_firings, void* stream);
 
-/* whitebox.py:570-581 for a BATCH of layers of one image: sweep j re-runs ebp(img, 0*P0) with P_prior[firing[j]] set to a
- * tensor that is zero except element elem[j] = val[j] (mode 'elementwise'), or to dense_prior_dev (n_sweeps == 1; mode
- * 'argmax').  The forward is shared; the sweeps form the gradient batch.  pooled_dev: n_sweeps x H1 x W1 channel-pooled P[-2]. */
-xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n_sweeps, int32_t seed_tensor, const int32_t* firing_host,
-                             const int32_t* elem_host, const float* val_host, const float* dense_prior_dev, float* pooled_dev,
-                             void* stream);
+/* whitebox.py:570-581 for a BATCH of layers of N independent images: sweep j of image b re-runs ebp(img_b, 0*P0) with
+ * P_prior[firing[j][b]] set to a tensor that is zero except element elem[j][b] = val[j][b] (mode 'elementwise'), or -- one
+ * sweep of one image -- to dense_prior_dev (mode 'argmax').  The N forwards run once; the n_sweeps x N sweeps form the
+ * gradient batch (n_sweeps * N <= 2 * max_batch).  firing / elem / val: n_sweeps x N host arrays, firing < 0 marks an idle
+ * sweep (its map is zero).  Handing the sweeps over in ascending firing order per image lets sweep j join the backward
+ * pass only where its first prior fires.  pooled_dev: n_sweeps x N x H1 x W1 channel-pooled P[-2]. */
+xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32_t n_sweeps, int32_t seed_tensor,
+                             const int32_t* firing_host, const int32_t* elem_host, const float* val_host,
+                             const float* dense_prior_dev, float* pooled_dev, void* stream);
 
 /* Whitebox.P[firing] of a standard EBP sweep (whitebox.py:394): out_dev receives N x C x H x W; (c,h,w) receive its shape
  * (out_dev == NULL: shape query only, nothing is run). */

@@ -53,8 +53,8 @@ SYMBOLS = [
     ('xfr_firing_count', _I, [_P, _I, ctypes.POINTER(_I)]),
     ('xfr_firing_kinds', _I, [_P, _I, ctypes.POINTER(_I), _I]),
     ('xfr_subtree_weights', _I, [_P, _P, _I, _I, _P, _I, ctypes.POINTER(_F), ctypes.POINTER(_I), _I, _P]),
-    ('xfr_ebp_capture', _I, [_P, _P, _I, _P, ctypes.POINTER(_I), ctypes.POINTER(_F), _I, _P]),
-    ('xfr_layerwise_ebp', _I, [_P, _P, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_F), _P, _P, _P]),
+    ('xfr_ebp_capture', _I, [_P, _P, _I, _I, _P, ctypes.POINTER(_I), ctypes.POINTER(_F), _I, _P]),
+    ('xfr_layerwise_ebp', _I, [_P, _P, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_F), _P, _P, _P]),
     ('xfr_ebp_store_firing', _I, [_P, _P, _I, _I, _P, _I, _P, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), _P]),
     ('xfr_engine_set_trace', _I, [_P, _I]),
     ('xfr_engine_trace_size', _I, [_P, ctypes.POINTER(_I)]),

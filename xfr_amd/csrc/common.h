@@ -38,15 +38,19 @@ struct EwStep {
     float* pstore;     // HOOK: if non-null, p is stored here (g-index);  STORE / FORK_POSBN: destination
     double* trace;     // HOOK: if non-null, sum(p) per (stream,sample) is accumulated at trace[sb] (stand-alone kernels only)
     float f;           // SCALE: factor
-    // HOOK extras for layerwise EBP (whitebox.py:390-392,406-419): sample `prior_sb` has its p OVERRIDDEN by a prior at
-    // this firing -- a single element (prior_elem, prior_val; c*HW+hw within the sample) or a dense tensor prior_dense
-    int prior_sb;      // -1: no prior at this firing
-    int prior_action;  // PRIOR_* : what the hook returns for that sample
-    int prior_elem;
-    float prior_val;
+    // HOOK extras for layerwise EBP (whitebox.py:390-392,406-419): at this firing a gradient row sb (stream * B + sample) may
+    // have its p OVERRIDDEN by a prior --
+    //   prior_elem != null: table over sb; prior_elem[sb] >= 0 means p of row sb is zero except element prior_elem[sb]
+    //                       (c*HW+hw within the sample), which is prior_val[sb]   (mode 'elementwise'; many probes x sweeps)
+    //   prior_dense != null: row prior_sb gets the dense tensor prior_dense       (mode 'argmax'; one sweep of one image)
+    int prior_sb;
+    int prior_action;  // PRIOR_* : what the hook returns for such a row
+    const int* prior_elem;
+    const float* prior_val;
     const float* prior_dense;
-    // HOOK: capture p of one element (g-index) into *cap_dst (stand-alone kernels only)
-    long cap_idx;
+    // HOOK: capture p of element cap_elem[sb] (c*HW+hw within the sample; -1: none) of every row sb into cap_dst[sb]
+    // (stand-alone kernels only)
+    const int* cap_elem;
     float* cap_dst;
     // float4 chain kernel: prefetch slots of p0 / p1 (elementwise.hip, plan_loads); -1: load in place, -2: not needed
     int ls0, ls1;
@@ -103,7 +107,7 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
         st.ls0 = -1;
         st.ls1 = -1;
         if (st.type == EW_HOOK) {
-            if (!st.pstore && !st.trace && st.action != HOOK_DIV && st.prior_sb < 0 && !st.cap_dst) { st.ls0 = -2; continue; }
+            if (!st.pstore && !st.trace && st.action != HOOK_DIV && !st.prior_elem && !st.prior_dense && !st.cap_dst) { st.ls0 = -2; continue; }
             st.ls0 = slot_for(st.p0, 0);
             if (st.action == HOOK_DIV && st.p1) st.ls1 = slot_for(st.p1, 0);
         } else if (st.type == EW_MASK) {
@@ -138,7 +142,7 @@ inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
         unsigned op = 0, s0 = 7, s1 = 7, store = 0;
         switch (st.type) {
             case EW_HOOK:
-                if (st.trace || st.prior_sb >= 0 || st.cap_dst) return -1;
+                if (st.trace || st.prior_elem || st.prior_dense || st.cap_dst) return -1;
                 if (st.ls0 == -2) {                     // p unobserved: relu(g) or the identity
                     if (st.action != HOOK_RELU) continue;
                     op = SIG_RELU;

@@ -62,11 +62,14 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                     const float a = fmaxf(st.p0[aidx], 0.f);
                     const float zh = fmaxf(g, 0.f);
                     p = a * zh;
-                    if (st.prior_sb >= 0 && sb == st.prior_sb) {
+                    const int hw_ = (int)((idx - (long)c * per_c) - (long)sb * HW);
+                    const int el = c * HW + hw_;
+                    int pel = -2;               // -2: no prior for this row, -1: the dense prior, >= 0: the one non-zero element
+                    if (st.prior_dense) pel = (sb == st.prior_sb) ? -1 : -2;
+                    else if (st.prior_elem) { const int pe = st.prior_elem[sb]; pel = pe >= 0 ? pe : -2; }
+                    if (pel != -2) {
                         // layerwise EBP: p is overridden by the prior (whitebox.py:390-392)
-                        const int hw_ = (int)((idx - (long)c * per_c) - (long)sb * HW);
-                        const int el = c * HW + hw_;
-                        const float pr = st.prior_dense ? st.prior_dense[el] : (el == st.prior_elem ? st.prior_val : 0.f);
+                        const float pr = pel == -1 ? st.prior_dense[el] : (el == pel ? st.prior_val[sb] : 0.f);
                         p = pr;
                         if (st.pstore) st.pstore[idx] = p;
                         if (st.prior_action == PRIOR_DIV) {
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                             g = zh;
                         }
                     }
-                    if (st.cap_dst && idx == st.cap_idx) *st.cap_dst = p;
+                    if (st.cap_dst && el == st.cap_elem[sb]) st.cap_dst[sb] = p;
                 }
                 if (TRACE && st.trace) {
                     // per-(stream,sample) sum of p; a block may straddle samples when HW < NT, so reduce per lane
@@ -581,7 +584,7 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
     for (int i = 0; i < chain.n; ++i) {
         if (chain.s[i].type != EW_HOOK) continue;
         if (chain.s[i].trace) trace = true;
-        if (chain.s[i].prior_sb >= 0 || chain.s[i].cap_dst) prior = true;
+        if (chain.s[i].prior_elem || chain.s[i].prior_dense || chain.s[i].cap_dst) prior = true;
     }
     const long total = (long)C * SB * HW;
     for (int i = 0; i < chain.n; ++i)

@@ -149,13 +149,21 @@ struct xfr_engine {
     const float* held_x = nullptr;
     int held_B = 0, held_last = -1;
     hipStream_t held_stream = nullptr;
-    std::vector<int> rc_active;                       // layerwise sweeps in ascending firing order: stream j is identically zero before firing rc_active[j]
+    std::vector<int> rc_active;                       // layerwise sweeps in ascending firing order: stream j (all its samples) is identically zero before firing rc_active[j]
+    int rc_n = 1;                                     // samples per stream of the current layerwise batch
     size_t g_begin = 0, g_end = 0;                    // the gradient region of the workspace (floats)
-    std::vector<int> rc_prior_sb, rc_prior_elem;      // per firing slot: sample with a prior (-1 none), its element
-    std::vector<float> rc_prior_val;
-    const float* rc_prior_dense = nullptr;            // dense prior tensor (single sweep) instead of (elem, val)
-    std::vector<long> rc_cap_idx;                     // per firing slot: g-index whose p is captured (-1 none)
-    float* cap_dev = nullptr;                         // [n_firings] captured values
+    // priors / captures of the current sweep: tables [n_firings][tab_sb] over the gradient rows sb (stream * n + sample),
+    // staged in pinned host memory and copied once per call (common.h: EwStep::prior_elem / cap_elem)
+    bool rc_priors = false, rc_caps = false;
+    int tab_sb = 0;                                   // row length of the tables of the current call
+    std::vector<char> rc_prior_row, rc_cap_row;       // per firing: does the row hold any entry?
+    int rc_dense_slot = -1;                           // firing that carries the dense prior (-1: none)
+    const float* rc_prior_dense = nullptr;            // dense prior tensor (single sweep of one image)
+    int *tab_elem_h = nullptr, *tab_elem_d = nullptr; // prior element (or capture element) per (firing, row); -1: none
+    float *tab_val_h = nullptr, *tab_val_d = nullptr; // prior value per (firing, row)
+    size_t tab_cap = 0;                               // entries allocated
+    hipEvent_t ev_tab = nullptr;                      // the last host-to-device table copy
+    float* cap_dev = nullptr;                         // [n_firings][tab_sb] captured values
     float* stat_v = nullptr;                          // [n_firings][max_batch]
     int* stat_i = nullptr;
     void* stat_scratch = nullptr;
@@ -591,7 +599,7 @@ void fuse_forward_only(xfr_engine* e, int k, int B, ConvParams& p)
     const int bn_out = bn.d.out;
     EwChain& ch = p.chain;
     ch.n = 0;
-    auto push = [&](int type) -> EwStep& { EwStep& q = ch.s[ch.n++]; memset(&q, 0, sizeof(q)); q.type = type; q.prior_sb = -1; q.cap_idx = -1; return q; };
+    auto push = [&](int type) -> EwStep& { EwStep& q = ch.s[ch.n++]; memset(&q, 0, sizeof(q)); q.type = type; q.prior_sb = -1; return q; };
     {
         EwStep& q = push(EW_AFFINE_C);
         q.p0 = e->arena + bn.bn_alpha_t;
@@ -1109,7 +1117,6 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
         q.action = sy.action;
         q.f = sy.f;
         q.prior_sb = -1;
-        q.cap_idx = -1;
         switch (sy.type) {
             case EW_HOOK:
                 q.p0 = e->T(sy.t0);
@@ -1118,16 +1125,18 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
                 if (e->trace_on && sy.slot >= 0 && trace) q.trace = trace + (size_t)sy.slot * SB;
                 if (sy.slot >= 0) {
                     if (sy.slot == e->store_slot && !sy.tap) q.pstore = e->store_dev;
-                    if (sy.slot < (int)e->rc_prior_sb.size() && e->rc_prior_sb[sy.slot] >= 0) {
-                        q.prior_sb = e->rc_prior_sb[sy.slot];
-                        q.prior_elem = e->rc_prior_elem[sy.slot];
-                        q.prior_val = e->rc_prior_val[sy.slot];
+                    if (e->rc_priors && sy.slot == e->rc_dense_slot) {
+                        q.prior_sb = 0;
                         q.prior_dense = e->rc_prior_dense;
                         q.prior_action = prior_action_for(e->mode, e->ops[sy.op].d.kind);
+                    } else if (e->rc_priors && sy.slot < (int)e->rc_prior_row.size() && e->rc_prior_row[sy.slot]) {
+                        q.prior_elem = e->tab_elem_d + (size_t)sy.slot * e->tab_sb;
+                        q.prior_val = e->tab_val_d + (size_t)sy.slot * e->tab_sb;
+                        q.prior_action = prior_action_for(e->mode, e->ops[sy.op].d.kind);
                     }
-                    if (sy.slot < (int)e->rc_cap_idx.size() && e->rc_cap_idx[sy.slot] >= 0) {
-                        q.cap_idx = e->rc_cap_idx[sy.slot];
-                        q.cap_dst = e->cap_dev + sy.slot;
+                    if (e->rc_caps && sy.slot < (int)e->rc_cap_row.size() && e->rc_cap_row[sy.slot]) {
+                        q.cap_elem = e->tab_elem_d + (size_t)sy.slot * e->tab_sb;
+                        q.cap_dst = e->cap_dev + (size_t)sy.slot * e->tab_sb;
                     }
                 }
                 break;
@@ -1150,12 +1159,12 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
         e->last_trace_sb = SB;
         e->last_trace_kinds = plan.firing_kinds;
     }
-    const bool special = !e->rc_prior_sb.empty() || !e->rc_cap_idx.empty() || e->store_slot >= 0;
+    const bool special = e->rc_priors || e->rc_caps || e->store_slot >= 0;
     const bool use_fused = !e->trace_on && !plan.fused.empty() && !plan.plain;
     // Layerwise sweeps sorted by firing (rc_active): stream j is identically zero until the step that holds its prior
     // hook, so the GEMMs and hook chains before that step leave it out (the gradient region was zero-filled; the small
     // pool / copy kernels still run over all streams and move zeros).  SBa = streams alive at this step.
-    const bool prefix = !e->rc_active.empty() && (int)e->rc_active.size() == SB;
+    const bool prefix = !e->rc_active.empty() && (int)e->rc_active.size() * e->rc_n == SB;
     int run_max = -1;
     const bool use_gemm_fusion = use_fused && e->fuse_gemm_epilogue && !special && !plan.fused_gemm.empty();
     for (const BwdStep& st : (use_gemm_fusion ? plan.fused_gemm : use_fused ? plan.fused : plan.steps)) {
@@ -1163,7 +1172,7 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
         if (prefix) {
             for (const auto& sy : st.chain)
                 if (sy.type == EW_HOOK && sy.slot > run_max) run_max = sy.slot;
-            SBa = (int)(std::upper_bound(e->rc_active.begin(), e->rc_active.end(), run_max) - e->rc_active.begin());
+            SBa = (int)(std::upper_bound(e->rc_active.begin(), e->rc_active.end(), run_max) - e->rc_active.begin()) * e->rc_n;
             if (SBa == 0) continue;
         }
         switch (st.kind) {
@@ -1388,6 +1397,11 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     for (int i = 0; i < e->n_tail_ws; ++i) (void)hipFree(e->tail_ws[i].ws);
     if (e->ws2) (void)hipFree(e->ws2);
     if (e->cap_dev) (void)hipFree(e->cap_dev);
+    if (e->tab_elem_d) (void)hipFree(e->tab_elem_d);
+    if (e->tab_val_d) (void)hipFree(e->tab_val_d);
+    if (e->tab_elem_h) (void)hipHostFree(e->tab_elem_h);
+    if (e->tab_val_h) (void)hipHostFree(e->tab_val_h);
+    if (e->ev_tab) (void)hipEventDestroy(e->ev_tab);
     if (e->stat_v) (void)hipFree(e->stat_v);
     if (e->stat_i) (void)hipFree(e->stat_i);
     if (e->stat_scratch) (void)hipFree(e->stat_scratch);
@@ -1758,7 +1772,13 @@ static xfr_status ensure_subtree_scratch(xfr_engine* e)
     const size_t nf = e->trace_cap + 1;
     size_t max_per_n = 0;
     for (auto& x : e->tens) max_per_n = std::max(max_per_n, (size_t)x.per_n());
-    HIP_TRY(hipMalloc(&e->cap_dev, nf * sizeof(float)));
+    e->tab_cap = nf * 2 * (size_t)e->max_batch;
+    HIP_TRY(hipMalloc(&e->cap_dev, e->tab_cap * sizeof(float)));
+    HIP_TRY(hipMalloc(&e->tab_elem_d, e->tab_cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&e->tab_val_d, e->tab_cap * sizeof(float)));
+    HIP_TRY(hipHostMalloc(&e->tab_elem_h, e->tab_cap * sizeof(int)));
+    HIP_TRY(hipHostMalloc(&e->tab_val_h, e->tab_cap * sizeof(float)));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_tab, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&e->stat_v, nf * e->max_batch * sizeof(float)));
     HIP_TRY(hipMalloc(&e->stat_i, nf * e->max_batch * sizeof(int)));
     HIP_TRY(hipMalloc(&e->stat_scratch, subtree_stats_scratch_bytes(e->max_batch, (int)nf)));
@@ -1797,7 +1817,7 @@ xfr_status xfr_subtree_weights(xfr_engine* e, const float* x_dev, int32_t n, int
     if (st != XFR_OK) return st;
     const Tensor& sd = e->tens[seed_tensor];
     launch_seed_to_cnhw(seed_dev, e->G(seed_tensor), 2 * n, sd.C, sd.HW(), s);
-    e->rc_prior_sb.clear(); e->rc_cap_idx.clear(); e->store_slot = -1;
+    e->rc_priors = e->rc_caps = false; e->store_slot = -1;
     st = run_backward(e, *plan, n, 2, s);
     if (st != XFR_OK) return st;
     if (e->stat_plan != plan) {       // descriptor table of this plan: one entry per distinct gradient tensor
@@ -1823,10 +1843,30 @@ xfr_status xfr_subtree_weights(xfr_engine* e, const float* x_dev, int32_t n, int
     return XFR_OK;
 }
 
-xfr_status xfr_ebp_capture(xfr_engine* e, const float* x_dev, int32_t seed_tensor, const float* seed_dev, const int32_t* elem_host,
-                           float* p_host, int32_t n_firings, void* stream)
+// stage the element / value tables of a call: the pinned host copies may only be rewritten once the previous call's
+// host-to-device copy has completed
+static xfr_status tables_begin(xfr_engine* e, int nf, int rows)
 {
-    xfr_status st = check_run(e, x_dev, 1);
+    if ((size_t)nf * rows > e->tab_cap) return fail(XFR_INVALID_ARG, "%d firings x %d gradient rows exceed the table scratch", nf, rows);
+    HIP_TRY(hipEventSynchronize(e->ev_tab));
+    e->tab_sb = rows;
+    for (size_t i = 0; i < (size_t)nf * rows; ++i) { e->tab_elem_h[i] = -1; e->tab_val_h[i] = 0.f; }
+    return XFR_OK;
+}
+
+static xfr_status tables_commit(xfr_engine* e, int nf, bool with_vals, hipStream_t s)
+{
+    const size_t n = (size_t)nf * e->tab_sb;
+    HIP_TRY(hipMemcpyAsync(e->tab_elem_d, e->tab_elem_h, n * sizeof(int), hipMemcpyHostToDevice, s));
+    if (with_vals) HIP_TRY(hipMemcpyAsync(e->tab_val_d, e->tab_val_h, n * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(e->ev_tab, s));
+    return XFR_OK;
+}
+
+xfr_status xfr_ebp_capture(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
+                           const int32_t* elem_host, float* p_host, int32_t n_firings, void* stream)
+{
+    xfr_status st = check_run(e, x_dev, n);
     if (st != XFR_OK) return st;
     if (!seed_dev || !elem_host || !p_host) return fail(XFR_INVALID_ARG, "null argument");
     st = ensure_subtree_scratch(e);
@@ -1836,68 +1876,98 @@ xfr_status xfr_ebp_capture(xfr_engine* e, const float* x_dev, int32_t seed_tenso
     st = get_plan(e, seed_tensor, &plan);
     if (st != XFR_OK) return st;
     if (n_firings != plan->n_firings) return fail(XFR_INVALID_ARG, "expected %d firings, got %d", plan->n_firings, n_firings);
-    e->rc_prior_sb.clear(); e->store_slot = -1;
-    e->rc_cap_idx.assign(n_firings, -1);
+    st = tables_begin(e, n_firings, n);
+    if (st != XFR_OK) return st;
+    e->rc_priors = false; e->store_slot = -1;
+    e->rc_cap_row.assign(n_firings, 0);
     for (int f = 0; f < n_firings; ++f) {
         const Tensor& x = e->tens[plan->firing_tensor[f]];
-        if (elem_host[f] >= 0 && elem_host[f] < x.per_n()) e->rc_cap_idx[f] = elem_host[f];   // SB == 1: g-index == c*HW+hw
+        for (int b = 0; b < n; ++b) {
+            const int el = elem_host[(size_t)f * n + b];
+            if (el >= 0 && el < x.per_n()) { e->tab_elem_h[(size_t)f * n + b] = el; e->rc_cap_row[f] = 1; }
+        }
     }
-    HIP_TRY(hipMemsetAsync(e->cap_dev, 0, n_firings * sizeof(float), s));
-    st = ebp_core(e, x_dev, 1, 1, seed_tensor, seed_dev, s);
-    e->rc_cap_idx.clear();
+    st = tables_commit(e, n_firings, false, s);
     if (st != XFR_OK) return st;
-    HIP_TRY(hipMemcpyAsync(p_host, e->cap_dev, n_firings * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(e->cap_dev, 0, (size_t)n_firings * n * sizeof(float), s));
+    e->rc_caps = true;
+    st = ebp_core(e, x_dev, n, 1, seed_tensor, seed_dev, s);
+    e->rc_caps = false;
+    if (st != XFR_OK) return st;
+    HIP_TRY(hipMemcpyAsync(p_host, e->cap_dev, (size_t)n_firings * n * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return XFR_OK;
 }
 
-xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n_sweeps, int32_t seed_tensor, const int32_t* firing_host,
-                             const int32_t* elem_host, const float* val_host, const float* dense_prior_dev, float* pooled_dev,
-                             void* stream)
+xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32_t n_sweeps, int32_t seed_tensor,
+                             const int32_t* firing_host, const int32_t* elem_host, const float* val_host,
+                             const float* dense_prior_dev, float* pooled_dev, void* stream)
 {
-    xfr_status st = check_run(e, x_dev, 1);
+    xfr_status st = check_run(e, x_dev, n);
     if (st != XFR_OK) return st;
     if (!firing_host || !pooled_dev) return fail(XFR_INVALID_ARG, "null argument");
-    if (n_sweeps < 1 || n_sweeps > 2 * e->max_batch) return fail(XFR_INVALID_ARG, "n_sweeps %d outside [1, %d]", n_sweeps, 2 * e->max_batch);
-    if (dense_prior_dev && n_sweeps != 1) return fail(XFR_INVALID_ARG, "a dense prior needs n_sweeps == 1");
+    const long rows = (long)n_sweeps * n;
+    if (n_sweeps < 1 || rows > 2L * e->max_batch)
+        return fail(XFR_INVALID_ARG, "%d sweeps x %d images exceed the %d gradient rows of this engine", n_sweeps, n, 2 * e->max_batch);
+    if (dense_prior_dev && rows != 1) return fail(XFR_INVALID_ARG, "a dense prior needs one sweep of one image");
     if (!dense_prior_dev && (!elem_host || !val_host)) return fail(XFR_INVALID_ARG, "null prior arrays");
+    st = ensure_subtree_scratch(e);
+    if (st != XFR_OK) return st;
     hipStream_t s = (hipStream_t)stream;
     BwdPlan* plan = nullptr;
     st = get_plan(e, seed_tensor, &plan);
     if (st != XFR_OK) return st;
     const int nf = plan->n_firings;
-    e->rc_cap_idx.clear(); e->store_slot = -1;
-    e->rc_prior_sb.assign(nf, -1);
-    e->rc_prior_elem.assign(nf, -1);
-    e->rc_prior_val.assign(nf, 0.f);
+    for (long r = 0; r < rows; ++r)
+        if (firing_host[r] >= nf || (firing_host[r] < 0 && dense_prior_dev))
+            return fail(XFR_INVALID_ARG, "firing %d outside [0, %d)", firing_host[r], nf);
+    st = tables_begin(e, nf, (int)rows);
+    if (st != XFR_OK) return st;
+    e->rc_caps = false; e->store_slot = -1;
+    e->rc_prior_row.assign(nf, 0);
+    e->rc_dense_slot = -1;
     e->rc_prior_dense = dense_prior_dev;
-    for (int j = 0; j < n_sweeps; ++j) {
-        const int f = firing_host[j];
-        if (f < 0 || f >= nf) { e->rc_prior_sb.clear(); return fail(XFR_INVALID_ARG, "firing %d outside [0, %d)", f, nf); }
-        if (e->rc_prior_sb[f] >= 0) { e->rc_prior_sb.clear(); return fail(XFR_INVALID_ARG, "firing %d requested twice in one batch", f); }
-        e->rc_prior_sb[f] = j;
-        if (!dense_prior_dev) { e->rc_prior_elem[f] = elem_host[j]; e->rc_prior_val[f] = val_host[j]; }
+    if (dense_prior_dev) {
+        e->rc_dense_slot = firing_host[0];
+    } else {
+        for (long r = 0; r < rows; ++r) {          // row r = sweep j * n + image b; firing < 0: an idle row (stays zero)
+            const int f = firing_host[r];
+            if (f < 0) continue;
+            e->tab_elem_h[(size_t)f * rows + r] = elem_host[r];
+            e->tab_val_h[(size_t)f * rows + r] = val_host[r];
+            e->rc_prior_row[f] = 1;
+        }
+        st = tables_commit(e, nf, true, s);
+        if (st != XFR_OK) return st;
     }
-    // sweeps given in ascending firing order: each one joins the backward pass at its own firing (run_backward)
+    // Sweeps handed over in ascending firing order (per image): sweep j -- identically zero above the earliest of its n priors --
+    // only joins the GEMMs and hook chains from the step that holds that prior hook (run_backward: the launches cover a prefix
+    // of the gradient rows)
     e->rc_active.clear();
+    e->rc_n = n;
+    std::vector<int> first(n_sweeps, nf);
+    for (int j = 0; j < n_sweeps; ++j)
+        for (int b = 0; b < n; ++b) { const int f = firing_host[(size_t)j * n + b]; if (f >= 0) first[j] = std::min(first[j], f); }
     bool ascending = n_sweeps > 1;
-    for (int j = 1; j < n_sweeps; ++j) ascending = ascending && firing_host[j] > firing_host[j - 1];
-    if (ascending && !e->trace_on) e->rc_active.assign(firing_host, firing_host + n_sweeps);
+    for (int j = 1; j < n_sweeps; ++j) ascending = ascending && first[j] >= first[j - 1];
+    if (ascending && !e->trace_on) e->rc_active = first;
     // one forward for all sweeps (whitebox.py:581 runs ebp(img, 0*P0) again for every layer); zero seeds: all the
     // gradient enters through the priors
-    st = forward_all(e, x_dev, 1, seed_tensor, true, s);
+    e->rc_priors = true;
+    st = forward_all(e, x_dev, n, seed_tensor, true, s);
     if (st == XFR_OK) {
         const Tensor& sd = e->tens[seed_tensor];
         if (!e->rc_active.empty()) HIP_TRY(hipMemsetAsync(e->ws + e->g_begin, 0, (e->g_end - e->g_begin) * sizeof(float), s));
-        launch_fill(e->G(seed_tensor), (long)sd.per_n() * n_sweeps, 0.f, s);
-        st = run_backward(e, *plan, 1, n_sweeps, s);
+        launch_fill(e->G(seed_tensor), (long)sd.per_n() * rows, 0.f, s);
+        st = run_backward(e, *plan, n, n_sweeps, s);
     }
     e->rc_active.clear();
-    e->rc_prior_sb.clear();
+    e->rc_priors = false;
     e->rc_prior_dense = nullptr;
+    e->rc_dense_slot = -1;
     if (st != XFR_OK) return st;
     const Tensor& t1 = e->tens[1];
-    launch_channel_pool(e->ws + e->tap_off, pooled_dev, t1.C, n_sweeps, t1.HW(), s);
+    launch_channel_pool(e->ws + e->tap_off, pooled_dev, t1.C, (int)rows, t1.HW(), s);
     HIP_TRY(hipGetLastError());
     return fence_slot0(e, s);
 }
@@ -1920,7 +1990,7 @@ xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, in
     if (h) *h = x.H;
     if (w) *w = x.W;
     if (!out_dev) return XFR_OK;          // shape query
-    e->rc_prior_sb.clear(); e->rc_cap_idx.clear();
+    e->rc_priors = e->rc_caps = false;
     const bool is_tap = (firing == plan->n_firings - 1);
     e->store_slot = is_tap ? -1 : firing;
     st = ebp_core(e, x_dev, n, 1, seed_tensor, seed_dev, s);

@@ -42,11 +42,17 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int s
             float p[4], zh[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { zh[q] = fmaxf(g[q], 0.f); p[q] = a[q] * zh[q]; }
-            if (PRIOR && st.prior_sb >= 0 && sb == st.prior_sb) {
-                // layerwise EBP: p of this sample is overridden by the prior (whitebox.py:390-392)
+            int pel = -2;                   // -2: no prior for this row, -1: the dense prior, >= 0: the one non-zero element
+            if (PRIOR) {
+                if (st.prior_dense) pel = (sb == st.prior_sb) ? -1 : -2;
+                else if (st.prior_elem) { const int pe = st.prior_elem[sb]; pel = pe >= 0 ? pe : -2; }
+            }
+            if (PRIOR && pel != -2) {
+                // layerwise EBP: p of this row is overridden by the prior (whitebox.py:390-392)
                 float pr[4];
+                const float pv = pel >= 0 ? st.prior_val[sb] : 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) pr[q] = st.prior_dense ? st.prior_dense[el0 + q] : ((el0 + q) == st.prior_elem ? st.prior_val : 0.f);
+                for (int q = 0; q < 4; ++q) pr[q] = pel == -1 ? st.prior_dense[el0 + q] : ((el0 + q) == pel ? pv : 0.f);
                 if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(pr[0], pr[1], pr[2], pr[3]);
                 if (st.prior_action == PRIOR_DIV) {
                     float x[4] = {a[0], a[1], a[2], a[3]};
@@ -61,14 +67,16 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int s
                     for (int q = 0; q < 4; ++q) g[q] = pr[q] > 0.f ? g[q] : 0.f;
                 }
                 if (st.cap_dst) {
+                    const int ce = st.cap_elem[sb];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (idx * 4 + q == st.cap_idx) *st.cap_dst = pr[q];
+                    for (int q = 0; q < 4; ++q) if (el0 + q == ce) st.cap_dst[sb] = pr[q];
                 }
                 continue;
             }
             if (PRIOR && st.cap_dst) {
+                const int ce = st.cap_elem[sb];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (idx * 4 + q == st.cap_idx) *st.cap_dst = p[q];
+                for (int q = 0; q < 4; ++q) if (el0 + q == ce) st.cap_dst[sb] = p[q];
             }
             if (st.pstore) reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(p[0], p[1], p[2], p[3]);
             if (st.action == HOOK_DIV) {
