@@ -62,6 +62,69 @@ def test_weighted_subtree_max_variant_and_visit_elements(gpu_device):
     assert swaps == 0
 
 
+@pytest.mark.parametrize('gating', [True, False])
+def test_weighted_subtree_batch_equals_per_probe(gpu_device, gating):
+    """weighted_subtree_ebp_batch (N probes, per-probe classifier, shared launches: 2N-stream weight pass, N-stream capture,
+    J x N layerwise rounds with per-row prior tables) against the one-probe method on each probe, and -- probe 0 -- against the
+    reference's golden map."""
+    g = GC.golden('golden_subtree_mini')
+    subj, sd, x0 = _mini('norelu')
+    wb = subj.wb
+    n = 3
+    x = torch.cat((x0, make_images('stresnet_mini', n - 1, seed=11)), dim=0)
+    xm = torch.cat((synth.unit_rows(1, 512, seed=1), synth.unit_rows(n - 1, 512, seed=31)), dim=0) / 2500
+    xn = torch.cat((synth.unit_rows(1, 512, seed=2), synth.unit_rows(n - 1, 512, seed=32)), dim=0) / 2500
+    single = []
+    for i in range(n):
+        subj.set_cls(xm[i:i + 1], xn[i:i + 1])
+        single.append(wb.weighted_subtree_ebp(x[i:i + 1], 0, 1, topk=8, verbose=False, subtree_mode='norelu',
+                                              do_mated_similarity_gating=gating))
+    for sweep_batch in (None, 5):             # 5: several rounds, idle rows once a probe is done
+        batch = wb.weighted_subtree_ebp_batch(x, xm, xn, topk=8, subtree_mode='norelu', do_mated_similarity_gating=gating,
+                                              sweep_batch=sweep_batch)
+        assert len(batch) == n
+        for i in range(n):
+            sm_b, P_b, w_b, k_b = batch[i]
+            sm_s, P_s, w_s, k_s = single[i]
+            assert sorted(k_b) == sorted(k_s), (i, k_b, k_s)
+            assert np.allclose(sorted(w_b), sorted(w_s), rtol=1e-4)
+            assert_map_close_robust(sm_b, sm_s, 'probe %d batch vs single' % i)
+    if gating:
+        key = 'mini/norelu/top8'
+        assert [int(k) for k in batch[0][3]] == [int(k) for k in g[key + '/k_valid']]
+        assert_map_close_robust(batch[0][0], g[key + '/map'], key + ' (batched)')
+
+
+def test_layerwise_batch_rows_and_idle_sweeps(gpu_device):
+    """xfr_layerwise_ebp with N images x J sweeps: row (j, b) equals the one-image call with the same prior; firing -1 rows stay
+    zero; xfr_ebp_capture at N images equals N one-image calls."""
+    subj, sd, x0 = _mini('all')
+    wb = subj.wb
+    eng = wb._engine(2)
+    x = torch.cat((x0, make_images('stresnet_mini', 1, seed=12)), dim=0).to(gpu_device)
+    st, seed = wb.net.seed_for(torch.tensor([[1.0, 0.0]]), 2)
+    nf = eng.firing_count(st)
+    w_, idx = eng.subtree_weights(x, st, torch.stack((seed, seed), 0))
+    cap2 = eng.ebp_capture(x, st, seed.unsqueeze(0), idx)
+    for b in range(2):
+        cap1 = eng.ebp_capture(x[b:b + 1], st, seed[b:b + 1].unsqueeze(0), idx[:, b])
+        assert np.allclose(cap2[:, b], cap1, rtol=1e-5, atol=1e-30)
+    F = np.array([[3, 7], [12, -1], [33, 20]], dtype=np.int32)
+    E = np.array([[idx[3, 0], idx[7, 1]], [idx[12, 0], 0], [idx[33, 0], idx[20, 1]]], dtype=np.int32)
+    V = np.array([[cap2[3, 0], cap2[7, 1]], [cap2[12, 0], 0.0], [cap2[33, 0], cap2[20, 1]]], dtype=np.float32)
+    maps = eng.layerwise(x, st, F, E, V).cpu().numpy()
+    assert maps.shape[:2] == (3, 2) and np.all(maps[1, 1] == 0)
+    for j in range(3):
+        for b in range(2):
+            if F[j, b] < 0:
+                continue
+            one = eng.layerwise(x[b:b + 1], st, [int(F[j, b])], [int(E[j, b])], [float(V[j, b])]).cpu().numpy()[0]
+            if np.abs(one).max() == 0:
+                assert np.abs(maps[j, b]).max() == 0
+            else:
+                assert_map_close(maps[j, b], one, 'row (%d, %d)' % (j, b))
+
+
 @pytest.mark.parametrize('k', [5, 20, 40])
 def test_layerwise_argmax_golden(gpu_device, k):
     g = GC.golden('golden_subtree_mini')

@@ -32,6 +32,10 @@ def main():
                     help='write {mask_id}-{method}-saliency.npz + overlay PNG per job and method (show.py:196-232); '
                          'methods whose files exist are skipped unless --overwrite (the generator\'s resume)')
     ap.add_argument('--overwrite', action='store_true')
+    ap.add_argument('--group', type=int, default=1,
+                    help='jobs processed together in shared launches (xfr_amd.inpainting_game.run_jobs_batched); 1 = job by job '
+                         'through the reference-shaped callers')
+    ap.add_argument('--max-batch', type=int, default=0, help='engine batch capacity (default 32, or 8 * group in group mode)')
     ap.add_argument('--numpy-inputs', action='store_true', help='uint8 H x W x 3 images through convert_from_numpy (PIL) per call, like the reference')
     args = ap.parse_args()
     import numpy as np
@@ -49,7 +53,7 @@ def main():
     wb = WB.Whitebox(wbn, ebp_subtree_mode='norelu')            # eval/create_wbnet.py:51-52 default for resnetv4/v6
     from xfr_amd.engine import Engine
     wbn._program = bb.build_program()
-    wbn._engine = Engine(wbn._program, 32, dev)
+    wbn._engine = Engine(wbn._program, args.max_batch or (32 if args.group <= 1 else max(32, 8 * args.group)), dev)
     wbn._engine_key = (str(bb.device), id(bb))
     packed = {'n': 0}
 
@@ -72,9 +76,44 @@ def main():
         pool = [np.clip(p.numpy() + mean, 0, 255).astype(np.uint8).transpose(0, 2, 3, 1) for p in pool]
     else:
         pool = [p.to(dev) for p in pool]
+    mode = wb.ebp_subtree_mode()
+    names = {'meanEBP': SIO.method_name('meanEBP', mode, 6, 'cuda'), 'contrastive': SIO.method_name('contrastive', mode, 6, 'cuda'),
+             'truncated': SIO.method_name('contrastive', mode, 6, 'cuda', truncate_percent=20),
+             'weighted-subtree': SIO.method_name('weighted-subtree', mode, 6, 'cuda', topk=args.topk, mode_weighted='norelu')}
+
+    def displayable(probe):      # stand-in for the aligned crop the overlay is drawn on: min-max scaled to [0, 1]
+        disp = (probe.astype(np.float64) if args.numpy_inputs else probe.permute(1, 2, 0).cpu().numpy().astype(np.float64))
+        return (disp - disp.min()) / (disp.max() - disp.min() + 1e-9)
+
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for job in range(lo, hi):
+    for g0 in range(lo, hi if args.group > 1 else lo, args.group):
+        # group mode: the jobs [g0, g1) whose outputs are not all on disk yet run as ONE batch through every method
+        g1 = min(hi, g0 + args.group)
+        todo = []
+        for job in range(g0, g1):
+            odir = os.path.join(args.output_dir, 'subject_ID_%d' % (job % len(pool))) if args.output_dir else None
+            missing = args.overwrite or odir is None or not all(all(os.path.exists(f) for f in SIO.saliency_paths(odir, '%05d' % job, nm))
+                                                                for nm in names.values())
+            if missing:
+                todo.append((job, odir))
+        if todo:
+            jobs = []
+            for job, _ in todo:
+                imgs = pool[job % len(pool)]
+                jobs.append((list(imgs[1:1 + k]), list(imgs[1 + k:]), imgs[0]))
+            t1 = time.perf_counter()
+            res = IG.run_jobs_batched(wb, jobs, 'resnetv4_pytorch', 'norelu', 6, dev, topk=args.topk)
+            torch.cuda.synchronize()
+            t_methods[3] += time.perf_counter() - t1            # group mode reports the per-job total in the last slot
+            for i, (job, odir) in enumerate(todo):
+                for key, nm in names.items():
+                    m = np.asarray(res[key][i])
+                    assert m.shape == (112, 112) and np.isfinite(m).all() and abs(float(m.sum()) - 1.0) < 1e-3
+                    if odir:
+                        written += int(SIO.create_save_smap(nm, odir, True, lambda m=m: m, '%05d' % job, displayable(jobs[i][2])))
+        done += g1 - g0
+    for job in range(lo, hi if args.group <= 1 else lo):
         imgs = pool[job % len(pool)]
         probe, mates, nonmates = imgs[0], list(imgs[1:1 + k]), list(imgs[1 + k:])
         net_name, ver = 'resnetv4_pytorch', 6
@@ -92,11 +131,7 @@ def main():
         def f_sub():
             return IG.run_weighted_subtree_triplet_ebp(wb, mates, nonmates, probe, net_name, 'norelu', ver, dev, topk=args.topk)
 
-        mode = wb.ebp_subtree_mode()
-        methods = [(SIO.method_name('meanEBP', mode, 6, 'cuda'), f_mean),
-                   (SIO.method_name('contrastive', mode, 6, 'cuda'), f_con),
-                   (SIO.method_name('contrastive', mode, 6, 'cuda', truncate_percent=20), f_tru),
-                   (SIO.method_name('weighted-subtree', mode, 6, 'cuda', topk=args.topk, mode_weighted='norelu'), f_sub)]
+        methods = [(names['meanEBP'], f_mean), (names['contrastive'], f_con), (names['truncated'], f_tru), (names['weighted-subtree'], f_sub)]
         stamps = [time.perf_counter()]
         for name, fn in methods:
             def checked(fn=fn):
@@ -104,9 +139,8 @@ def main():
                 assert m.shape == (112, 112) and np.isfinite(m).all() and abs(float(m.sum()) - 1.0) < 1e-3
                 return m
             if args.output_dir:
-                if probe_u8 is None:          # displayable stand-in for the aligned crop: min-max scaled to [0, 1]
-                    disp = (probe.astype(np.float64) if args.numpy_inputs else probe.permute(1, 2, 0).cpu().numpy().astype(np.float64))
-                    probe_u8 = (disp - disp.min()) / (disp.max() - disp.min() + 1e-9)
+                if probe_u8 is None:
+                    probe_u8 = displayable(probe)
                 written += int(SIO.create_save_smap(name, os.path.join(args.output_dir, 'subject_ID_%d' % (job % len(pool))), args.overwrite,
                                                     checked, '%05d' % job, probe_u8))
             else:
@@ -133,7 +167,7 @@ def main():
     if rank == 0:
         per = (t_methods / max(done, 1) * 1e3).round(1).tolist()
         print(json.dumps({'workload': 'inpainting-game whitebox saliency generation shape, ResNet-101, synthetic', 'jobs': total,
-                          'n_gpus': world, 'seconds': dt, 'jobs_per_s': total / dt,
+                          'n_gpus': world, 'seconds': dt, 'jobs_per_s': total / dt, 'group': args.group,
                           'ms_per_job_rank0': {'meanEBP': per[0], 'contrastive(+%d encodes)' % (2 * k): per[1], 'truncated': per[2],
                                                'weighted_subtree_top%d' % args.topk: per[3]},
                           'maps_written_rank0': written if args.output_dir else None,

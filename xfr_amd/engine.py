@@ -250,41 +250,53 @@ class Engine(object):
         return (np.frombuffer(w, dtype=np.float32).reshape(nf, n).copy(), np.frombuffer(idx, dtype=np.int32).reshape(nf, n).copy())
 
     def ebp_capture(self, x, seed_tensor, seed, elems):
-        """One image, seed 1 x 1 x D; elems[k] = flattened (c,h,w) element of firing k -> P[k].flatten()[elems[k]]."""
+        """N images, seed 1 x N x D; elems[k][b] = flattened (c,h,w) element of firing k for image b (a flat list of n_firings
+        ints is accepted for N = 1) -> float32 [n_firings, N] of P[k][b].flatten()[elems[k][b]]."""
         x, _ = self._prep(x)
+        n = x.shape[0]
         seed = seed.detach().to(self.device, torch.float32).contiguous()
         nf = self.firing_count(seed_tensor)
-        el = (ctypes.c_int32 * nf)(*[int(v) for v in elems])
-        out = (ctypes.c_float * nf)()
+        el_np = np.ascontiguousarray(np.asarray(elems, dtype=np.int32).reshape(nf, n))
+        out = np.zeros((nf, n), dtype=np.float32)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.xfr_ebp_capture(self._h, x.data_ptr(), int(seed_tensor), seed.data_ptr(), el, out, nf,
-                                                _stream_ptr(self.device)))
-        return np.frombuffer(out, dtype=np.float32).copy()
+            _lib.check(self.lib.xfr_ebp_capture(self._h, x.data_ptr(), n, int(seed_tensor), seed.data_ptr(),
+                                                el_np.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), nf, _stream_ptr(self.device)))
+        return out if n > 1 else out[:, 0]
 
     def layerwise(self, x, seed_tensor, firings, elems=None, vals=None, dense_prior=None):
-        """Batch of layerwise sweeps of one image -> J x H1 x W1 pooled P[-2] (in the order of `firings`).  The sweeps are
-        handed to the engine in ascending firing order: each then joins the backward pass at its own firing."""
+        """Layerwise sweeps of N images sharing their forwards -> pooled P[-2].
+        One image: `firings` is a list of J firings (any order) -> J x H1 x W1, in the order given.
+        N images: `firings` / `elems` / `vals` are J x N arrays (firing < 0: idle sweep) -> J x N x H1 x W1; hand the sweeps of
+        every image over in ascending firing order so that sweep j joins the backward pass where its first prior fires."""
         x, _ = self._prep(x)
-        J = len(firings)
-        order = sorted(range(J), key=lambda j: int(firings[j]))
-        if order != list(range(J)) and dense_prior is None:
-            out = self.layerwise(x, seed_tensor, [firings[j] for j in order], [elems[j] for j in order] if elems is not None else None,
-                                 [vals[j] for j in order] if vals is not None else None)
-            inv = torch.empty(J, dtype=torch.long)
-            inv[torch.tensor(order)] = torch.arange(J)
-            return out[inv.to(out.device)]
-        fi = (ctypes.c_int32 * J)(*[int(v) for v in firings])
-        el = (ctypes.c_int32 * J)(*[int(v) for v in elems]) if elems is not None else None
-        va = (ctypes.c_float * J)(*[float(v) for v in vals]) if vals is not None else None
+        n = x.shape[0]
+        f_np = np.asarray(firings, dtype=np.int32)
+        if f_np.ndim == 1 and n == 1 and dense_prior is None:
+            order = np.argsort(f_np, kind='stable')
+            out = self.layerwise(x, seed_tensor, f_np[order].reshape(-1, 1), np.asarray(elems, dtype=np.int32)[order].reshape(-1, 1),
+                                 np.asarray(vals, dtype=np.float32)[order].reshape(-1, 1))
+            inv = np.empty_like(order)
+            inv[order] = np.arange(len(order))
+            return out[torch.as_tensor(inv, device=out.device), 0]
+        f_np = np.ascontiguousarray(f_np.reshape(-1, n))
+        J = f_np.shape[0]
+        c1, h1, w1 = self.tensor_shape(1)
+        out = torch.empty((J, n, h1, w1), device=self.device)
+        el = va = dp = None
         if dense_prior is not None:
             dense_prior = dense_prior.detach().to(self.device, torch.float32).contiguous()
-        c1, h1, w1 = self.tensor_shape(1)
-        out = torch.empty((J, h1, w1), device=self.device)
+            dp = dense_prior.data_ptr()
+        else:
+            el_np = np.ascontiguousarray(np.asarray(elems, dtype=np.int32).reshape(J, n))
+            va_np = np.ascontiguousarray(np.asarray(vals, dtype=np.float32).reshape(J, n))
+            el = el_np.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+            va = va_np.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.xfr_layerwise_ebp(self._h, x.data_ptr(), J, int(seed_tensor), fi, el, va,
-                                                  dense_prior.data_ptr() if dense_prior is not None else None, out.data_ptr(),
+            _lib.check(self.lib.xfr_layerwise_ebp(self._h, x.data_ptr(), n, J, int(seed_tensor),
+                                                  f_np.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), el, va, dp, out.data_ptr(),
                                                   _stream_ptr(self.device)))
-        return out
+        return out if (n > 1 or dense_prior is None) else out[:, 0]
 
     def ebp_firing(self, x, seed_tensor, seed, firing):
         """Whitebox.P[firing] of a standard sweep: N x C x H x W."""

@@ -69,10 +69,54 @@ def run_weighted_subtree_triplet_ebp(wb, im_mates, im_nonmates, probe_im, net_na
     return img_subtree
 
 
+def run_jobs_batched(wb, jobs, net_name, subtree_mode_weighted, ebp_version, device, topk=32, methods=None):
+    """Additive: the four saliency methods of generate_wb_smaps (:295-399) for a GROUP of independent jobs in shared launches.
+    jobs: list of (im_mates, im_nonmates, probe_im).  Per job the same calls as mean_ebp, run_contrastive_triplet_ebp
+    (truncate_percent None and 20) and run_weighted_subtree_triplet_ebp above; here all probes form one batch, all mate /
+    non-mate images one encode batch, and each method one (or a few) engine calls: Whitebox.ebp at N probes,
+    contrastive_triplet_ebp_batch, weighted_subtree_ebp_batch.  Returns {method: [map per job]} with the method keys
+    'meanEBP', 'contrastive', 'truncated', 'weighted-subtree'.  Needs the hooked classifier for meanEBP (restored afterwards)
+    and ebp_version 6 maps (float32) for the batched tails."""
+    methods = methods or ('meanEBP', 'contrastive', 'truncated', 'weighted-subtree')
+    n = len(jobs)
+    probes = torch.cat([wb.convert_from_numpy(j[2]) for j in jobs], dim=0).to(device)
+    out = {}
+    saved = wb.net._classifier
+    if 'meanEBP' in methods:
+        wb.net._classifier = None
+        m = wb.ebp(probes, torch.ones((1, wb.net.num_classes())))
+        out['meanEBP'] = list(m.reshape((n,) + m.shape[-2:]))
+        wb.net._classifier = saved
+    if len(set(methods) - {'meanEBP'}) == 0:
+        return out
+    km = [len(j[0]) for j in jobs]
+    kn = [len(j[1]) for j in jobs]
+    gallery = torch.cat([wb.convert_from_numpy(im) for j in jobs for im in list(j[0]) + list(j[1])], dim=0).to(device)
+    enc = torch.cat([wb.encode(gallery[i:i + wb.batch_size]).detach() for i in range(0, gallery.shape[0], wb.batch_size)], dim=0)
+    xm, xn, o = [], [], 0
+    for a, b in zip(km, kn):
+        m_ = enc[o:o + a].mean(dim=0, keepdim=True)
+        n_ = enc[o + a:o + a + b].mean(dim=0, keepdim=True)
+        xm.append(m_ / torch.norm(m_))
+        xn.append(n_ / torch.norm(n_))
+        o += a + b
+    xm, xn = torch.cat(xm, dim=0), torch.cat(xn, dim=0)
+    if 'contrastive' in methods:
+        out['contrastive'] = list(wb.contrastive_triplet_ebp_batch(probes, xm / 2500.0, xn / 2500.0).cpu().numpy())
+    if 'truncated' in methods:
+        out['truncated'] = list(wb.contrastive_triplet_ebp_batch(probes, xm / 2500.0, xn / 2500.0, percentile=20).cpu().numpy())
+    if 'weighted-subtree' in methods:
+        do_max_subtree, gating = SUBTREE_VERSIONS.get(ebp_version, (False, False))
+        res = wb.weighted_subtree_ebp_batch(probes, xm, xn, k_poschannel=0, topk=topk, do_max_subtree=do_max_subtree,
+                                            do_mated_similarity_gating=gating, subtree_mode=subtree_mode_weighted)
+        out['weighted-subtree'] = [r[0] for r in res]
+    return out
+
+
 def shorten_subtree_mode(ebp_subtree_mode):
     """:216-219"""
     return 'awp' if ebp_subtree_mode == 'affineonly_with_prior' else ebp_subtree_mode
 
 
-__all__ = ['mean_ebp', 'run_contrastive_triplet_ebp', 'run_weighted_subtree_triplet_ebp', 'shorten_subtree_mode', 'mean_encoding',
+__all__ = ['mean_ebp', 'run_contrastive_triplet_ebp', 'run_weighted_subtree_triplet_ebp', 'run_jobs_batched', 'shorten_subtree_mode', 'mean_encoding',
            'SUBTREE_VERSIONS']

@@ -430,54 +430,92 @@ class Whitebox(object):
         self._ebp_subtree_mode = subtree_mode                                   # whitebox.py:651
         eng = self._engine(1)
         C = self.net.num_classes()
-        e0 = torch.zeros((1, C))
-        e0[0][0] = 1.0
-        e1 = torch.zeros((1, C))
-        e1[0][1] = 1.0
-        seed_tensor, s1 = self.net.seed_for(e1, 1)
+        onehot = lambda k: torch.nn.functional.one_hot(torch.tensor([k]), C).float()        # noqa: E731
+        seed_tensor, s1 = self.net.seed_for(onehot(1), 1)                       # y[0][1].backward  (:676)
         if do_mated_similarity_gating:
-            _, s0 = self.net.seed_for(e0, 1)                                    # y[0][0].backward  (:668)
+            _, s0 = self.net.seed_for(onehot(0), 1)                             # y[0][0].backward  (:668)
         else:
             y = self.net.classify(img_probe).detach().cpu().float()
             g = torch.softmax(y, dim=1)
             g[0, 0] -= 1.0                                                      # d cross_entropy(y,[0])/dy  (:657,:664)
             _, s0 = self.net.seed_for(g, 1)
-        img_probe, _ = eng._prep(img_probe)                                    # one device tensor for all phases
+        _, sk = self.net.seed_for(onehot(k_poschannel), 1)
+        return self._weighted_subtree(eng, img_probe, seed_tensor, s0, s1, sk, topk, verbose, do_max_subtree,
+                                      do_mated_similarity_gating, do_mwp_to_saliency, sweep_batch)[0]
+
+    def weighted_subtree_ebp_batch(self, img_probes, x_mates, x_nonmates, k_poschannel=0, topk=1, do_max_subtree=False,
+                                   do_mated_similarity_gating=True, subtree_mode='norelu', do_mwp_to_saliency=True,
+                                   sweep_batch=None):
+        """Additive: weighted_subtree_ebp for N independent probes in shared launches.  For probe i equivalent to
+        set_triplet_classifier(x_mates[i], x_nonmates[i]); weighted_subtree_ebp(img_probes[i:i+1], k_poschannel, 1 - k_poschannel...)
+        with channel 0 the mate and channel 1 the non-mate.  The N forwards run once; the layer-weight pass carries 2N gradient
+        streams, the capture pass N, and every round of layerwise sweeps J x N (J * N <= 2 * max_batch).  Returns a list of N
+        (smap, P_img_valid, P_subtree_valid, k_subtree_valid) tuples."""
+        n = img_probes.shape[0]
+        self._ebp_subtree_mode = subtree_mode
+        eng = self._engine(n)
+        seed_tensor = self.net._program.marks['encode']
+        xm = torch.as_tensor(x_mates, dtype=torch.float32).reshape(n, -1).to(eng.device)
+        xn = torch.as_tensor(x_nonmates, dtype=torch.float32).reshape(n, -1).to(eng.device)
+        if do_mated_similarity_gating:
+            s0 = xm
+        else:
+            enc = self.net.encode(img_probes).to(eng.device)
+            y = torch.stack(((enc * xm).sum(dim=1), (enc * xn).sum(dim=1)), dim=1)
+            g = torch.softmax(y, dim=1)
+            g[:, 0] -= 1.0
+            s0 = g[:, 0:1] * xm + g[:, 1:2] * xn                               # g @ W_cls per probe
+        sk = xm if k_poschannel == 0 else xn
+        return self._weighted_subtree(eng, img_probes, seed_tensor, s0, xn, sk, topk, False, do_max_subtree,
+                                      do_mated_similarity_gating, do_mwp_to_saliency, sweep_batch)
+
+    def _weighted_subtree(self, eng, x, seed_tensor, s0, s1, sk, topk, verbose, do_max_subtree, do_mated_similarity_gating,
+                          do_mwp_to_saliency, sweep_batch):
+        """s0 / s1 / sk: N x D gradient seeds of the gate output, the non-mate output and the EBP channel at `seed_tensor`."""
+        x, _ = eng._prep(x)                                                     # one device tensor for all phases ...
+        n = x.shape[0]
         eng.hold_forward(True)                                                  # ... which share its forward pass
         try:
-            return self._weighted_subtree_held(eng, img_probe, seed_tensor, s0, s1, k_poschannel, topk, verbose, do_max_subtree,
-                                               do_mated_similarity_gating, do_mwp_to_saliency, sweep_batch, C)
+            w, idx = eng.subtree_weights(x, seed_tensor, torch.stack((s0, s1), dim=0), gate_ge0=do_mated_similarity_gating)
+            nf = w.shape[0]
+            vals = np.asarray(eng.ebp_capture(x, seed_tensor, sk.unsqueeze(0), idx)).reshape(nf, n)
+            order = [np.argsort(w[:, b]) for b in range(n)]                     # ascending (:697)
+            J = int(sweep_batch or max(1, min((2 * eng.max_batch) // n, max(8, 2 * topk))))
+            pos = [nf] * n
+            valid = [[] for _ in range(n)]                                      # per probe: (k, P), heaviest first
+            while any(pos[b] > 0 and len(valid[b]) < topk for b in range(n)):
+                F = -np.ones((J, n), dtype=np.int32)
+                E = np.zeros((J, n), dtype=np.int32)
+                V = np.zeros((J, n), dtype=np.float32)
+                todo = []
+                for b in range(n):
+                    ks = []
+                    if pos[b] > 0 and len(valid[b]) < topk:
+                        ks = [int(k) for k in order[b][max(0, pos[b] - J):pos[b]]][::-1]
+                        pos[b] -= len(ks)
+                    row = {k: j for j, k in enumerate(sorted(ks))}             # ascending firing: a sweep joins at its own firing
+                    for k, j in row.items():
+                        F[j, b], E[j, b], V[j, b] = k, idx[k, b], vals[k, b]
+                    todo.append((ks, row))
+                maps = eng.layerwise(x, seed_tensor, F, E, V).cpu().numpy()
+                for b, (ks, row) in enumerate(todo):
+                    for k in ks:
+                        P = maps[row[k], b]
+                        if verbose:
+                            print('[weighted_subtree_ebp][%d]: grad=%f' % (k, w[k, b]))
+                        if np.max(P) > 0 and k != 1 and len(valid[b]) < topk:  # :706-707 (k==1: STR-Janus Multiply layer)
+                            valid[b].append((k, P.astype(np.float32)))
         finally:
             eng.hold_forward(False)
+        return [self._merge_subtrees(valid[b][::-1], [float(v) for v in w[:, b]], do_max_subtree, do_mwp_to_saliency) for b in range(n)]
 
-    def _weighted_subtree_held(self, eng, img_probe, seed_tensor, s0, s1, k_poschannel, topk, verbose, do_max_subtree,
-                               do_mated_similarity_gating, do_mwp_to_saliency, sweep_batch, C):
-        w, idx = eng.subtree_weights(img_probe, seed_tensor, torch.stack((s0, s1), dim=0), gate_ge0=do_mated_similarity_gating)
-        P_subtree = [float(v) for v in w[:, 0]]
-        P_subtree_idx = [int(v) for v in idx[:, 0]]
-        k_subtree = np.argsort(np.array(P_subtree))                             # ascending (:697)
-        Pk = torch.zeros((1, C))
-        Pk[0][k_poschannel] = 1.0
-        _, sk = self.net.seed_for(Pk, 1)
-        vals = eng.ebp_capture(img_probe, seed_tensor, sk.unsqueeze(0), P_subtree_idx)
-        J = int(sweep_batch or min(2 * eng.max_batch, max(8, 2 * topk)))
-        valid = []                                                              # (k, P) heaviest first
-        pos = len(k_subtree)
-        while pos > 0 and len(valid) < topk:
-            ks = [int(k) for k in k_subtree[max(0, pos - J):pos]][::-1]
-            pos -= len(ks)
-            maps = eng.layerwise(img_probe, seed_tensor, ks, [P_subtree_idx[k] for k in ks], [vals[k] for k in ks]).cpu().numpy()
-            for k, P in zip(ks, maps):
-                if verbose:
-                    print('[weighted_subtree_ebp][%d]: grad=%f' % (k, P_subtree[k]))
-                if np.max(P) > 0 and k != 1 and len(valid) < topk:             # :706-707 (k==1: STR-Janus Multiply layer)
-                    valid.append((k, P.astype(np.float32)))
+    def _merge_subtrees(self, valid, P_subtree, do_max_subtree, do_mwp_to_saliency):
+        """whitebox.py:706-737 on the valid subtrees (ascending weight, like the reference's [-topk:])."""
         if len(valid) == 0:
             raise RuntimeError(
                 'Failed to calculate valid subtrees. The ebp subtree mode '
                 '(%s) may not support by this type of network. You may want '
                 'to try the "affineonly_with_prior" ebp subtree mode.' % self._ebp_subtree_mode)
-        valid = valid[::-1]                                                     # ascending weight, like [-topk:]
         k_subtree_valid = [k for k, _ in valid]
         P_img_valid = [P for _, P in valid]
         P_subtree_valid = [P_subtree[k] for k in k_subtree_valid]
