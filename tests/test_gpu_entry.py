@@ -148,7 +148,10 @@ def test_whitebox_P_surface(gpu_device):
             assert np.abs(a).max() == 0
         else:
             assert_map_close_robust(a, b, 'layerwise k=%d' % k)
-    assert np.abs(ow.layerwise_ebp(x, k_layer=-25, mode='argmax', k_poschannel=2)).max() > 0
+    pos = wb.layerwise_ebp(x, k_layer=20, mode='argmax', k_poschannel=2)           # a layer whose subtree reaches the image
+    neg = wb.layerwise_ebp(x, k_layer=20 - (nf + 1), mode='argmax', k_poschannel=2)
+    assert np.abs(pos).max() > 0 and np.array_equal(pos, neg)
+    assert_map_close_robust(pos, ow.layerwise_ebp(x, k_layer=20, mode='argmax', k_poschannel=2), 'layerwise k=20')
     assert np.all(wb.layerwise_ebp(x, k_layer=nf, mode='argmax', k_poschannel=2) == 0)       # the image hook: nothing reaches P[-2]
     assert np.all(ow.layerwise_ebp(x, k_layer=nf, mode='argmax', k_poschannel=2) == 0)
     with pytest.raises(IndexError):

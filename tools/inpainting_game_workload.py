@@ -36,6 +36,7 @@ def main():
                     help='jobs processed together in shared launches (xfr_amd.inpainting_game.run_jobs_batched); 1 = job by job '
                          'through the reference-shaped callers')
     ap.add_argument('--max-batch', type=int, default=0, help='engine batch capacity (default 32, or 8 * group in group mode)')
+    ap.add_argument('--phases', action='store_true', help='group mode: time every method separately (adds device synchronisations)')
     ap.add_argument('--numpy-inputs', action='store_true', help='uint8 H x W x 3 images through convert_from_numpy (PIL) per call, like the reference')
     args = ap.parse_args()
     import numpy as np
@@ -85,6 +86,7 @@ def main():
         disp = (probe.astype(np.float64) if args.numpy_inputs else probe.permute(1, 2, 0).cpu().numpy().astype(np.float64))
         return (disp - disp.min()) / (disp.max() - disp.min() + 1e-9)
 
+    phase = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for g0 in range(lo, hi if args.group > 1 else lo, args.group):
@@ -103,7 +105,7 @@ def main():
                 imgs = pool[job % len(pool)]
                 jobs.append((list(imgs[1:1 + k]), list(imgs[1 + k:]), imgs[0]))
             t1 = time.perf_counter()
-            res = IG.run_jobs_batched(wb, jobs, 'resnetv4_pytorch', 'norelu', 6, dev, topk=args.topk)
+            res = IG.run_jobs_batched(wb, jobs, 'resnetv4_pytorch', 'norelu', 6, dev, topk=args.topk, timings=phase if args.phases else None)
             torch.cuda.synchronize()
             t_methods[3] += time.perf_counter() - t1            # group mode reports the per-job total in the last slot
             for i, (job, odir) in enumerate(todo):
@@ -168,6 +170,7 @@ def main():
         per = (t_methods / max(done, 1) * 1e3).round(1).tolist()
         print(json.dumps({'workload': 'inpainting-game whitebox saliency generation shape, ResNet-101, synthetic', 'jobs': total,
                           'n_gpus': world, 'seconds': dt, 'jobs_per_s': total / dt, 'group': args.group,
+                          'ms_per_job_by_phase_rank0': {k_: round(1e3 * v / max(done, 1), 2) for k_, v in phase.items()} or None,
                           'ms_per_job_rank0': {'meanEBP': per[0], 'contrastive(+%d encodes)' % (2 * k): per[1], 'truncated': per[2],
                                                'weighted_subtree_top%d' % args.topk: per[3]},
                           'maps_written_rank0': written if args.output_dir else None,

@@ -198,7 +198,10 @@ class Engine(object):
 
     def hold_forward(self, on):
         """Consecutive calls on the same input tensor share one forward pass while held (include/xfr_amd.h)."""
-        _lib.check(self.lib.xfr_engine_hold_forward(self._h, int(bool(on))))
+        # re-entrant: nested holders (run_jobs_batched around weighted_subtree_ebp) keep one group open
+        self._hold_depth = max(0, getattr(self, '_hold_depth', 0) + (1 if on else -1))
+        if (on and self._hold_depth == 1) or (not on and self._hold_depth == 0):
+            _lib.check(self.lib.xfr_engine_hold_forward(self._h, int(bool(on))))
 
     def set_tail_balance(self, on):
         """GEMM tail balancing (default on); off = batch-invariant fp32 arithmetic (include/xfr_amd.h)."""

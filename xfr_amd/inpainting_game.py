@@ -69,16 +69,27 @@ def run_weighted_subtree_triplet_ebp(wb, im_mates, im_nonmates, probe_im, net_na
     return img_subtree
 
 
-def run_jobs_batched(wb, jobs, net_name, subtree_mode_weighted, ebp_version, device, topk=32, methods=None):
+def run_jobs_batched(wb, jobs, net_name, subtree_mode_weighted, ebp_version, device, topk=32, methods=None, timings=None):
     """Additive: the four saliency methods of generate_wb_smaps (:295-399) for a GROUP of independent jobs in shared launches.
     jobs: list of (im_mates, im_nonmates, probe_im).  Per job the same calls as mean_ebp, run_contrastive_triplet_ebp
     (truncate_percent None and 20) and run_weighted_subtree_triplet_ebp above; here all probes form one batch, all mate /
     non-mate images one encode batch, and each method one (or a few) engine calls: Whitebox.ebp at N probes,
     contrastive_triplet_ebp_batch, weighted_subtree_ebp_batch.  Returns {method: [map per job]} with the method keys
     'meanEBP', 'contrastive', 'truncated', 'weighted-subtree'.  Needs the hooked classifier for meanEBP (restored afterwards)
-    and ebp_version 6 maps (float32) for the batched tails."""
+    and ebp_version 6 maps (float32) for the batched tails.  The three triplet methods run the same probes through the
+    network: they share one forward pass (xfr_engine_hold_forward).  timings: optional dict that receives seconds per phase
+    (synchronises the device between phases)."""
+    import time
     methods = methods or ('meanEBP', 'contrastive', 'truncated', 'weighted-subtree')
     n = len(jobs)
+    clock = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + t - clock[0]
+            clock[0] = t
     probes = torch.cat([wb.convert_from_numpy(j[2]) for j in jobs], dim=0).to(device)
     out = {}
     saved = wb.net._classifier
@@ -87,6 +98,7 @@ def run_jobs_batched(wb, jobs, net_name, subtree_mode_weighted, ebp_version, dev
         m = wb.ebp(probes, torch.ones((1, wb.net.num_classes())))
         out['meanEBP'] = list(m.reshape((n,) + m.shape[-2:]))
         wb.net._classifier = saved
+        lap('meanEBP')
     if len(set(methods) - {'meanEBP'}) == 0:
         return out
     km = [len(j[0]) for j in jobs]
@@ -101,15 +113,25 @@ def run_jobs_batched(wb, jobs, net_name, subtree_mode_weighted, ebp_version, dev
         xn.append(n_ / torch.norm(n_))
         o += a + b
     xm, xn = torch.cat(xm, dim=0), torch.cat(xn, dim=0)
-    if 'contrastive' in methods:
-        out['contrastive'] = list(wb.contrastive_triplet_ebp_batch(probes, xm / 2500.0, xn / 2500.0).cpu().numpy())
-    if 'truncated' in methods:
-        out['truncated'] = list(wb.contrastive_triplet_ebp_batch(probes, xm / 2500.0, xn / 2500.0, percentile=20).cpu().numpy())
-    if 'weighted-subtree' in methods:
-        do_max_subtree, gating = SUBTREE_VERSIONS.get(ebp_version, (False, False))
-        res = wb.weighted_subtree_ebp_batch(probes, xm, xn, k_poschannel=0, topk=topk, do_max_subtree=do_max_subtree,
-                                            do_mated_similarity_gating=gating, subtree_mode=subtree_mode_weighted)
-        out['weighted-subtree'] = [r[0] for r in res]
+    lap('encodes')
+    eng = wb._engine(n)
+    probes, _ = eng._prep(probes)
+    eng.hold_forward(True)
+    try:
+        if 'contrastive' in methods:
+            out['contrastive'] = list(wb.contrastive_triplet_ebp_batch(probes, xm / 2500.0, xn / 2500.0).cpu().numpy())
+            lap('contrastive')
+        if 'truncated' in methods:
+            out['truncated'] = list(wb.contrastive_triplet_ebp_batch(probes, xm / 2500.0, xn / 2500.0, percentile=20).cpu().numpy())
+            lap('truncated')
+        if 'weighted-subtree' in methods:
+            do_max_subtree, gating = SUBTREE_VERSIONS.get(ebp_version, (False, False))
+            res = wb.weighted_subtree_ebp_batch(probes, xm, xn, k_poschannel=0, topk=topk, do_max_subtree=do_max_subtree,
+                                                do_mated_similarity_gating=gating, subtree_mode=subtree_mode_weighted)
+            out['weighted-subtree'] = [r[0] for r in res]
+            lap('weighted-subtree')
+    finally:
+        eng.hold_forward(False)
     return out
 
 
