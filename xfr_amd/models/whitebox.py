@@ -482,29 +482,42 @@ class Whitebox(object):
             order = [np.argsort(w[:, b]) for b in range(n)]                     # ascending (:697)
             J = int(sweep_batch or max(1, min((2 * eng.max_batch) // n, max(8, 2 * topk))))
             pos = [nf] * n
-            valid = [[] for _ in range(n)]                                      # per probe: (k, P), heaviest first
+            valid = [[] for _ in range(n)]                                      # per probe: (k, P on the device), heaviest first
+
+            def take(b):
+                """The next (up to J) layers of probe b, heaviest first, that can yield a valid subtree.  A layer whose chosen
+                element has P == 0 gives an all-zero prior, hence an all-zero map (np.max(P) > 0 fails, :706): it is invalid
+                without being swept.  k == 1 is excluded by the reference (:707)."""
+                ks = []
+                while pos[b] > 0 and len(ks) < J:
+                    pos[b] -= 1
+                    k = int(order[b][pos[b]])
+                    if verbose:
+                        print('[weighted_subtree_ebp][%d]: grad=%f' % (k, w[k, b]))
+                    if vals[k, b] != 0 and k != 1:
+                        ks.append(k)
+                return ks
+
             while any(pos[b] > 0 and len(valid[b]) < topk for b in range(n)):
                 F = -np.ones((J, n), dtype=np.int32)
                 E = np.zeros((J, n), dtype=np.int32)
                 V = np.zeros((J, n), dtype=np.float32)
                 todo = []
                 for b in range(n):
-                    ks = []
-                    if pos[b] > 0 and len(valid[b]) < topk:
-                        ks = [int(k) for k in order[b][max(0, pos[b] - J):pos[b]]][::-1]
-                        pos[b] -= len(ks)
+                    ks = take(b) if len(valid[b]) < topk else []
                     row = {k: j for j, k in enumerate(sorted(ks))}             # ascending firing: a sweep joins at its own firing
                     for k, j in row.items():
                         F[j, b], E[j, b], V[j, b] = k, idx[k, b], vals[k, b]
                     todo.append((ks, row))
-                maps = eng.layerwise(x, seed_tensor, F, E, V).cpu().numpy()
+                if not any(ks for ks, _ in todo):
+                    continue
+                maps = eng.layerwise(x, seed_tensor, F, E, V)                    # J x n x H1 x W1, stays on the device
+                alive = (maps.amax(dim=(2, 3)) > 0).cpu().numpy()                # np.max(P) > 0 per sweep (:706)
                 for b, (ks, row) in enumerate(todo):
                     for k in ks:
-                        P = maps[row[k], b]
-                        if verbose:
-                            print('[weighted_subtree_ebp][%d]: grad=%f' % (k, w[k, b]))
-                        if np.max(P) > 0 and k != 1 and len(valid[b]) < topk:  # :706-707 (k==1: STR-Janus Multiply layer)
-                            valid[b].append((k, P.astype(np.float32)))
+                        if alive[row[k], b] and len(valid[b]) < topk:
+                            valid[b].append((k, maps[row[k], b]))
+            valid = [[(k, P.cpu().numpy().astype(np.float32)) for k, P in vb] for vb in valid]
         finally:
             eng.hold_forward(False)
         return [self._merge_subtrees(valid[b][::-1], [float(v) for v in w[:, b]], do_max_subtree, do_mwp_to_saliency) for b in range(n)]
