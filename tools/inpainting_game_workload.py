@@ -35,7 +35,7 @@ def main():
     ap.add_argument('--group', type=int, default=1,
                     help='jobs processed together in shared launches (xfr_amd.inpainting_game.run_jobs_batched); 1 = job by job '
                          'through the reference-shaped callers')
-    ap.add_argument('--max-batch', type=int, default=0, help='engine batch capacity (default 32, or 8 * group in group mode)')
+    ap.add_argument('--max-batch', type=int, default=0, help='engine batch capacity (default 32, or 16 * group in group mode: 32 layerwise sweeps per probe and round)')
     ap.add_argument('--phases', action='store_true', help='group mode: time every method separately (adds device synchronisations)')
     ap.add_argument('--numpy-inputs', action='store_true', help='uint8 H x W x 3 images through convert_from_numpy (PIL) per call, like the reference')
     args = ap.parse_args()
@@ -54,7 +54,7 @@ def main():
     wb = WB.Whitebox(wbn, ebp_subtree_mode='norelu')            # eval/create_wbnet.py:51-52 default for resnetv4/v6
     from xfr_amd.engine import Engine
     wbn._program = bb.build_program()
-    wbn._engine = Engine(wbn._program, args.max_batch or (32 if args.group <= 1 else max(32, 8 * args.group)), dev)
+    wbn._engine = Engine(wbn._program, args.max_batch or (32 if args.group <= 1 else max(32, 16 * args.group)), dev)
     wbn._engine_key = (str(bb.device), id(bb))
     packed = {'n': 0}
 

@@ -196,13 +196,13 @@ class Whitebox_resnet50_128(WhiteboxNetwork):
 
 class _PList(object):
     """`Whitebox.P` (whitebox.py:294,394): the MWP tensors of the last sweep in firing order.  The reference clones every one
-    of them on every sweep; the engine keeps P[-2] (the only entry its callers read, whitebox.py:499,524) and recomputes any
-    other entry on demand with one more sweep that stores that firing (xfr_ebp_store_firing).  len(P) counts the image hook
+    of them on every sweep; the engine hands back the channel-pooled P[-2] its callers read (whitebox.py:499,524) and recomputes
+    any entry on demand with one more sweep that stores that firing (xfr_ebp_store_firing).  len(P) counts the image hook
     P[-1] like the reference does; its tensor needs the first layer's backward-data pass, which the engine does not run."""
 
-    def __init__(self, wb, x, seed_tensor, seed, p_minus2, n_firings):
+    def __init__(self, wb, x, seed_tensor, seed, n_firings):
         self._wb, self._x, self._seed_tensor, self._seed = wb, x, seed_tensor, seed
-        self._cache = {n_firings - 1: p_minus2}
+        self._cache = {}
         self._n = n_firings + 1
 
     def __len__(self):
@@ -311,14 +311,14 @@ class Whitebox(object):
         seed_tensor, seed = self.net.seed_for(Pn, n)
         if self.debug_trace:
             eng.set_trace(True)
-        mwp_full, pooled = eng.ebp(x, seed_tensor, seed.unsqueeze(0), want_mwp=True, want_pooled=True)
+        _, pooled = eng.ebp(x, seed_tensor, seed.unsqueeze(0), want_mwp=False, want_pooled=True)
         self.P_layername = eng.firing_names(seed_tensor)         # whitebox.py:393 (class names; the image hook has no entry here)
         if self.debug_trace:
             sums, names, nf = eng.get_trace()
             assert names == self.P_layername
             self.P_trace = sums[:nf * n].reshape(nf, n).copy()
             eng.set_trace(False)
-        self.P = _PList(self, x, seed_tensor, seed.unsqueeze(0), mwp_full[0], len(self.P_layername))
+        self.P = _PList(self, x, seed_tensor, seed.unsqueeze(0), len(self.P_layername))
         P = np.squeeze(pooled[0].cpu().numpy()).astype(np.float32)
         return self._mwp_to_saliency(P) if not mwp else P
 
