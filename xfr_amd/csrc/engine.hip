@@ -186,6 +186,7 @@ struct xfr_engine {
     TailWs tail_ws[8];
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
+    bool fuse_probe_fwd = false;       // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
                                        // (both: xfr_engine_set_epilogue_fusion; DESIGN.md section 6 has the measurements)
@@ -628,6 +629,51 @@ void fuse_forward_only(xfr_engine* e, int k, int B, ConvParams& p)
     if (fused_add) e->fwd_done[k2] = 1;
 }
 
+// The probe forward (with the positive pass) needs more than the gallery forward: the RAW convolution output stays (the
+// BatchNorm hook's a is relu(conv output)), and in the modes that divide by a ReLU / Add input's X the BatchNorm's positive
+// output is needed too.  Conv -> BatchNorm [-> in-place ReLU] then runs as: STORE raw, [FORK positive BatchNorm], affine, [clamp].
+// The residual add is left to its own kernel (its pre-add operand is hook state as well).  Returns false if nothing was fused.
+bool can_fuse_probe(xfr_engine* e, int k, int* k1_out)
+{
+    const xfr_op_desc& d = e->ops[k].d;
+    const Tensor& c = e->tens[d.out];
+    if (c.consumers.size() != 1) return false;
+    const int k1 = c.consumers[0];
+    if (k1 > e->fwd_last_op || e->ops[k1].d.kind != XFR_OP_BATCHNORM) return false;
+    *k1_out = k1;
+    return true;
+}
+
+void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
+{
+    int k1 = -1;
+    if (!can_fuse_probe(e, k, &k1)) return;
+    const xfr_op_desc& d = e->ops[k].d;
+    const OpRec& bn = e->ops[k1];
+    const int bn_out = bn.d.out;
+    EwChain& ch = p.chain;
+    ch.n = 0;
+    auto push = [&](int type) -> EwStep& { EwStep& q = ch.s[ch.n++]; memset(&q, 0, sizeof(q)); q.type = type; q.prior_sb = -1; return q; };
+    push(EW_STORE).pstore = e->T(d.out);
+    if (e->tens[bn_out].need_pv) {
+        EwStep& q = push(EW_FORK_POSBN);
+        q.p0 = e->arena + bn.bn_alpha_p;
+        q.p1 = e->arena + (e->with_bias ? bn.bn_beta_pb : bn.bn_beta_p);
+        q.pstore = e->Pv(bn_out);
+        e->pos_done[k1] = 1;
+    }
+    {
+        EwStep& q = push(EW_AFFINE_C);
+        q.p0 = e->arena + bn.bn_alpha_t;
+        q.p1 = e->arena + bn.bn_beta_t;
+    }
+    if (bn.fuse_relu) push(EW_RELU);
+    p.out0 = e->T(bn_out);
+    p.chain_B = B;
+    p.chain_eps = e->eps;
+    e->fwd_done[k1] = 1;
+}
+
 // forward of op k on true values (and, for "dual" convolutions, the positive output in the same launch)
 xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
 {
@@ -657,6 +703,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
                 p.nhalves = 2;
             } else p.nhalves = 1;
             if (!want_pos && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p);
+            else if (want_pos && e->fuse_probe_fwd && !p.relu_in) fuse_probe_forward(e, k, B, p);
             return run_conv(e, p, s);
         }
         case XFR_OP_BATCHNORM:
@@ -1709,8 +1756,9 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
-    e->fuse_gemm_epilogue = enable != 0;
-    e->fuse_fwd_only = enable != 0;
+    e->fuse_gemm_epilogue = (enable & 1) != 0;
+    e->fuse_fwd_only = (enable & 1) != 0;
+    e->fuse_probe_fwd = (enable & 2) != 0;
     e->held_x = nullptr;
     return XFR_OK;
 }
@@ -2269,6 +2317,24 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
         EwLoads ld;
         ew_plan_loads(p.chain, p.out0, ld);
         snprintf(line, sizeof(line), "fwd CONV op %d [%d x %d x %d] K %d", k, e->tens[d.out].C, e->tens[d.out].H, e->tens[d.out].W, e->ops[k].K);
+        out += line;
+        emit_sig(p.chain);
+        out += "\n";
+    }
+    // the probe forward (positive pass alongside): Conv -> BatchNorm [-> ReLU] with the raw output kept
+    e->fwd_done.assign(e->ops.size(), 0);
+    e->pos_done.assign(e->ops.size(), 0);
+    for (int k = 0; k <= last_op; ++k) {
+        const xfr_op_desc& d = e->ops[k].d;
+        if (d.kind != XFR_OP_CONV && d.kind != XFR_OP_LINEAR) continue;
+        ConvParams p;
+        conv_geometry(e, k, batch, p);
+        p.out0 = e->T(d.out);
+        fuse_probe_forward(e, k, batch, p);
+        if (p.chain.n == 0) continue;
+        EwLoads ld;
+        ew_plan_loads(p.chain, p.out0, ld);
+        snprintf(line, sizeof(line), "probe CONV op %d [%d x %d x %d] K %d", k, e->tens[d.out].C, e->tens[d.out].H, e->tens[d.out].W, e->ops[k].K);
         out += line;
         emit_sig(p.chain);
         out += "\n";
