@@ -186,6 +186,7 @@ struct xfr_engine {
     TailWs tail_ws[8];
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
+    bool planning_only = false;        // xfr_plan_describe: list what the planner WOULD fuse, whatever the signature table holds
     bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
@@ -668,6 +669,19 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
         q.p1 = e->arena + bn.bn_beta_t;
     }
     if (bn.fuse_relu) push(EW_RELU);
+    // a dual launch can only carry a chain through the compiled float4 epilogue (conv_gemm.hip): rows that are a multiple of 4
+    // long and a signature that is in the table; otherwise the BatchNorm keeps its own kernel
+    {
+        const Tensor& t = e->tens[d.out];
+        EwChain probe = ch;
+        EwLoads ld;
+        ew_plan_loads(probe, e->T(bn_out), ld);
+        if (!e->planning_only && ((((long)B * t.HW()) & 3) != 0 || conv_gemm_chain_sig(probe) < 0)) {
+            ch.n = 0;
+            e->pos_done[k1] = 0;
+            return;
+        }
+    }
     p.out0 = e->T(bn_out);
     p.chain_B = B;
     p.chain_eps = e->eps;
@@ -2278,6 +2292,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     struct Del { xfr_engine* e; ~Del() { delete e; } } del{e};
     e->max_batch = batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
     e->mode = subtree_mode;
+    e->planning_only = true;
     xfr_status st = build(e, ops, n_ops);
     if (st == XFR_OK) st = layout_arena(e, false);
     if (st == XFR_OK) st = layout_workspace(e);
