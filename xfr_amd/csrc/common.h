@@ -66,17 +66,22 @@ struct EwChain {
 // ReLU hook, the BatchNorm hook and the mask all see the ReLU output).  The float4 chain kernel and the chain epilogue
 // of the GEMM issue the distinct loads together before they interpret the steps, instead of one dependent load after
 // another.  EwStep::ls0/ls1 hold the slot of p0 / p1.
-constexpr int EW_NLOADS = 4;      // distinct per-element operands hoisted per chain (ResNet / Light-CNN chains need <= 4)
+// Slots 0..2 hold operands indexed like the forward tensors (shared by the gradient streams of one position), slot 3 the one
+// gradient-indexed operand (fan-in); slots 5 and 6 are two more forward-indexed ones that only the compiled GEMM epilogues use
+// (the 'norelu' / 'all' chains read up to five forward tensors).  4 is not a slot: it encodes "load in place" in a signature.
+constexpr int EW_NLOADS = 7;
+constexpr int EW_FWD_SLOTS_BASE = 3, EW_FWD_SLOTS_WIDE = 5;
 struct EwLoads {
-    int nl;
+    int nl;                                  // stand-alone kernels: slots 0..nl-1 may be in use (3 may follow a gap)
     const float* lp[EW_NLOADS];
     int lk[EW_NLOADS];                       // 0: indexed like the forward tensors (a-index), 1: like the gradient
 };
 
 // Assign prefetch slots.  A load may be hoisted only if nothing in the chain (or the final store to dst) writes the
 // buffer it reads: stores land at the same element index in the same thread, after the prefetch.
-inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
+inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld, int fwd_slots = EW_FWD_SLOTS_BASE)
 {
+    static const int fwd_order[EW_FWD_SLOTS_WIDE] = {0, 1, 2, 5, 6};
     ld.nl = 0;
     for (int l = 0; l < EW_NLOADS; ++l) { ld.lp[l] = nullptr; ld.lk[l] = 0; }
     auto written = [&](const float* p) {
@@ -85,8 +90,6 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
             if (ch.s[i].pstore == p) return true;
         return false;
     };
-    // slots 0..2 hold operands indexed like the forward tensors (shared by the gradient streams of one position), slot 3
-    // the one gradient-indexed operand (fan-in)
     auto slot_for = [&](const float* p, int kind) -> int {
         if (!p || written(p)) return -1;
         if (kind == 1) {
@@ -96,7 +99,8 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld)
             ld.lk[3] = 1;
             return 3;
         }
-        for (int l = 0; l < 3; ++l) {
+        for (int i = 0; i < fwd_slots; ++i) {
+            const int l = fwd_order[i];
             if (ld.lp[l] == p) return l;
             if (!ld.lp[l]) { ld.lp[l] = p; ld.lk[l] = 0; return l; }
         }
@@ -130,13 +134,14 @@ constexpr int sig_s0(unsigned c) { return (int)((c >> 4) & 7u); }
 constexpr int sig_s1(unsigned c) { return (int)((c >> 7) & 7u); }
 constexpr bool sig_store(unsigned c) { return ((c >> 10) & 1u) != 0; }
 constexpr int sig_step(unsigned c) { return (int)((c >> 11) & 15u); }
+constexpr bool sig_is_slot(int v) { return v != 4 && v != 7; }
 
 // codes[] of a chain whose prefetch slots are assigned (ew_plan_loads); returns the number of codes, or -1 if the chain
 // uses features only the interpreter has (priors, captures, traces)
 inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
 {
     int n = 0;
-    auto slot = [](int ls) -> unsigned { return ls >= 0 ? (unsigned)ls : 4u; };
+    auto slot = [](int ls) -> unsigned { return ls >= 0 ? (unsigned)ls : 4u; };     // slots 0..3, 5, 6; 4 = in place
     for (int i = 0; i < ch.n; ++i) {
         const EwStep& st = ch.s[i];
         unsigned op = 0, s0 = 7, s1 = 7, store = 0;

@@ -675,7 +675,7 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
         const Tensor& t = e->tens[d.out];
         EwChain probe = ch;
         EwLoads ld;
-        ew_plan_loads(probe, e->T(bn_out), ld);
+        ew_plan_loads(probe, e->T(bn_out), ld, EW_FWD_SLOTS_WIDE);
         if (!e->planning_only && ((((long)B * t.HW()) & 3) != 0 || conv_gemm_chain_sig(probe) < 0)) {
             ch.n = 0;
             e->pos_done[k1] = 0;
@@ -2330,7 +2330,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
         fuse_forward_only(e, k, batch, p);
         if (p.chain.n == 0) continue;
         EwLoads ld;
-        ew_plan_loads(p.chain, p.out0, ld);
+        ew_plan_loads(p.chain, p.out0, ld, EW_FWD_SLOTS_WIDE);
         snprintf(line, sizeof(line), "fwd CONV op %d [%d x %d x %d] K %d", k, e->tens[d.out].C, e->tens[d.out].H, e->tens[d.out].W, e->ops[k].K);
         out += line;
         emit_sig(p.chain);
@@ -2348,7 +2348,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
         fuse_probe_forward(e, k, batch, p);
         if (p.chain.n == 0) continue;
         EwLoads ld;
-        ew_plan_loads(p.chain, p.out0, ld);
+        ew_plan_loads(p.chain, p.out0, ld, EW_FWD_SLOTS_WIDE);
         snprintf(line, sizeof(line), "probe CONV op %d [%d x %d x %d] K %d", k, e->tens[d.out].C, e->tens[d.out].H, e->tens[d.out].W, e->ops[k].K);
         out += line;
         emit_sig(p.chain);
@@ -2365,7 +2365,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
             EwChain ch;
             EwLoads ld;
             resolve_chain(e, b.chain, ch, nullptr, 2 * batch);
-            ew_plan_loads(ch, e->G(b.dst_t), ld);
+            ew_plan_loads(ch, e->G(b.dst_t), ld, b.kind == ST_CONV_BWD ? EW_FWD_SLOTS_WIDE : EW_FWD_SLOTS_BASE);
             if (b.kind == ST_CONV_BWD) emit_sig(ch);
             else { snprintf(line, sizeof(line), " steps %d", ch.n); out += line; }
         }
