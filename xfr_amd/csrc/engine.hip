@@ -187,7 +187,8 @@ struct xfr_engine {
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
     bool planning_only = false;        // xfr_plan_describe: list what the planner WOULD fuse, whatever the signature table holds
-    bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue
+    bool fuse_probe_fwd = false;       // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue.  Off by
+                                       // default: measured +0.3 % per step, bit-identical -- and 0.5 ms more inside the GEMM launches
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
                                        // (both: xfr_engine_set_epilogue_fusion; DESIGN.md section 6 has the measurements)
@@ -1770,9 +1771,9 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
-    e->fuse_gemm_epilogue = enable != 0;
-    e->fuse_fwd_only = enable != 0;
-    e->fuse_probe_fwd = enable != 0;
+    e->fuse_gemm_epilogue = (enable & 1) != 0;
+    e->fuse_fwd_only = (enable & 1) != 0;
+    e->fuse_probe_fwd = (enable & 2) != 0;
     e->held_x = nullptr;
     return XFR_OK;
 }

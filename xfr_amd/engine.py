@@ -193,8 +193,9 @@ class Engine(object):
 
     def set_epilogue_fusion(self, on):
         """Hook chains / BatchNorm+add+ReLU inside the GEMM epilogue (default on) or as their own launches."""
-        _lib.check(self.lib.xfr_engine_set_epilogue_fusion(self._h, int(bool(on))))
-        self.options['epilogue_fusion'] = bool(on)
+        level = int(on) if not isinstance(on, bool) else (1 if on else 0)      # 0 off, 1 default, 3 = also the probe forward
+        _lib.check(self.lib.xfr_engine_set_epilogue_fusion(self._h, level))
+        self.options['epilogue_fusion'] = level
 
     def hold_forward(self, on):
         """Consecutive calls on the same input tensor share one forward pass while held (include/xfr_amd.h)."""
