@@ -1635,8 +1635,15 @@ xfr_status xfr_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32_t n_strea
 static xfr_status ensure_streams(xfr_engine* e)
 {
     if (e->s_a) return XFR_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&e->s_a, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&e->s_b, hipStreamNonBlocking));
+    {
+        // The internal streams run forwards -- in pipelined mode the NEXT call's -- while the caller's stream runs the backward
+        // sweep whose maps the caller waits for: the forwards take the lowest priority, so the dispatcher prefers the sweep's
+        // workgroups when both have some ready (measured on MI355X: 26.81 -> 26.69 ms per step; forwards at high priority: 27.3)
+        int lowest = 0, highest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lowest, &highest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->s_a, hipStreamNonBlocking, lowest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->s_b, hipStreamNonBlocking, lowest));
+    }
     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
