@@ -89,49 +89,60 @@ def subtree(out, key, wb, call):
     print('  %-56s %.1fs  dtype %s  sum=%.6f' % (key, time.time() - t, np.asarray(smap).dtype, float(np.sum(smap))))
 
 
-def main():
-    out = {}
+def main(sections):
+    """sections: any of 'r101', 'mini_nogate', 'mini_versions' (default: all).  Cases of sections that are not regenerated are
+    kept from the existing golden_c2.npz."""
+    path = os.path.join(HERE, 'golden_c2.npz')
+    out = dict(np.load(path)) if (sections and os.path.exists(path)) else {}
+    sections = sections or ['r101', 'mini_nogate', 'mini_versions']
     im_mates, im_nonmates, probe_im = c2_images()
 
     # ---- ResNet-101: the three cheap methods of one generator job --------------------------------------------------
-    NC = 65359
-    bb, sd = make_backbone('stresnet101', seed=0, recipe='mild', num_classes=NC)
-    out['r101/wsum'] = np.array(synth.state_checksum(sd))
-    for mode in ('norelu', 'affineonly_with_prior'):
-        wbn = ref_net('stresnet101', sd, NC)
-        wb = ns.whitebox.Whitebox(wbn, ebp_subtree_mode=mode)
-        pre = 'c2/r101/%s/' % mode
-        timed(out, pre + 'mean_ebp', wb, lambda: G.mean_ebp(wb, probe_im, 'resnetv4_pytorch', 6, CPU))
-        spy_encodings(wb, out, pre[:-1])
-        timed(out, pre + 'contrastive', wb,
-              lambda: G.run_contrastive_triplet_ebp(wb, im_mates, im_nonmates, probe_im, 'resnetv4_pytorch', 6, None, CPU))
-        timed(out, pre + 'truncated20', wb,
-              lambda: G.run_contrastive_triplet_ebp(wb, im_mates, im_nonmates, probe_im, 'resnetv4_pytorch', 6, 20, CPU))
+    if 'r101' in sections:
+        NC = 65359
+        bb, sd = make_backbone('stresnet101', seed=0, recipe='mild', num_classes=NC)
+        out['r101/wsum'] = np.array(synth.state_checksum(sd))
+        for mode in ('norelu', 'affineonly_with_prior'):
+            wbn = ref_net('stresnet101', sd, NC)
+            wb = ns.whitebox.Whitebox(wbn, ebp_subtree_mode=mode)
+            pre = 'c2/r101/%s/' % mode
+            timed(out, pre + 'mean_ebp', wb, lambda: G.mean_ebp(wb, probe_im, 'resnetv4_pytorch', 6, CPU))
+            spy_encodings(wb, out, pre[:-1])
+            timed(out, pre + 'contrastive', wb,
+                  lambda: G.run_contrastive_triplet_ebp(wb, im_mates, im_nonmates, probe_im, 'resnetv4_pytorch', 6, None, CPU))
+            timed(out, pre + 'truncated20', wb,
+                  lambda: G.run_contrastive_triplet_ebp(wb, im_mates, im_nonmates, probe_im, 'resnetv4_pytorch', 6, 20, CPU))
 
     # ---- mini STR-ResNet: weighted-subtree parameterisations -----------------------------------------------------------
     bb, sd = make_backbone('stresnet_mini', seed=3, recipe='mild', num_classes=5)
     out['mini/wsum'] = np.array(synth.state_checksum(sd))
     # (a) do_mated_similarity_gating=False through the method itself, float32 maps (ebp_version 6)
-    for mode in ('norelu', 'all'):
-        wbn = ref_net('stresnet_mini', sd, 5)
-        wb = ns.whitebox.Whitebox(wbn, ebp_subtree_mode=mode)
-        x = wb.convert_from_numpy(probe_im)
-        em = torch.from_numpy(synth.unit_rows(1, 512, seed=1).numpy())
-        en = torch.from_numpy(synth.unit_rows(1, 512, seed=2).numpy())
-        wbn.set_triplet_classifier(em, en)
-        subtree(out, 'c2/mini/%s/nogate_top8' % mode, wb,
-                lambda: wb.weighted_subtree_ebp(x, 0, 1, topk=8, verbose=False, do_mated_similarity_gating=False, subtree_mode=mode))
-    # (b) the generator's own caller with ebp_version 8 / 9 / 10 (uint8 saliency path: whitebox.py:451-454,726-727)
-    for ver, mode_w in ((8, 'all'), (9, 'norelu'), (10, 'norelu')):
-        wbn = ref_net('stresnet_mini', sd, 5)
-        wb = ns.whitebox.Whitebox(wbn, ebp_version=ver, ebp_subtree_mode='norelu')       # create_wbnet.py:51-66
-        key = 'c2/mini/v%02d_%s_top8' % (ver, mode_w)
-        spy_encodings(wb, out, key)
-        subtree(out, key, wb,
-                lambda: G.run_weighted_subtree_triplet_ebp(wb, im_mates, im_nonmates, probe_im, 'resnetv4_pytorch', mode_w, ver, CPU, topk=8))
-    np.savez_compressed(os.path.join(HERE, 'golden_c2.npz'), **out)
+    if 'mini_nogate' in sections:
+        for mode in ('norelu', 'all'):
+            wbn = ref_net('stresnet_mini', sd, 5)
+            wb = ns.whitebox.Whitebox(wbn, ebp_subtree_mode=mode)
+            x = wb.convert_from_numpy(probe_im)
+            em = torch.from_numpy(synth.unit_rows(1, 512, seed=1).numpy())
+            en = torch.from_numpy(synth.unit_rows(1, 512, seed=2).numpy())
+            wbn.set_triplet_classifier(em, en)
+            subtree(out, 'c2/mini/%s/nogate_top8' % mode, wb,
+                    lambda: wb.weighted_subtree_ebp(x, 0, 1, topk=8, verbose=False, do_mated_similarity_gating=False, subtree_mode=mode))
+    # (b) the generator's own caller with every ebp_version it knows, 7 .. 12 (uint8 saliency path: whitebox.py:451-454,726-727;
+    #     11 additionally turns with_bias on: whitebox.py:285-289); the weighted mode is the one the generator's docstring pairs
+    #     with the version (generate_whitebox_saliency.py:145-169)
+    if 'mini_versions' in sections:
+        for ver, mode_w in ((7, 'all'), (8, 'all'), (9, 'norelu'), (10, 'norelu'), (11, 'all'), (12, 'affineonly_with_prior')):
+            wbn = ref_net('stresnet_mini', sd, 5)
+            wb = ns.whitebox.Whitebox(wbn, ebp_version=ver, ebp_subtree_mode='norelu')       # create_wbnet.py:51-66
+            key = 'c2/mini/v%02d_%s_top8' % (ver, mode_w)
+            if key + '/map' in out:
+                continue
+            spy_encodings(wb, out, key)
+            subtree(out, key, wb,
+                    lambda: G.run_weighted_subtree_triplet_ebp(wb, im_mates, im_nonmates, probe_im, 'resnetv4_pytorch', mode_w, ver, CPU, topk=8))
+    np.savez_compressed(path, **out)
     print('done')
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1:])

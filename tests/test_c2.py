@@ -98,13 +98,15 @@ def test_oracle_c2_resnet101_norelu(monkeypatch):
     assert float(cm @ cn / np.linalg.norm(cm) / np.linalg.norm(cn)) > 0.999      # the conditioning the docstring talks about
 
 
-@pytest.mark.parametrize('key,ver,mode_w', [('c2/mini/v08_all_top8', 8, 'all'), ('c2/mini/all/nogate_top8', 6, 'all')])
+@pytest.mark.parametrize('key,ver,mode_w', [('c2/mini/v08_all_top8', 8, 'all'), ('c2/mini/v11_all_top8', 11, 'all'),
+                                            ('c2/mini/all/nogate_top8', 6, 'all')])
 def test_oracle_c2_subtree_variants_mini(key, ver, mode_w):
     torch.set_num_threads(8)
     gold = GC.golden('golden_c2')
     bb, sd = make_backbone('stresnet_mini', seed=3, recipe='mild', num_classes=5)
     im_mates, im_nonmates, probe = GC.c2_images()
     wb = OracleCaller('stresnet_mini', sd, 'norelu', ebp_version=ver)
+    wb.ow.with_bias = (ver == 11)                      # whitebox.py:285-289
     if ver == 6:
         x = wb.convert_from_numpy(probe)
         wb.net.set_triplet_classifier(synth.unit_rows(1, 512, seed=1), synth.unit_rows(1, 512, seed=2))
@@ -168,10 +170,13 @@ def test_engine_c2_resnet101(gpu_device, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('key,ver,mode_w', [('c2/mini/v08_all_top8', 8, 'all'), ('c2/mini/v09_norelu_top8', 9, 'norelu'),
-                                            ('c2/mini/v10_norelu_top8', 10, 'norelu')])
+@pytest.mark.parametrize('key,ver,mode_w', [('c2/mini/v07_all_top8', 7, 'all'), ('c2/mini/v08_all_top8', 8, 'all'),
+                                            ('c2/mini/v09_norelu_top8', 9, 'norelu'), ('c2/mini/v10_norelu_top8', 10, 'norelu'),
+                                            ('c2/mini/v11_all_top8', 11, 'all'),
+                                            ('c2/mini/v12_affineonly_with_prior_top8', 12, 'affineonly_with_prior')])
 def test_engine_c2_subtree_versions(gpu_device, key, ver, mode_w):
-    """generate_whitebox_saliency.py:171-194: ebp_version 8 / 9 / 10 through run_weighted_subtree_triplet_ebp (uint8 maps)."""
+    """generate_whitebox_saliency.py:171-194: every ebp_version the generator knows (7 .. 12; 11 also switches with_bias on)
+    through run_weighted_subtree_triplet_ebp (uint8 maps)."""
     gold = GC.golden('golden_c2')
     bb, sd = make_backbone('stresnet_mini', seed=3, recipe='mild', num_classes=5)
     wb = _engine_wb('stresnet_mini', bb, 'norelu', gpu_device, ebp_version=ver)
