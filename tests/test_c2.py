@@ -60,6 +60,13 @@ def test_convert_from_numpy_matches_reference_preprocessing():
         wb.convert_from_numpy(probe.astype(np.float32) - 300.0)
     out = wb.convert_from_numpy(np.random.RandomState(0).rand(100, 80, 3))      # other sizes: shape only (parity unpinned)
     assert tuple(out.shape) == (1, 3, 224, 224)
+    t = torch.zeros((3, 224, 224))
+    assert wb.convert_from_numpy(t).shape == (1, 3, 224, 224)                  # additive: tensors pass through
+    # preprocess_loader (whitebox.py:808-825), in-memory branch of image_loader: (image, tensor[3,H,W], fn=None)
+    items = list(WB.Whitebox.preprocess_loader(wb, [probe, f]))
+    assert len(items) == 2 and items[0][2] is None and torch.equal(items[0][1], want[0]) and items[1][0] is f
+    with pytest.raises(NotImplementedError):
+        list(WB.Whitebox.preprocess_loader(wb, ['some_file.jpg']))
 
 
 def _check_r101(wb, gold, mode, key_check):

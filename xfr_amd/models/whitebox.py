@@ -588,3 +588,16 @@ class Whitebox(object):
         img = resize_linear(img, (224, 224))
         img = (img * 255).astype(np.uint8)
         return self.net.preprocess(PIL.Image.fromarray(img).convert('RGB'))
+
+    def preprocess_loader(self, images, returnImageIndex=False, repeats=1):
+        """whitebox.py:808-825: iterate (displayable image, tensor, fn) over `images`.  The reference pulls the images through
+        xfr.utils.image_loader, which also reads files and DataFrames; that loader (and its face cropping) is outside the hot
+        path, so only the in-memory branch is provided: H x W x 3 arrays (xfr/utils.py:82-85: fn is None for those)."""
+        if returnImageIndex or repeats != 1:
+            raise NotImplementedError('preprocess_loader: the reference itself only unpacks (image, fn) pairs (whitebox.py:817)')
+        for im in images:
+            if not isinstance(im, np.ndarray):
+                raise NotImplementedError('preprocess_loader(): file names / DataFrames go through xfr.utils.image_loader, '
+                                          'which is outside the hot path')
+            assert im.ndim == 3 and im.shape[2] == 3
+            yield im, self.convert_from_numpy(im)[0], None
