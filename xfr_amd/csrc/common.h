@@ -197,7 +197,9 @@ struct ConvParams {
     size_t tail_ws_bytes;
     int tail_force;     // 0 = heuristic, 1 = off, S >= 2 = force S parts per tail tile (tuning / tests)
     int tail_q, tail_s; // set by launch_conv_gemm: whole tiles, parts per tail tile (tail_s <= 1: off)
-    int tap_major;      // K ordered (kh, kw, ci) instead of (ci, kh, kw); requires Cin % 16 == 0
+    int tap_major;      // 1: K ordered (kh, kw, ci) instead of (ci, kh, kw); requires Cin % 16 == 0.  2: Cin <= 4 (image stems): K ordered
+                        // (kh, kw, 4 channel slots), i.e. K = 4 * kh * kw with zero rows for the missing channels
+    int K_logical;      // Cin * kh * kw, for FLOP accounting (== K unless tap_major == 2)
     int kh, kw, stride, pad;
     int OH, OW;
     int K, M;           // M = NB*OH*OW

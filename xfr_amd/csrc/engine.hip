@@ -77,6 +77,8 @@ struct OpRec {
     long bn_alpha_t = -1, bn_beta_t = -1, bn_alpha_p = -1, bn_beta_p = -1, bn_beta_pb = -1;
     int ldw = 0, ldb = 0;
     bool tap_fwd = false, tap_bwd = false;   // K packed tap-major (kh,kw,ci) for the forward / backward-data GEMM
+    bool tap4_fwd = false;                   // image stems (Cin 3 or 4): K packed (kh,kw,4 channel slots); Kf = rows of the forward pack
+    int Kf = 0;
     int Cin = 0, K = 0, Kb = 0;
     size_t idx_off = 0;                      // maxpool argmax (bytes into idx workspace)
     size_t norm_off = 0;                     // normalize: norms (floats into misc workspace)
@@ -506,8 +508,10 @@ xfr_status layout_arena(xfr_engine* e, bool device = true)
             o.ldw = (int)align_up(d.cout, 128);
             o.tap_fwd = (d.kh * d.kw > 1) && (o.Cin % 16 == 0) && (d.kh * d.kw <= 64);
             o.tap_bwd = (d.kh * d.kw > 1) && (d.cout % 16 == 0) && (d.kh * d.kw <= 64);
-            o.w_true = take(align_up(o.K, 32) * o.ldw);
-            o.w_pos = take(align_up(o.K, 32) * o.ldw);
+            o.tap4_fwd = (d.kh * d.kw > 1) && (o.Cin == 3 || o.Cin == 4) && (d.kh * d.kw <= 60);
+            o.Kf = o.tap4_fwd ? 4 * d.kh * d.kw : o.K;
+            o.w_true = take(align_up(o.Kf, 32) * o.ldw);
+            o.w_pos = take(align_up(o.Kf, 32) * o.ldw);
             if (k != 0) {
                 o.ldb = (int)align_up(o.Cin, 128);
                 o.w_bwd = take(align_up(o.Kb, 32) * o.ldb);
@@ -561,7 +565,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
         HIP_TRY(hipEventRecord(ev.first, s));
         launch_conv_gemm(p, s);
         HIP_TRY(hipEventRecord(ev.second, s));
-        e->prof_flops += 2.0 * (double)p.K * (double)p.M * (double)p.CoutTot * (double)p.nhalves;
+        e->prof_flops += 2.0 * (double)(p.K_logical ? p.K_logical : p.K) * (double)p.M * (double)p.CoutTot * (double)p.nhalves;
     } else {
         launch_conv_gemm(p, s);
     }
@@ -578,12 +582,12 @@ void conv_geometry(xfr_engine* e, int k, int NB, ConvParams& p)
     p.Cin = a.C; p.H = a.H; p.W = a.W; p.NB = NB;
     p.kh = d.kh; p.kw = d.kw; p.stride = d.stride; p.pad = d.pad;
     p.OH = t.H; p.OW = t.W;
-    p.K = o.K; p.M = NB * t.H * t.W;
+    p.K = o.Kf; p.K_logical = o.K; p.M = NB * t.H * t.W;
     p.ldw = o.ldw;
     p.out_H = t.H; p.out_W = t.W; p.out_stride = 1;
     p.in_nb = NB; p.out_nb = NB;
     p.in_bytes = (unsigned)((size_t)NB * a.per_n() * sizeof(float));
-    p.tap_major = o.tap_fwd ? 1 : 0;
+    p.tap_major = o.tap4_fwd ? 2 : (o.tap_fwd ? 1 : 0);
 }
 
 // Forward-only runs (encode, embeddings, the gallery of a triplet step) never need the raw convolution output:
@@ -1353,8 +1357,9 @@ xfr_status prof_end(xfr_engine* e, hipStream_t s)
         ms += t;
         if (f) {
             const ConvParams& p = e->ev_params[i];
-            const double fl = 2.0 * p.K * (double)p.M * p.CoutTot * p.nhalves;
-            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", p.CoutTot, p.nhalves, p.K, p.M, p.kh, p.stride, p.out_stride,
+            const int Kl = p.K_logical ? p.K_logical : p.K;
+            const double fl = 2.0 * Kl * (double)p.M * p.CoutTot * p.nhalves;
+            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", p.CoutTot, p.nhalves, Kl, p.M, p.kh, p.stride, p.out_stride,
                     p.relu_in, p.accumulate, t, fl / (t * 1e-3) / 1e12);
         }
     }
@@ -1506,7 +1511,7 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
                 for (int ci = 0; ci < o.Cin; ++ci)
                     for (int tp = 0; tp < khw; ++tp) {
                         const float v = src[ci * khw + tp];
-                        const size_t kk = o.tap_fwd ? (size_t)tp * o.Cin + ci : (size_t)ci * khw + tp;
+                        const size_t kk = o.tap4_fwd ? (size_t)tp * 4 + ci : (o.tap_fwd ? (size_t)tp * o.Cin + ci : (size_t)ci * khw + tp);
                         wt[kk * o.ldw + co] = v;
                         wp[kk * o.ldw + co] = v > 0.f ? v : 0.f;   // relu(W): whitebox.py:319
                     }
@@ -2125,11 +2130,13 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     const int khw = kh * kw, K = cin * khw;
     const int ldw = (int)align_up(cout, 128);
     const bool tap = khw > 1 && (cin % 16 == 0) && khw <= 64;
-    std::vector<float> host(align_up(K, 32) * (size_t)ldw, 0.f);
+    const bool tap4 = khw > 1 && (cin == 3 || cin == 4) && khw <= 60;
+    const int Kf = tap4 ? 4 * khw : K;
+    std::vector<float> host(align_up(Kf, 32) * (size_t)ldw, 0.f);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int tp = 0; tp < khw; ++tp) {
-                const size_t kk = tap ? (size_t)tp * cin + ci : (size_t)ci * khw + tp;
+                const size_t kk = tap4 ? (size_t)tp * 4 + ci : (tap ? (size_t)tp * cin + ci : (size_t)ci * khw + tp);
                 host[kk * ldw + co] = w_host[((size_t)co * cin + ci) * khw + tp];
             }
     float *wd = nullptr, *bd = nullptr;
@@ -2145,10 +2152,10 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     p.Cin = cin; p.H = h; p.W = w; p.NB = nb; p.in_nb = nb; p.out_nb = nb;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
     p.OH = (h + 2 * pad - kh) / stride + 1; p.OW = (w + 2 * pad - kw) / stride + 1;
-    p.K = K; p.M = nb * p.OH * p.OW; p.CoutTot = cout; p.nhalves = 1; p.ldw = ldw;
+    p.K = Kf; p.K_logical = K; p.M = nb * p.OH * p.OW; p.CoutTot = cout; p.nhalves = 1; p.ldw = ldw;
     p.relu_in = relu_in; p.out_H = p.OH; p.out_W = p.OW; p.out_stride = 1;
     p.in_bytes = (unsigned)((size_t)cin * nb * h * w * sizeof(float));
-    p.tap_major = tap ? 1 : 0; p.force_cfg = cfg % 100;
+    p.tap_major = tap4 ? 2 : (tap ? 1 : 0); p.force_cfg = cfg % 100;
     float* tws = nullptr;
     HIP_TRY(hipMalloc(&tws, XFR_TAIL_WS_BYTES + XFR_TAIL_MAX_TILES * sizeof(unsigned)));
     p.tail_ws = tws; p.tail_ws_bytes = XFR_TAIL_WS_BYTES;
