@@ -238,6 +238,21 @@ def test_bench_two_ranks_on_one_gpu(gpu_device):
     assert abs(j['value'] - 2 * 8 * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
 
 
+def test_bench_under_the_drivers_launcher(gpu_device):
+    """The driver's own launch line -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ... -- with N = 2 on this one GPU (gloo instead of RCCL, both ranks on device 0)."""
+    env = dict(os.environ, XFR_DIST_BACKEND='gloo', XFR_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29671', 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '8', '--no-cpu-baseline',
+           '--no-sustained', '--no-profile']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 2 and j['warmup'] == 1 and j['outputs_ok'] is True and j['unit'] == 'maps/s'
+
+
 def test_rccl_entry_points_world_size_1(gpu_device):
     """xfr_comm_unique_id / xfr_comm_init / xfr_broadcast_weights / xfr_comm_destroy through librccl (one rank: the
     communicator is real, the broadcast degenerates to a self-copy); the receiving side's bookkeeping is checked on a second
