@@ -253,6 +253,43 @@ def test_bench_under_the_drivers_launcher(gpu_device):
     assert j['n_gpus'] == 2 and j['steps'] == 2 and j['warmup'] == 1 and j['outputs_ok'] is True and j['unit'] == 'maps/s'
 
 
+NCCL_WORLD1 = '''
+import sys, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from parity_utils import make_backbone, make_images
+from xfr_amd import shard
+from xfr_amd.engine import Engine
+rank, world, local = shard.init_process_group('nccl', force=True)          # backend "nccl" IS RCCL on ROCm
+assert dist.is_initialized() and dist.get_backend() == 'nccl' and (rank, world) == (0, 1)
+dev = torch.device('cuda', local)
+bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=5)
+prog = bb.build_program()
+eng = Engine(prog, 4, dev)
+shard.load_and_broadcast(eng, lambda: sd, src=0)                          # dist.broadcast of the arena tensor through RCCL
+x = make_images('stresnet_mini', 3, seed=1).to(dev)
+enc = eng.forward(x, prog.marks['encode']).reshape(3, -1)
+maps = shard.gather_maps(enc.reshape(3, 1, -1), 3)                        # all_gather through RCCL
+assert torch.equal(maps.reshape(3, -1), enc)
+t = torch.tensor([1.5], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                                  # bench.py's max-over-ranks timing
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print('NCCL_WORLD1_OK', float(t.item()))
+'''
+
+
+def test_rccl_backend_of_the_python_path_world_size_1(gpu_device):
+    """The torch.distributed calls bench.py and the tools make at N > 1 -- broadcast of the arena, all_gather of maps, all_reduce
+    MAX, barrier -- through the RCCL backend itself (one rank: that is what one GPU allows; the 2-rank tests above use gloo)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29677', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('XFR_DIST_BACKEND', None)
+    out = subprocess.run([sys.executable, '-c', NCCL_WORLD1 % (ROOT, os.path.join(ROOT, 'tests'))], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and 'NCCL_WORLD1_OK 1.5' in out.stdout, out.stderr[-3000:]
+
+
 def test_rccl_entry_points_world_size_1(gpu_device):
     """xfr_comm_unique_id / xfr_comm_init / xfr_broadcast_weights / xfr_comm_destroy through librccl (one rank: the
     communicator is real, the broadcast degenerates to a self-copy); the receiving side's bookkeeping is checked on a second

@@ -21,9 +21,10 @@ def dist_env():
     return rank, world, local
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, force=False):
+    """force: initialise the group even at world size 1 (exercises the RCCL code path on a single GPU)."""
     rank, world, local = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         if backend is None:
@@ -44,7 +45,7 @@ def shard_range(n_items, rank, world):
 
 def broadcast_arena(arena, src=0):
     """Broadcast a packed parameter arena (uint8 tensor; CUDA for RCCL, CPU for gloo) from rank `src`."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.broadcast(arena, src=src)
     return arena
 
@@ -64,7 +65,7 @@ def load_and_broadcast(engine, state_dict_fn, src=0):
 def gather_maps(local_maps, n_total):
     """All-gather per-rank saliency maps [n_local, H, W] into [n_total, H, W] on every rank (optional; ranks can
     equally write their shard to disk, like the reference's workers do)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return local_maps
     world = dist.get_world_size()
     sizes = [shard_range(n_total, r, world) for r in range(world)]
