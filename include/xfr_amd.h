@@ -224,7 +224,8 @@ xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
  * the LDS-transposed accumulator tile instead of in their own launches -- same arithmetic in the same order, bit-identical
  * maps, about 8 % more triplet maps per second.  Bit 1 (off by default; enable = 3): also BatchNorm / ReLU after a convolution
  * of the PROBE forward, which additionally keeps the raw output and, where a hook needs it, the positive-pass BatchNorm output
- * (measured: bit-identical, +0.3 % per step, 100 launches fewer, 0.5 ms more inside the GEMM launches).  enable = 0 gives every elementwise segment its own kernel again (the GEMM launches
+ * (measured: bit-identical, +0.3 % per step, 100 launches fewer, 0.5 ms more inside the GEMM launches).  Bit 2 (tests): fused
+ * chains run through the INTERPRETED epilogue -- the path a network outside the compiled signature table takes.  enable = 0 gives every elementwise segment its own kernel again (the GEMM launches
  * then contain convolution work only, which is what one wants when profiling the MFMA kernel by itself). */
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable);
 

@@ -212,6 +212,7 @@ struct ConvParams {
     EwChain chain;      // epilogue micro-program applied to half 0 before the final store (n == 0: none)
     EwLoads chain_ld;   // its operand prefetch plan (set by launch_conv_gemm)
     int chain_sig;      // index of the chain's compiled epilogue (chain_sigs.inc), -1: interpreted (set by launch_conv_gemm)
+    int chain_interpret; // 1: run the chain through the interpreted epilogue even if a compiled one exists (tests)
 };
 
 constexpr int XFR_TAIL_MAX_TILES = 256;

@@ -188,6 +188,7 @@ struct xfr_engine {
     TailWs tail_ws[8];
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
+    bool interpret_chains = false;     // xfr_engine_set_epilogue_fusion bit 2: fused chains run through the interpreted epilogue (tests)
     bool planning_only = false;        // xfr_plan_describe: list what the planner WOULD fuse, whatever the signature table holds
     bool fuse_probe_fwd = false;       // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue.  Off by
                                        // default: measured +0.3 % per step, bit-identical -- and 0.5 ms more inside the GEMM launches
@@ -532,6 +533,7 @@ xfr_status layout_arena(xfr_engine* e, bool device = true)
 xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
+    p.chain_interpret = e->interpret_chains ? 1 : 0;
     p.tail_force = 1;
     if (e->tail_balance) {
         p.tail_force = 0;
@@ -1785,7 +1787,8 @@ xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     e->fuse_gemm_epilogue = (enable & 1) != 0;
     e->fuse_fwd_only = (enable & 1) != 0;
-    e->fuse_probe_fwd = (enable & 2) != 0;
+    e->fuse_probe_fwd = (enable & 2) != 0 && (enable & 4) == 0;     // a dual launch needs the compiled epilogue
+    e->interpret_chains = (enable & 4) != 0;
     e->held_x = nullptr;
     return XFR_OK;
 }
