@@ -214,9 +214,12 @@ xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
 /* Pipeline level 2 only.  ready = 0 (default): the internal forward stream of xfr_ebp / xfr_contrastive /
  * xfr_contrastive_raw first waits for everything already enqueued on the caller's `stream`, so an x_dev that is still
  * being produced there (a cast, a host-to-device copy) is safe -- at the price of the cross-call overlap.  ready = 1: the
- * caller promises that x_dev of the following calls is already valid on the device and stays untouched until the result
- * has been consumed (the inputs_ready contract of xfr_triplet_contrastive); the forward then only waits for the slot it
- * overwrites.  The reference has no counterpart: its inputs are host tensors moved with .to(device) on one stream. */
+ * caller promises that x_dev of the NEXT run call is already valid on the device and stays untouched until the result
+ * has been consumed (the inputs_ready contract of xfr_triplet_contrastive); that call's forward then only waits for the slot
+ * it overwrites.  The promise is consumed by the call it covers (one-shot): every later call is back to ready = 0 until the
+ * caller renews it, so a stale promise cannot leak into a call that never made one (xfr_ebp_capture, xfr_ebp_store_firing and
+ * every other entry point that sweeps go through the same core).  The reference has no counterpart: its inputs are host
+ * tensors moved with .to(device) on one stream. */
 xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
 
 /* Epilogue fusion.  Bit 0 (on by default): the hook chain that follows a backward-data GEMM, and BatchNorm / residual add /
@@ -305,6 +308,12 @@ xfr_status xfr_engine_get_trace(xfr_engine* e, double* sums, int32_t* kinds, int
 xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float* bias_host, float* out_dev, int32_t cin,
                           int32_t h, int32_t w, int32_t nb, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
                           int32_t pad, int32_t relu_in, int32_t cfg, int32_t reps, float* ms_out);
+
+/* Tuning hook: while stamps_dev is non-NULL, every GEMM launch of this process records, per wave, 8 64-bit words at
+ * stamps_dev[(block * 4 + wave) * 8]: s_memrealtime (100 MHz) at kernel entry / first operands landed / K loop done / epilogue entered / exit,
+ * then HW_ID, XCC_ID, block index (tools/conv_sweep.py --stamps draws a launch's timeline from them).  The buffer must hold
+ * 32 words per workgroup of the largest grid launched.  NULL switches it off (the default). */
+xfr_status xfr_debug_conv_stamps(void* stamps_dev);
 
 /* Bytes of device memory held by the engine (weights + workspace). */
 xfr_status xfr_engine_memory(xfr_engine* e, size_t* weight_bytes, size_t* workspace_bytes);

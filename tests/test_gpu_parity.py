@@ -43,7 +43,7 @@ def _check_factory():
     (64, 16, 16, 2, 32, 1, 2, 0),      # strided 1x1
     (128, 8, 8, 2, 40, 8, 1, 0),       # Linear on a flattened 8x8 map (64 taps)
 ])
-@pytest.mark.parametrize("cfg", [0, 4, 5, 10004, 20004, 30005, 80004])
+@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8, 9, 10, 10004, 20004, 30005, 80004, 20006, 30008])
 def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
     """The MFMA implicit-GEMM kernel against plain PyTorch fp32 conv2d on the CPU."""
     from xfr_amd import _lib
@@ -69,7 +69,7 @@ def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
     (1024, 14, 14, 32, 256, 1, 1, 0),  # 392 tiles: 136 tail tiles, float4 operand path
     (512, 7, 7, 32, 512, 3, 1, 1),     # 200 tiles: fewer tiles than CUs
 ])
-@pytest.mark.parametrize('cfg', [0, 10004, 40004, 30005])
+@pytest.mark.parametrize('cfg', [0, 10004, 40004, 30005, 6, 40006, 20008, 30007])
 def test_conv_gemm_tail_balancing(gpu_device, shape, cfg):
     """Whole tiles and K-parts of tail tiles in one grid (conv_gemm.hip, pick_tail_split): equal to fp32 conv2d, and
     launching repeatedly on the same scratch (arrival counters re-armed by the last part) gives the same bits."""

@@ -213,11 +213,15 @@ struct ConvParams {
     EwLoads chain_ld;   // its operand prefetch plan (set by launch_conv_gemm)
     int chain_sig;      // index of the chain's compiled epilogue (chain_sigs.inc), -1: interpreted (set by launch_conv_gemm)
     int chain_interpret; // 1: run the chain through the interpreted epilogue even if a compiled one exists (tests)
+    unsigned long long* stamps;   // tuning hook (xfr_debug_conv_stamps): per wave 8 words -- s_memrealtime at kernel entry, first operands landed,
+                                  // K loop done, epilogue entered, exit; HW_ID; XCC_ID; blockIdx.  nullptr: off
 };
+void conv_gemm_set_stamps(unsigned long long* dev_ptr);   // every later launch_conv_gemm records into dev_ptr (nullptr: stop)
 
 constexpr int XFR_TAIL_MAX_TILES = 256;
 constexpr size_t XFR_TAIL_WS_BYTES = (size_t)16 << 20;
-void launch_conv_gemm(const ConvParams& p, hipStream_t s);
+// false: nothing was launched -- a dual (W / relu(W)) launch carries a chain for which no compiled epilogue exists
+bool launch_conv_gemm(const ConvParams& p, hipStream_t s);
 int conv_gemm_pick_cfg(const ConvParams& p);
 
 // g = src[idx]; run chain; dst[idx] = (accumulate ? dst[idx] : 0) + g.   Tensors are [C][SB][HW] for the gradient

@@ -29,6 +29,7 @@
 // elements (padding, K/M tails) are out-of-range offsets for which the hardware writes 0.0 -- the K-loop carries
 // no per-element address arithmetic and no branches.
 #include <algorithm>
+#include <atomic>
 #include "common.h"
 #include "ew_interp.h"
 #include <cstdio>
@@ -39,7 +40,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int NT = 256;
-long g_chain_launches[2] = {0, 0};     // GEMM launches with a fused chain: [0] compiled epilogue, [1] interpreted
+std::atomic<long> g_chain_launches[2];   // GEMM launches with a fused chain: [0] compiled epilogue, [1] interpreted (engines may run on several host threads)
 
 // XCD-aware block -> tile mapping.  The dispatcher places block b on XCD b % 8; remap so that each XCD walks a
 // contiguous range of logical tiles, ordered co-fastest: the blocks that share one activation (m) tile run
@@ -69,6 +70,20 @@ __device__ inline void bload4(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff,
 constexpr unsigned OOB = 0x80000000u;
 
 enum { MODE_VEC = 0, MODE_TAP = 1, MODE_GEN = 2, MODE_TAP4 = 3 };
+
+// tuning hook: phase stamps of a wave (ConvParams::stamps)
+__device__ __forceinline__ void stamp(const ConvParams& p, int wave, int lane, int slot)
+{
+    if (p.stamps && lane == 0) {
+        unsigned long long* q = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        q[slot] = __builtin_amdgcn_s_memrealtime();      // the 100 MHz reference clock: one time base for all XCDs
+        if (slot == 0) {
+            q[5] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);       // HW_REG_HW_ID
+            q[6] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);       // HW_REG_XCC_ID
+            q[7] = blockIdx.x;
+        }
+    }
+}
 
 template <int N>
 __device__ inline void wait_vmcnt()
@@ -292,6 +307,284 @@ __device__ __forceinline__ void chain_epilogue_dispatch(int sig, const ConvParam
     }
 }
 
+// Everything after the K loop of a 64x64 block tile whose wave (wrow, wcol) holds the 32x32 quadrant acc[0][0]: the exchange of a
+// tail tile's K-parts, then the epilogue.  Shared by the two kernels below.  CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue
+// (p.chain_sig), 2 = interpreted chain epilogue; LDS_OK: the workgroup's LDS holds the four 32 x 36 transposition tiles.
+template <int CHAIN, bool LDS_OK>
+__device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[1][1], float* smem, const int tid, const int lane, const int wave,
+                                               const int co0, const int m0, const int half, const int tail_t, const int part, const int nparts,
+                                               float* __restrict__ osel, const float* __restrict__ bsel)
+{
+    constexpr int MI = 1, NJ = 1, TCO = 64, TM = 64;
+    const int wrow = wave >> 1, wcol = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    if (tail_t >= 0) {
+        // K-part of a tail tile: park the accumulators, count arrivals; the last part to arrive sums all parts in
+        // part order (deterministic) and runs the normal epilogue.  Agent-scope stores / loads: the parts ran on
+        // different XCDs, whose L2s are not coherent for plain accesses.
+        constexpr int TILE_FLOATS = TCO * TM;
+        float* __restrict__ slab = p.tail_ws + (long)(tail_t * nparts + part) * TILE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(slab + ((i * NJ + j) * 16 + r) * NT + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // write-through (agent-scope) stores, then only wait for them: a full __threadfence() would write back AND
+        // invalidate this XCD's whole L2 under the other resident workgroups (measured: 37 us per launch at 256 parts)
+        wait_vmcnt<0>();
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const unsigned old = atomicAdd(p.tail_cnt + tail_t, 1u);
+            const int last = (old == (unsigned)(nparts - 1));
+            if (last) atomicExch(p.tail_cnt + tail_t, 0u);     // ready for the next launch on this stream
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        const float* base = p.tail_ws + (long)tail_t * nparts * TILE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sum = 0.f;
+                    for (int q = 0; q < nparts; ++q)
+                        sum += __hip_atomic_load(base + (long)q * TILE_FLOATS + ((i * NJ + j) * 16 + r) * NT + tid,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[i][j][r] = sum;
+                }
+    }
+
+    // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
+    // Optional fused micro-program (half 0 only): forward = bias -> [store raw] -> BatchNorm -> [+residual] -> ReLU;
+    // backward = [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP -> next GEMM's input.
+    if constexpr (CHAIN == 1) {
+        // compiled chain epilogue; launch_one only selects this instantiation when the float4 layout conditions hold.  The chain
+        // belongs to half 0; the relu(W) half of a dual launch (positive activations) leaves as plain dense rows.
+        if constexpr (MI == 1 && NJ == 1) {
+            if (half == 0)
+                chain_epilogue_dispatch<0>(p.chain_sig, p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
+                                           m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
+            else
+                dense_epilogue(p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32, m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
+        }
+    } else if constexpr (CHAIN == 2) {
+        // Epilogue with a fused micro-program (backward: [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP ->
+        // the next GEMM's input).  The 16 accumulator registers of a 32x32 tile are 4 groups of 4 consecutive output
+        // channels; they are processed group by group, and all per-element operands of a group (plan in
+        // p.chain_ld, <= 4 distinct tensors) are in flight together before the steps are interpreted: every workgroup of
+        // a launch reaches its epilogue at the same time, so a chain of dependent loads here is paid in full.
+        const EwLoads& ld = p.chain_ld;
+        // float4 pieces need rows whose length is a multiple of 4 on both sides (gradient rows of out_nb images, forward
+        // rows of chain_B images); a piece may then straddle two samples (7x7 maps) but never a row
+        const bool vec_ok = MI == 1 && NJ == 1 && LDS_OK && (p.M & 3) == 0 &&
+                            ((p.chain_B * p.OH * p.OW) & 3) == 0 && ((p.out_nb * p.OH * p.OW) & 3) == 0;
+        if (vec_ok) {
+            // vector path: the tile is turned through LDS like in the plain epilogue, a lane then owns float4 pieces
+            // (one channel, four consecutive positions of one sample) and runs the same float4 interpreter as the
+            // stand-alone chain kernel, operands fetched as 16-byte loads
+            constexpr int LD = 36;
+            __syncthreads();
+            float* tile = smem + wave * (32 * LD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = acc[0][0][r];
+            const int ohw = p.OH * p.OW;
+            const long row4 = (long)p.out_nb * ohw / 4, arow4 = (long)p.chain_B * ohw / 4;
+            const int mq = (lane & 7) * 4;
+            const int m = m0 + wcol * 32 + mq;
+            const int mm = m < p.M ? m : 0;
+            const int sb = mm / ohw;
+            const long acol4 = (mm % (p.chain_B * ohw)) / 4;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4* out4 = reinterpret_cast<float4*>(osel);
+#pragma unroll
+            for (int hf = 0; hf < 4; ++hf) {
+                float4 g[1], od[1], v0[1], v1[1], v2[1], v3[1];
+                long idx4[1], aidx4[1];
+                bool ok[1];
+                int cos[1];
+#pragma unroll
+                for (int u = 0; u < 1; ++u) {
+                    const int cl = (hf + u) * 8 + (lane >> 3);
+                    cos[u] = co0 + wrow * 32 + cl;
+                    ok[u] = cos[u] < p.CoutTot && m < p.M;
+                    const int cc = ok[u] ? cos[u] : 0;
+                    idx4[u] = (long)cc * row4 + mm / 4;
+                    aidx4[u] = (long)cc * arow4 + acol4;
+                    g[u] = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
+                    v0[u] = v1[u] = v2[u] = v3[u] = od[u] = z4;
+                    if (ld.lp[0]) v0[u] = reinterpret_cast<const float4*>(ld.lp[0])[aidx4[u]];
+                    if (ld.lp[1]) v1[u] = reinterpret_cast<const float4*>(ld.lp[1])[aidx4[u]];
+                    if (ld.lp[2]) v2[u] = reinterpret_cast<const float4*>(ld.lp[2])[aidx4[u]];
+                    if (ld.lp[3]) v3[u] = reinterpret_cast<const float4*>(ld.lp[3])[idx4[u]];
+                    if (p.accumulate) od[u] = out4[idx4[u]];
+                    if (bsel && ok[u]) { const float b = bsel[cos[u]]; g[u].x += b; g[u].y += b; g[u].z += b; g[u].w += b; }
+                }
+#pragma unroll
+                for (int u = 0; u < 1; ++u)
+                    ew_interpret<false>(ok[u], idx4[u], aidx4[u], sb, 0, g[u], od[u], v0[u], v1[u], v2[u], v3[u], out4, p.accumulate,
+                                        p.chain, cos[u], p.chain_eps);
+            }
+        } else
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
+            if (m >= p.M) continue;
+            const int ohw = p.OH * p.OW;
+            const long col = m;                                   // chains are only fused into dense (out_stride 1) launches
+            const long row_stride = (long)p.out_nb * ohw;
+            const int sb = m / ohw;
+            const int hw = m - sb * ohw;
+            const long acol = (long)(sb % p.chain_B) * ohw + hw;
+            const long arow = (long)p.chain_B * ohw;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int hf = 0; hf < 4; ++hf) {
+                    float g[4], pv0[4], pv1[4], pv2[4], pv3[4];
+                    int gi[4], ai[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int e8 = 0; e8 < 4; ++e8) {
+                        const int rg = hf, q = e8;
+                        const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
+                        ok[e8] = co < p.CoutTot;
+                        const int cc = ok[e8] ? co : 0;
+                        gi[e8] = (int)((long)cc * row_stride + col);
+                        ai[e8] = (int)((long)cc * arow + acol);
+                        pv0[e8] = pv1[e8] = pv2[e8] = pv3[e8] = 0.f;
+                    }
+#pragma unroll
+                    for (int e8 = 0; e8 < 4; ++e8) {
+                        if (ld.lp[0]) pv0[e8] = ld.lp[0][ld.lk[0] ? gi[e8] : ai[e8]];
+                        if (ld.lp[1]) pv1[e8] = ld.lp[1][ld.lk[1] ? gi[e8] : ai[e8]];
+                        if (ld.lp[2]) pv2[e8] = ld.lp[2][ld.lk[2] ? gi[e8] : ai[e8]];
+                        if (ld.lp[3]) pv3[e8] = ld.lp[3][ld.lk[3] ? gi[e8] : ai[e8]];
+                    }
+#pragma unroll
+                    for (int e8 = 0; e8 < 4; ++e8) {
+                        const int rg = hf, q = e8;
+                        const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
+                        float v = acc[i][j][rg * 4 + q];
+                        if (ok[e8]) {
+                            if (bsel) v += bsel[co];
+                            if (p.accumulate) v += osel[gi[e8]];
+                        }
+                        g[e8] = v;
+                    }
+#pragma unroll 1
+                    for (int sidx = 0; sidx < p.chain.n; ++sidx) {
+                        const EwStep& st = p.chain.s[sidx];
+                        const int type = st.type, s0 = st.ls0, s1 = st.ls1;
+                        if (type == EW_HOOK) {
+                            if (s0 == -2) {                      // p is not observed: relu(g) or the identity
+                                if (st.action == HOOK_RELU) {
+#pragma unroll
+                                    for (int e8 = 0; e8 < 4; ++e8) g[e8] = fmaxf(g[e8], 0.f);
+                                }
+                                continue;
+                            }
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                if (!ok[e8]) continue;
+                                const float a = fmaxf(s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]], 0.f);
+                                const float zh = fmaxf(g[e8], 0.f);
+                                const float pp = a * zh;
+                                if (st.pstore) st.pstore[gi[e8]] = pp;
+                                if (st.action == HOOK_DIV) {
+                                    const float x = st.p1 ? fmaxf(s1 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s1) : st.p1[ai[e8]], 0.f) : a;
+                                    g[e8] = __fdiv_rn(pp, x + p.chain_eps);
+                                } else if (st.action == HOOK_RELU) {
+                                    g[e8] = zh;
+                                }
+                            }
+                        } else if (type == EW_MASK) {
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                if (!ok[e8]) continue;
+                                const float t = s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]];
+                                g[e8] = t > 0.f ? g[e8] : 0.f;
+                            }
+                        } else if (type == EW_SCALE_C) {
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8)
+                                if (ok[e8]) g[e8] *= st.p0[co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8];
+                        } else if (type == EW_SCALE) {
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8) g[e8] *= st.f;
+                        } else if (type == EW_STORE) {
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8)
+                                if (ok[e8]) st.pstore[gi[e8]] = g[e8];
+                        } else if (type == EW_ADDP) {
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8)
+                                if (ok[e8]) g[e8] += s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[gi[e8]];
+                        } else if (type == EW_AFFINE_C) {
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
+                                if (ok[e8]) g[e8] = __fadd_rn(__fmul_rn(g[e8], st.p0[co]), st.p1[co]);
+                            }
+                        } else if (type == EW_RELU) {
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8) g[e8] = fmaxf(g[e8], 0.f);
+                        } else {   // EW_FORK_POSBN
+#pragma unroll
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
+                                if (ok[e8]) st.pstore[gi[e8]] = __fadd_rn(__fmul_rn(fmaxf(g[e8], 0.f), st.p0[co]), st.p1[co]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e8 = 0; e8 < 4; ++e8)
+                        if (ok[e8]) osel[gi[e8]] = g[e8];
+                }
+            }
+        }
+    } else if (MI == 1 && NJ == 1 && LDS_OK && p.out_stride == 1 && (p.M & 3) == 0 && ((p.out_nb * p.OH * p.OW) & 3) == 0) {
+        if constexpr (MI == 1 && NJ == 1)
+            dense_epilogue(p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32, m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
+            if (m >= p.M) continue;
+            long col;
+            long row_stride;
+            const int ohw = p.OH * p.OW;
+            if (p.out_stride == 1) {
+                col = m;
+                row_stride = (long)p.out_nb * ohw;
+            } else {
+                const int n = m / ohw;
+                const int r = m - n * ohw;
+                const int oh = r / p.OW;
+                const int ow = r - oh * p.OW;
+                col = ((long)n * p.out_H + (long)oh * p.out_stride) * p.out_W + (long)ow * p.out_stride;
+                row_stride = (long)p.out_nb * p.out_H * p.out_W;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wrow * (TCO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co >= p.CoutTot) continue;
+                    const long gi = (long)co * row_stride + col;
+                    float v = acc[i][j][r];
+                    if (bsel) v += bsel[co];
+                    if (p.accumulate) v += osel[gi];
+                    osel[gi] = v;
+                }
+        }
+    }
+}
+
 // CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue (p.chain_sig), 2 = interpreted chain epilogue
 template <int TCO, int TM, int BK, int NST, int MODE, bool RELU, int CHAIN>
 __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
@@ -313,6 +606,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wrow = wave >> 1, wcol = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
+    stamp(p, wave, lane, 0);
 
     // n_co_tiles counts the tiles of BOTH halves of a dual launch (half 1 = relu(W) -> positive activations)
     const int n_tiles_all = n_co_tiles * n_m_tiles;
@@ -537,6 +831,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         // guarantees every wave is done reading the stage we are about to refill.
         wait_vmcnt<(NST - 2) * L>();
         __builtin_amdgcn_s_barrier();
+        if (kt == kt_lo) stamp(p, wave, lane, 1);
         int st_fill = st + NST - 1;
         if (st_fill >= NST) st_fill -= NST;
         const float* As = smem + st * STAGE;
@@ -574,272 +869,280 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
         st = (st + 1 == NST) ? 0 : st + 1;
     }
     wait_vmcnt<0>();   // drain the tail loads before the LDS is released
+    stamp(p, wave, lane, 2);
+    stamp(p, wave, lane, 3);
 
-    if (tail_t >= 0) {
-        // K-part of a tail tile: park the accumulators, count arrivals; the last part to arrive sums all parts in
-        // part order (deterministic) and runs the normal epilogue.  Agent-scope stores / loads: the parts ran on
-        // different XCDs, whose L2s are not coherent for plain accesses.
-        constexpr int TILE_FLOATS = TCO * TM;
-        float* __restrict__ slab = p.tail_ws + (long)(tail_t * nparts + part) * TILE_FLOATS;
+    block_epilogue<CHAIN, (NST * STAGE >= 4 * 32 * 36)>(p, acc, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel);
+    stamp(p, wave, lane, 4);
+}
+
+// ---- intra-workgroup split-K kernel ------------------------------------------------------------------------------------
+// Same 64x64 block tile, same grid, same epilogues as conv_gemm_kernel -- a different K loop.  Above, the four waves split the
+// tile 2x2 and share one LDS ring: one accumulator chain per wave (every MFMA waits for the wave's previous one), one
+// workgroup barrier per K-step, and a stall of any wave is a stall of all four.  Here every wave owns the WHOLE 64x64 tile over a
+// QUARTER of the K range: four independent accumulators (four MFMAs back to back per k-pair), a wave-private ring that the
+// wave fills for itself with the same buffer-addressed global -> LDS loads, and therefore no barrier in the loop at all -- a
+// wave waits only for its own loads (counted vmcnt).  Each k row is still fetched exactly once per workgroup, so the L2 -> LDS
+// traffic is unchanged.  After the loop the four partial tiles are exchanged through the (now free) rings: wave q ends up with
+// quadrant q summed over the waves in K order, i.e. exactly the register layout the shared epilogues expect.
+// One exchange round covers the quadrants [Q0, Q0 + NQ): wave W parks those it does not own, consecutively, in its own LDS region.
+constexpr int ks_slot(int w, int q0, int q)
+{   // slot of quadrant q in wave w's region: the quadrants of the round before q that w parks
+    int n = 0;
+    for (int x = q0; x < q; ++x)
+        if (x != w) ++n;
+    return n;
+}
+template <int W, int Q0, int NQ>
+__device__ __forceinline__ void ks_park(float* my, const v16f (&acc)[2][2], int lane)
+{
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+    for (int q = Q0; q < Q0 + NQ; ++q) {
+        if (q == W) continue;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __hip_atomic_store(slab + ((i * NJ + j) * 16 + r) * NT + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // write-through (agent-scope) stores, then only wait for them: a full __threadfence() would write back AND
-        // invalidate this XCD's whole L2 under the other resident workgroups (measured: 37 us per launch at 256 parts)
-        wait_vmcnt<0>();
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            const unsigned old = atomicAdd(p.tail_cnt + tail_t, 1u);
-            const int last = (old == (unsigned)(nparts - 1));
-            if (last) atomicExch(p.tail_cnt + tail_t, 0u);     // ready for the next launch on this stream
-            *flag = last;
-        }
-        __syncthreads();
-        if (!*flag) return;
-        const float* base = p.tail_ws + (long)tail_t * nparts * TILE_FLOATS;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float sum = 0.f;
-                    for (int q = 0; q < nparts; ++q)
-                        sum += __hip_atomic_load(base + (long)q * TILE_FLOATS + ((i * NJ + j) * 16 + r) * NT + tid,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc[i][j][r] = sum;
-                }
+        for (int r = 0; r < 16; ++r) my[(ks_slot(W, Q0, q) * 16 + r) * 64 + lane] = acc[q >> 1][q & 1][r];
     }
-
-    // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
-    // Optional fused micro-program (half 0 only): forward = bias -> [store raw] -> BatchNorm -> [+residual] -> ReLU;
-    // backward = [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP -> next GEMM's input.
-    if constexpr (CHAIN == 1) {
-        // compiled chain epilogue; launch_one only selects this instantiation when the float4 layout conditions hold.  The chain
-        // belongs to half 0; the relu(W) half of a dual launch (positive activations) leaves as plain dense rows.
-        if constexpr (MI == 1 && NJ == 1) {
-            if (half == 0)
-                chain_epilogue_dispatch<0>(p.chain_sig, p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
-                                           m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
-            else
-                dense_epilogue(p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32, m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
+}
+template <int W, int Q0>
+__device__ __forceinline__ void ks_gather(const float* smem, int wave_lds, const v16f (&acc)[2][2], int lane, v16f& out)
+{   // quadrant W summed over the waves in K order (wave 0 holds the lowest K rows)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            const float t = (w2 == W) ? acc[W >> 1][W & 1][r] : smem[w2 * wave_lds + (ks_slot(w2, Q0, W) * 16 + r) * 64 + lane];
+            sum = (w2 == 0) ? t : sum + t;
         }
-    } else if constexpr (CHAIN == 2) {
-        // Epilogue with a fused micro-program (backward: [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP ->
-        // the next GEMM's input).  The 16 accumulator registers of a 32x32 tile are 4 groups of 4 consecutive output
-        // channels; they are processed group by group, and all per-element operands of a group (plan in
-        // p.chain_ld, <= 4 distinct tensors) are in flight together before the steps are interpreted: every workgroup of
-        // a launch reaches its epilogue at the same time, so a chain of dependent loads here is paid in full.
-        const EwLoads& ld = p.chain_ld;
-        // float4 pieces need rows whose length is a multiple of 4 on both sides (gradient rows of out_nb images, forward
-        // rows of chain_B images); a piece may then straddle two samples (7x7 maps) but never a row
-        const bool vec_ok = MI == 1 && NJ == 1 && NST * STAGE >= 4 * 32 * 36 && (p.M & 3) == 0 &&
-                            ((p.chain_B * p.OH * p.OW) & 3) == 0 && ((p.out_nb * p.OH * p.OW) & 3) == 0;
-        if (vec_ok) {
-            // vector path: the tile is turned through LDS like in the plain epilogue, a lane then owns float4 pieces
-            // (one channel, four consecutive positions of one sample) and runs the same float4 interpreter as the
-            // stand-alone chain kernel, operands fetched as 16-byte loads
-            constexpr int LD = 36;
-            __syncthreads();
-            float* tile = smem + wave * (32 * LD);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = acc[0][0][r];
-            const int ohw = p.OH * p.OW;
-            const long row4 = (long)p.out_nb * ohw / 4, arow4 = (long)p.chain_B * ohw / 4;
-            const int mq = (lane & 7) * 4;
-            const int m = m0 + wcol * 32 + mq;
-            const int mm = m < p.M ? m : 0;
-            const int sb = mm / ohw;
-            const long acol4 = (mm % (p.chain_B * ohw)) / 4;
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4* out4 = reinterpret_cast<float4*>(osel);
-#pragma unroll
-            for (int hf = 0; hf < 4; ++hf) {
-                float4 g[1], od[1], v0[1], v1[1], v2[1], v3[1];
-                long idx4[1], aidx4[1];
-                bool ok[1];
-                int cos[1];
-#pragma unroll
-                for (int u = 0; u < 1; ++u) {
-                    const int cl = (hf + u) * 8 + (lane >> 3);
-                    cos[u] = co0 + wrow * 32 + cl;
-                    ok[u] = cos[u] < p.CoutTot && m < p.M;
-                    const int cc = ok[u] ? cos[u] : 0;
-                    idx4[u] = (long)cc * row4 + mm / 4;
-                    aidx4[u] = (long)cc * arow4 + acol4;
-                    g[u] = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
-                    v0[u] = v1[u] = v2[u] = v3[u] = od[u] = z4;
-                    if (ld.lp[0]) v0[u] = reinterpret_cast<const float4*>(ld.lp[0])[aidx4[u]];
-                    if (ld.lp[1]) v1[u] = reinterpret_cast<const float4*>(ld.lp[1])[aidx4[u]];
-                    if (ld.lp[2]) v2[u] = reinterpret_cast<const float4*>(ld.lp[2])[aidx4[u]];
-                    if (ld.lp[3]) v3[u] = reinterpret_cast<const float4*>(ld.lp[3])[idx4[u]];
-                    if (p.accumulate) od[u] = out4[idx4[u]];
-                    if (bsel && ok[u]) { const float b = bsel[cos[u]]; g[u].x += b; g[u].y += b; g[u].z += b; g[u].w += b; }
-                }
-#pragma unroll
-                for (int u = 0; u < 1; ++u)
-                    ew_interpret<false>(ok[u], idx4[u], aidx4[u], sb, 0, g[u], od[u], v0[u], v1[u], v2[u], v3[u], out4, p.accumulate,
-                                        p.chain, cos[u], p.chain_eps);
-            }
-        } else
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
-            if (m >= p.M) continue;
-            const int ohw = p.OH * p.OW;
-            const long col = m;                                   // chains are only fused into dense (out_stride 1) launches
-            const long row_stride = (long)p.out_nb * ohw;
-            const int sb = m / ohw;
-            const int hw = m - sb * ohw;
-            const long acol = (long)(sb % p.chain_B) * ohw + hw;
-            const long arow = (long)p.chain_B * ohw;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int hf = 0; hf < 4; ++hf) {
-                    float g[4], pv0[4], pv1[4], pv2[4], pv3[4];
-                    int gi[4], ai[4];
-                    bool ok[4];
-#pragma unroll
-                    for (int e8 = 0; e8 < 4; ++e8) {
-                        const int rg = hf, q = e8;
-                        const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
-                        ok[e8] = co < p.CoutTot;
-                        const int cc = ok[e8] ? co : 0;
-                        gi[e8] = (int)((long)cc * row_stride + col);
-                        ai[e8] = (int)((long)cc * arow + acol);
-                        pv0[e8] = pv1[e8] = pv2[e8] = pv3[e8] = 0.f;
-                    }
-#pragma unroll
-                    for (int e8 = 0; e8 < 4; ++e8) {
-                        if (ld.lp[0]) pv0[e8] = ld.lp[0][ld.lk[0] ? gi[e8] : ai[e8]];
-                        if (ld.lp[1]) pv1[e8] = ld.lp[1][ld.lk[1] ? gi[e8] : ai[e8]];
-                        if (ld.lp[2]) pv2[e8] = ld.lp[2][ld.lk[2] ? gi[e8] : ai[e8]];
-                        if (ld.lp[3]) pv3[e8] = ld.lp[3][ld.lk[3] ? gi[e8] : ai[e8]];
-                    }
-#pragma unroll
-                    for (int e8 = 0; e8 < 4; ++e8) {
-                        const int rg = hf, q = e8;
-                        const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
-                        float v = acc[i][j][rg * 4 + q];
-                        if (ok[e8]) {
-                            if (bsel) v += bsel[co];
-                            if (p.accumulate) v += osel[gi[e8]];
-                        }
-                        g[e8] = v;
-                    }
-#pragma unroll 1
-                    for (int sidx = 0; sidx < p.chain.n; ++sidx) {
-                        const EwStep& st = p.chain.s[sidx];
-                        const int type = st.type, s0 = st.ls0, s1 = st.ls1;
-                        if (type == EW_HOOK) {
-                            if (s0 == -2) {                      // p is not observed: relu(g) or the identity
-                                if (st.action == HOOK_RELU) {
-#pragma unroll
-                                    for (int e8 = 0; e8 < 4; ++e8) g[e8] = fmaxf(g[e8], 0.f);
-                                }
-                                continue;
-                            }
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                if (!ok[e8]) continue;
-                                const float a = fmaxf(s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]], 0.f);
-                                const float zh = fmaxf(g[e8], 0.f);
-                                const float pp = a * zh;
-                                if (st.pstore) st.pstore[gi[e8]] = pp;
-                                if (st.action == HOOK_DIV) {
-                                    const float x = st.p1 ? fmaxf(s1 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s1) : st.p1[ai[e8]], 0.f) : a;
-                                    g[e8] = __fdiv_rn(pp, x + p.chain_eps);
-                                } else if (st.action == HOOK_RELU) {
-                                    g[e8] = zh;
-                                }
-                            }
-                        } else if (type == EW_MASK) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                if (!ok[e8]) continue;
-                                const float t = s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]];
-                                g[e8] = t > 0.f ? g[e8] : 0.f;
-                            }
-                        } else if (type == EW_SCALE_C) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8)
-                                if (ok[e8]) g[e8] *= st.p0[co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8];
-                        } else if (type == EW_SCALE) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) g[e8] *= st.f;
-                        } else if (type == EW_STORE) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8)
-                                if (ok[e8]) st.pstore[gi[e8]] = g[e8];
-                        } else if (type == EW_ADDP) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8)
-                                if (ok[e8]) g[e8] += s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[gi[e8]];
-                        } else if (type == EW_AFFINE_C) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
-                                if (ok[e8]) g[e8] = __fadd_rn(__fmul_rn(g[e8], st.p0[co]), st.p1[co]);
-                            }
-                        } else if (type == EW_RELU) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) g[e8] = fmaxf(g[e8], 0.f);
-                        } else {   // EW_FORK_POSBN
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
-                                if (ok[e8]) st.pstore[gi[e8]] = __fadd_rn(__fmul_rn(fmaxf(g[e8], 0.f), st.p0[co]), st.p1[co]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int e8 = 0; e8 < 4; ++e8)
-                        if (ok[e8]) osel[gi[e8]] = g[e8];
-                }
-            }
-        }
-    } else if (MI == 1 && NJ == 1 && NST * STAGE >= 4 * 32 * 36 && p.out_stride == 1 && (p.M & 3) == 0 && ((p.out_nb * p.OH * p.OW) & 3) == 0) {
-        if constexpr (MI == 1 && NJ == 1)
-            dense_epilogue(p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32, m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
+        out[r] = sum;
+    }
+}
+// all four waves call this with their own W: the same number of barriers on every path
+template <int W, int WAVE_LDS>
+__device__ __forceinline__ void ks_exchange(float* smem, const v16f (&acc)[2][2], int lane, v16f& out)
+{
+    float* my = smem + W * WAVE_LDS;
+    if constexpr (WAVE_LDS >= 3 * 16 * 64) {
+        ks_park<W, 0, 4>(my, acc, lane);
+        __syncthreads();
+        ks_gather<W, 0>(smem, WAVE_LDS, acc, lane, out);
     } else {
+        // a region holds two quadrants: first the upper half of the tile (owners: waves 0 and 1), then the lower half
+        static_assert(WAVE_LDS >= 2 * 16 * 64, "the exchange needs room for two quadrants per wave");
+        ks_park<W, 0, 2>(my, acc, lane);
+        __syncthreads();
+        if constexpr (W < 2) ks_gather<W, 0>(smem, WAVE_LDS, acc, lane, out);
+        __syncthreads();
+        ks_park<W, 2, 2>(my, acc, lane);
+        __syncthreads();
+        if constexpr (W >= 2) ks_gather<W, 2>(smem, WAVE_LDS, acc, lane, out);
+    }
+}
+
+template <int BK, int NST, int MODE, bool RELU, int CHAIN>
+__global__ __launch_bounds__(NT, 3) void conv_gemm_ks_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
+{
+    static_assert(MODE == MODE_VEC || MODE == MODE_TAP, "the split-K kernel covers the 1x1 float4 path and the tap-major gather");
+    constexpr int TCO = 64, TM = 64;
+    constexpr int A_FLOATS = BK * TCO, B_FLOATS = BK * TM;
+    constexpr int STAGE = A_FLOATS + B_FLOATS;                            // per wave
+    constexpr int RING = NST * STAGE;
+    constexpr int WAVE_LDS = RING > 2 * 16 * 64 ? RING : 2 * 16 * 64;     // the ring also parks partial quadrants: all three, or two per round
+    constexpr int A_LOADS = A_FLOATS / 256;                               // 16-byte wave-loads (4 k rows x 64 co each)
+    constexpr int B_LOADS = (MODE == MODE_VEC) ? B_FLOATS / 256 : BK;     // 16-byte wave-loads | one 4-byte wave-load per k row
+    constexpr int L = A_LOADS + B_LOADS;
+    constexpr int NP = BK / 2 - 1;                                        // shares the loads of a K-step are issued in: one after every k-pair but the last
+    static_assert((NST - 2) * L <= 63, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    stamp(p, wave, lane, 0);
+
+    const int n_tiles_all = n_co_tiles * n_m_tiles;
+    int part, nparts, lid, tail_t = -1;
+    if (p.tail_s > 1) {
+        if ((int)blockIdx.x < p.tail_q) {
+            lid = xcd_remap(blockIdx.x, p.tail_q);
+            part = 0;
+            nparts = 1;
+        } else {
+            const int tb = blockIdx.x - p.tail_q;
+            tail_t = tb / p.tail_s;
+            part = tb - tail_t * p.tail_s;
+            nparts = p.tail_s;
+            lid = p.tail_q + tail_t;
+        }
+    } else {
+        lid = xcd_remap(blockIdx.x, n_tiles_all);
+        part = 0;
+        nparts = 1;
+    }
+    const int tile_m = lid / n_co_tiles;
+    const int tile_co_all = lid - tile_m * n_co_tiles;
+    const int n_co_half = n_co_tiles / p.nhalves;
+    const int half = tile_co_all / n_co_half;
+    const int tile_co = tile_co_all - half * n_co_half;
+    const int co0 = tile_co * TCO;
+    const int m0 = tile_m * TM;
+    const float* __restrict__ wsel = half ? p.w_pos : p.w;
+    const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
+    float* __restrict__ osel = half ? p.out1 : p.out0;
+
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt_lo = (int)((long)nk_all * part / nparts);
+    const int kt_hi = (int)((long)nk_all * (part + 1) / nparts);
+    // this wave's quarter of the block's K-steps
+    const int w_lo = kt_lo + (int)((long)(kt_hi - kt_lo) * wave / 4);
+    const int w_hi = kt_lo + (int)((long)(kt_hi - kt_lo) * (wave + 1) / 4);
+    const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, ((p.K + 31) / 32) * 32 * p.ldw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+
+    // ---- A side: load i covers k rows 4i .. 4i+3 of the step, lane -> (row 4i + lane/16, four co at (lane%16)*4)
+    unsigned voffA[A_LOADS];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
-            if (m >= p.M) continue;
-            long col;
-            long row_stride;
-            const int ohw = p.OH * p.OW;
-            if (p.out_stride == 1) {
-                col = m;
-                row_stride = (long)p.out_nb * ohw;
-            } else {
-                const int n = m / ohw;
-                const int r = m - n * ohw;
-                const int oh = r / p.OW;
-                const int ow = r - oh * p.OW;
-                col = ((long)n * p.out_H + (long)oh * p.out_stride) * p.out_W + (long)ow * p.out_stride;
-                row_stride = (long)p.out_nb * p.out_H * p.out_W;
+    for (int i = 0; i < A_LOADS; ++i) voffA[i] = (unsigned)((4 * i + (lane >> 4)) * p.ldw + co0 + (lane & 15) * 4) * 4u;
+    const unsigned a_step = (unsigned)BK * p.ldw * 4u;
+
+    // ---- B side
+    unsigned voffB[(MODE == MODE_VEC) ? B_LOADS : 1];
+    int base_m = 0;
+    unsigned long long tapmask = 0ull;
+    if (MODE == MODE_VEC) {
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int m = m0 + (lane & 15) * 4;
+            voffB[i] = (m < p.M) ? (unsigned)(4 * i + (lane >> 4)) * chan_bytes + (unsigned)m * 4u : OOB;
+        }
+    } else {
+        const int m = m0 + lane;
+        const bool m_ok = m < p.M;
+        const int mm = m_ok ? m : 0;
+        const int ohw = p.OH * p.OW;
+        const int n = mm / ohw;
+        const int r = mm - n * ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+        base_m = n * p.H * p.W + ih0 * p.W + iw0;
+        if (m_ok) {
+            for (int dh = 0; dh < p.kh; ++dh)
+                for (int dw = 0; dw < p.kw; ++dw)
+                    if ((unsigned)(ih0 + dh) < (unsigned)p.H && (unsigned)(iw0 + dw) < (unsigned)p.W) tapmask |= 1ull << (dh * p.kw + dw);
+        }
+        voffB[0] = OOB;
+    }
+    int iss_tap = 0, iss_ci0 = 0;     // (tap, first input channel) of the next K-step to be issued
+    if (MODE == MODE_TAP) { iss_tap = (w_lo * BK) / p.Cin; iss_ci0 = w_lo * BK - iss_tap * p.Cin; }
+    bool tap_dirty = true;
+
+    float* ring = smem + wave * WAVE_LDS;
+    // `share` < 0: all loads of the K-step; 0 .. NP-1: the share issued with that k-pair's MFMAs
+    auto issue = [&](int kt, int st, int share) {
+        auto mine = [&](int i, int n) { return share < 0 || (i * NP) / n == share; };
+        float* As = ring + st * STAGE;
+        float* Bs = As + A_FLOATS;
+        const bool live = kt < w_hi;      // steps past the end load nothing real (uniform vmcnt accounting)
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            if (mine(i, A_LOADS)) bload16(rW, As + i * 256, live ? voffA[i] : OOB, (unsigned)kt * a_step);
+        if (MODE == MODE_VEC) {
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i)
+                if (mine(i, B_LOADS)) bload16(rIn, Bs + i * 256, live ? voffB[i] : OOB, (unsigned)(kt * BK) * chan_bytes);
+        } else {
+            const int tap = iss_tap, ci0 = iss_ci0;
+            if (share <= 0 && tap_dirty) {            // wave-uniform: new tap => new per-lane shifted offset
+                tap_dirty = false;
+                const int dh = tap / p.kw, dw = tap - dh * p.kw;
+                voffB[0] = (live && ((tapmask >> tap) & 1ull)) ? (unsigned)(base_m + dh * p.W + dw) * 4u : OOB;
             }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wrow * (TCO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (co >= p.CoutTot) continue;
-                    const long gi = (long)co * row_stride + col;
-                    float v = acc[i][j][r];
-                    if (bsel) v += bsel[co];
-                    if (p.accumulate) v += osel[gi];
-                    osel[gi] = v;
-                }
+            for (int row = 0; row < B_LOADS; ++row)
+                if (mine(row, B_LOADS)) bload4(rIn, Bs + row * 64, live ? voffB[0] : OOB, (unsigned)(ci0 + row) * chan_bytes);
+            if (share < 0 || share == NP - 1) {
+                iss_ci0 += BK;
+                if (iss_ci0 >= p.Cin) { iss_ci0 = 0; iss_tap += 1; tap_dirty = true; }
+            }
         }
+    };
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(w_lo + s, s, -1);
+
+    // The loop is software-pipelined across K-steps: the loads of step kt+NST-1 are issued during the first NP-1 k-pairs of step
+    // kt, then -- before the LAST k-pair -- the wave waits for step kt+1 to have landed ((NST-2)*L younger loads may stay in
+    // flight) and reads that step's first fragments, so that neither the wait for the loads nor the LDS latency of a step's
+    // first read sits in front of an idle MFMA pipe.  The stage refilled during step kt is the one step kt-1 was read from: all
+    // its reads fed MFMAs that have been issued.  No barrier anywhere: the ring is this wave's own.
+    static_assert(NST >= 3, "the stage being refilled must not be the one read next");
+    int st = 0;
+    float a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];
+    wait_vmcnt<(NST - 2) * L>();
+    stamp(p, wave, lane, 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { a_cur[i] = ring[lhi * TCO + l31 + i * 32]; b_cur[i] = ring[A_FLOATS + lhi * TM + l31 + i * 32]; }
+    for (int kt = w_lo; kt < w_hi; ++kt) {
+        int st_fill = st + NST - 1;
+        if (st_fill >= NST) st_fill -= NST;
+        const int st_next = (st + 1 == NST) ? 0 : st + 1;
+        const float* As = ring + st * STAGE;
+        const float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a_nxt[i] = As[(kk + 2 + lhi) * TCO + l31 + i * 32]; b_nxt[i] = Bs[(kk + 2 + lhi) * TM + l31 + i * 32]; }
+            } else {
+                wait_vmcnt<(NST - 2) * L>();
+                const float* An = ring + st_next * STAGE;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a_nxt[i] = An[lhi * TCO + l31 + i * 32]; b_nxt[i] = An[A_FLOATS + lhi * TM + l31 + i * 32]; }
+            }
+            if (RELU) { b_cur[0] = fmaxf(b_cur[0], 0.f); b_cur[1] = fmaxf(b_cur[1], 0.f); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+            if (kk + 2 < BK) issue(kt + NST - 1, st_fill, kk / 2);
+            // order within the k-pair: the next pair's fragment reads first (they then have four MFMAs to land), the global
+            // loads between the MFMAs (issued while the pipe is busy)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, (L + NP - 1) / NP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a_cur[i] = a_nxt[i]; b_cur[i] = b_nxt[i]; }
+        }
+        st = st_next;
+        asm volatile("" ::: "memory");     // the fragment reads of the next step stay in this iteration
     }
+    wait_vmcnt<0>();   // the tail loads (nothing real) have landed: the ring is free
+    stamp(p, wave, lane, 2);
+
+    // ---- exchange: park the three foreign quadrants in the own ring, meet, gather the own quadrant in K order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    v16f accq[1][1];
+    if (wave == 0) ks_exchange<0, WAVE_LDS>(smem, acc, lane, accq[0][0]);
+    else if (wave == 1) ks_exchange<1, WAVE_LDS>(smem, acc, lane, accq[0][0]);
+    else if (wave == 2) ks_exchange<2, WAVE_LDS>(smem, acc, lane, accq[0][0]);
+    else ks_exchange<3, WAVE_LDS>(smem, acc, lane, accq[0][0]);
+    // the epilogues start with a workgroup barrier before they reuse the LDS (tail parts: before the arrival flag)
+    stamp(p, wave, lane, 3);
+    block_epilogue<CHAIN, true>(p, accq, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel);
+    stamp(p, wave, lane, 4);
 }
 
 int num_cus()
@@ -890,7 +1193,7 @@ int pick_tail_split(const ConvParams& p, int tiles, int nk, size_t tile_bytes)
 }
 
 template <int TCO, int TM, int BK, int NST, int MODE>
-void launch_one(const ConvParams& p, hipStream_t s)
+bool launch_one(const ConvParams& p, hipStream_t s)
 {
     const int n_co = ((p.CoutTot + TCO - 1) / TCO) * p.nhalves;
     const int n_m = (p.M + TM - 1) / TM;
@@ -919,30 +1222,94 @@ void launch_one(const ConvParams& p, hipStream_t s)
                                 ((q.out_nb * ohw) & 3) == 0;
             q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
             if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
-            if (q.nhalves == 2 && q.chain_sig < 0) { fprintf(stderr, "xfr_amd: a dual launch carries a chain without a compiled epilogue\n"); abort(); }
+            if (q.nhalves == 2 && q.chain_sig < 0) return false;      // a dual launch can only carry a compiled chain: the caller un-fuses
             g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
             if (q.chain_sig >= 0)
                 hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 1>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
             else
                 hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 2>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
-            return;
+            return true;
         }
     }
     if (p.relu_in)
         hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, true, 0>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
     else
         hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 0>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+    return true;
+}
+
+// the split-K kernel: same grid, tail split and chain selection as launch_one
+template <int BK, int NST, int MODE>
+bool launch_one_ks(const ConvParams& p, hipStream_t s)
+{
+    constexpr int TCO = 64, TM = 64;
+    const int n_co = ((p.CoutTot + TCO - 1) / TCO) * p.nhalves;
+    const int n_m = (p.M + TM - 1) / TM;
+    constexpr int RING = NST * BK * (TCO + TM);
+    const size_t lds = (size_t)4 * (RING > 2048 ? RING : 2048) * sizeof(float);
+    ConvParams q = p;
+    int grid = n_co * n_m;
+    q.tail_q = 0;
+    q.tail_s = 1;
+    {
+        const int S = pick_tail_split(p, n_co * n_m, (p.K + BK - 1) / BK, (size_t)TCO * TM * sizeof(float));
+        if (S > 1) {
+            const int r = (n_co * n_m) % num_cus();
+            q.tail_q = n_co * n_m - r;
+            q.tail_s = S;
+            grid = q.tail_q + r * S;
+        }
+    }
+    if (q.chain.n > 0) {
+        EwChain wide = q.chain;
+        EwLoads wide_ld;
+        ew_plan_loads(wide, q.out0, wide_ld, EW_FWD_SLOTS_WIDE);
+        ew_plan_loads(q.chain, q.out0, q.chain_ld);
+        const int ohw = q.OH * q.OW;
+        const bool vec_ok = (q.M & 3) == 0 && ((q.chain_B * ohw) & 3) == 0 && ((q.out_nb * ohw) & 3) == 0;
+        q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
+        if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
+        if (q.nhalves == 2 && q.chain_sig < 0) return false;      // a dual launch can only carry a compiled chain: the caller un-fuses
+        g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
+        if (q.chain_sig >= 0)
+            hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 1>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+        else
+            hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 2>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+        return true;
+    }
+    if (p.relu_in)
+        hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, true, 0>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+    else
+        hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 0>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+    return true;
+}
+
+// shapes the split-K kernel covers: the 1x1 float4 path and the tap-major gather with whole K-steps per tap
+template <int BK>
+bool ks_ok(const ConvParams& p)
+{
+    const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H && p.OW == p.W);
+    if (vec) return true;
+    return p.tap_major == 1 && (p.Cin % BK) == 0 && p.kh * p.kw <= 64;
+}
+
+template <int BK, int NST>
+bool launch_cfg_ks(const ConvParams& p, hipStream_t s)
+{
+    const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H && p.OW == p.W);
+    if (vec) return launch_one_ks<BK, NST, MODE_VEC>(p, s);
+    return launch_one_ks<BK, NST, MODE_TAP>(p, s);
 }
 
 template <int TCO, int TM, int BK, int NST>
-void launch_cfg(const ConvParams& p, hipStream_t s)
+bool launch_cfg(const ConvParams& p, hipStream_t s)
 {
     const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H && p.OW == p.W);
-    if (vec) launch_one<TCO, TM, BK, NST, MODE_VEC>(p, s);
-    else if (p.tap_major == 2) launch_one<TCO, TM, 16, 4, MODE_TAP4>(p, s);
-    else if (p.tap_major && (p.Cin % BK) == 0) launch_one<TCO, TM, BK, NST, MODE_TAP>(p, s);
-    else if (p.tap_major) launch_one<TCO, TM, 16, 4, MODE_TAP>(p, s);
-    else launch_one<TCO, TM, 16, 4, MODE_GEN>(p, s);
+    if (vec) return launch_one<TCO, TM, BK, NST, MODE_VEC>(p, s);
+    if (p.tap_major == 2) return launch_one<TCO, TM, 16, 4, MODE_TAP4>(p, s);
+    if (p.tap_major && (p.Cin % BK) == 0) return launch_one<TCO, TM, BK, NST, MODE_TAP>(p, s);
+    if (p.tap_major) return launch_one<TCO, TM, 16, 4, MODE_TAP>(p, s);
+    return launch_one<TCO, TM, 16, 4, MODE_GEN>(p, s);
 }
 
 }  // namespace
@@ -963,16 +1330,21 @@ int conv_gemm_chain_sig(const EwChain& ch)
 int conv_gemm_num_chain_sigs() { return kNumChainSigs; }
 void conv_gemm_chain_launch_counts(long* compiled, long* interpreted)
 {
-    if (compiled) *compiled = g_chain_launches[0];
-    if (interpreted) *interpreted = g_chain_launches[1];
+    if (compiled) *compiled = g_chain_launches[0].load();
+    if (interpreted) *interpreted = g_chain_launches[1].load();
 }
 
 int conv_gemm_pick_cfg(const ConvParams& p)
 {
     // Measured on MI355X over the ResNet-101 / ResNet-50 / Light-CNN GEMM shapes (M = 1.5k..400k, K = 64..4608,
     // Cout = 64..2048): the 64x64 tile wins or ties everywhere -- these grids are small (1-12 workgroups per CU), so
-    // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.  Deep-K
-    // launches of at most two tiles per CU (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers
+    // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.
+    // K >= 512: the intra-workgroup split-K kernel (tools/conv_sweep.py, round 3: +6..13 % on the 3x3 layers and the K = 512 /
+    // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
+    static const int ks = [] { const char* e = getenv("XFR_KS"); return e ? atoi(e) : 8; }();
+    static const int ks_mink = [] { const char* e = getenv("XFR_KS_MINK"); return e ? atoi(e) : 512; }();
+    if (ks >= 6 && ks <= 10 && p.K >= ks_mink && ks_ok<16>(p)) return ks;
+    // Deep-K launches of at most two tiles per CU (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers
     // per MFMA.  Their 48 KB ring allows three workgroups per CU, so larger grids (the W / relu(W) dual launch of the
     // same layer has twice the tiles) stay on the 24 KB ring where whole tiles and tail parts are all resident.
     const long tiles = (long)((p.CoutTot + 63) / 64) * p.nhalves * ((p.M + 63) / 64);
@@ -980,12 +1352,23 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     return 4;
 }
 
-void launch_conv_gemm(const ConvParams& p, hipStream_t s)
+static unsigned long long* g_stamps = nullptr;
+void conv_gemm_set_stamps(unsigned long long* dev_ptr) { g_stamps = dev_ptr; }
+
+bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
 {
+    ConvParams p = p_in;
+    p.stamps = g_stamps;
     // cfg 4: 64x64 tile, 16-deep K-steps, 3-stage ring (24 KB of LDS: 6 workgroups per CU, room for a second stream's
     // workgroups); cfg 5: 32-deep K-steps for deep-K launches of few tiles.  Larger tiles, deeper rings and split-K were
     // measured slower on every ResNet / Light-CNN shape and are not built.
     const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
-    if (cfg == 5) launch_cfg<64, 64, 32, 3>(p, s);
-    else launch_cfg<64, 64, 16, 3>(p, s);
+    // cfg 6..10: the intra-workgroup split-K kernel (BK, ring stages) = (8,3) (4,4) (4,5) (4,6) (16,3)
+    if (cfg == 6 && ks_ok<8>(p)) return launch_cfg_ks<8, 3>(p, s);
+    if (cfg == 7 && ks_ok<4>(p)) return launch_cfg_ks<4, 4>(p, s);
+    if (cfg == 8 && ks_ok<4>(p)) return launch_cfg_ks<4, 5>(p, s);
+    if (cfg == 9 && ks_ok<4>(p)) return launch_cfg_ks<4, 6>(p, s);
+    if (cfg == 10 && ks_ok<16>(p)) return launch_cfg_ks<16, 3>(p, s);
+    if (cfg == 5) return launch_cfg<64, 64, 32, 3>(p, s);
+    return launch_cfg<64, 64, 16, 3>(p, s);
 }

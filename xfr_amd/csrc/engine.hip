@@ -216,7 +216,7 @@ struct xfr_engine {
     // triplet call i+1 may run while the backward sweep of call i still reads slot i%2
     bool pipeline = false;
     bool pipeline_all = false;     // level 2: xfr_ebp / xfr_contrastive calls are pipelined too
-    bool inputs_ready = false;     // xfr_engine_set_inputs_ready: level-2 calls may read x_dev without waiting for the caller's stream
+    bool inputs_ready = false;     // xfr_engine_set_inputs_ready: the NEXT level-2 call may read x_dev without waiting for the caller's stream (one-shot)
     int cur_slot = 0;
     long seq = 0;
     float* ws2 = nullptr;
@@ -565,11 +565,12 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
         e->ev_params[e->ev_used] = p;
         auto& ev = e->ev_pool[e->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, s));
-        launch_conv_gemm(p, s);
+        const bool launched = launch_conv_gemm(p, s);
         HIP_TRY(hipEventRecord(ev.second, s));
+        if (!launched) return fail(XFR_STATE_ERROR, "a dual convolution launch carries a fused chain without a compiled epilogue");
         e->prof_flops += 2.0 * (double)(p.K_logical ? p.K_logical : p.K) * (double)p.M * (double)p.CoutTot * (double)p.nhalves;
-    } else {
-        launch_conv_gemm(p, s);
+    } else if (!launch_conv_gemm(p, s)) {
+        return fail(XFR_STATE_ERROR, "a dual convolution launch carries a fused chain without a compiled epilogue");
     }
     return XFR_OK;
 }
@@ -1397,7 +1398,10 @@ xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_te
     e->cur_slot = pipe ? (int)(e->seq++ & 1) : 0;
     const int slot = e->cur_slot;
     if (pipe && e->slot_pending[slot]) HIP_TRY(hipStreamWaitEvent(sf, e->ev_slot_done[slot], 0));
-    if (pipe && !e->inputs_ready) {
+    // the promise covers ONE call: a caller that forgets to renew it falls back to the safe ordering, never to a stale promise
+    const bool ready = e->inputs_ready;
+    e->inputs_ready = false;
+    if (pipe && !ready) {
         // x_dev may still be pending on the caller's stream (a cast, a copy): order the internal forward after it.  Callers
         // whose inputs are resident declare it with xfr_engine_set_inputs_ready and keep the cross-call overlap.
         HIP_TRY(hipEventRecord(e->ev_fork, s));
@@ -2181,6 +2185,12 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     (void)hipFree(tws);
     if (bd) (void)hipFree(bd);
     HIP_TRY(hipGetLastError());
+    return XFR_OK;
+}
+
+xfr_status xfr_debug_conv_stamps(void* stamps_dev)
+{
+    conv_gemm_set_stamps(reinterpret_cast<unsigned long long*>(stamps_dev));
     return XFR_OK;
 }
 

@@ -112,8 +112,9 @@ class Engine(object):
         return y, fresh
 
     def _declare_ready(self, ready):
-        """Pipeline level 2: tell the engine whether the next ebp / contrastive call may read x without waiting for the
-        caller's stream (xfr_engine_set_inputs_ready)."""
+        """Pipeline level 2: tell the engine whether the NEXT ebp / contrastive call may read x without waiting for the
+        caller's stream (xfr_engine_set_inputs_ready; the engine consumes the promise with that call, so ebp_capture /
+        ebp_firing / layerwise, which never declare anything, always take the safe ordering)."""
         if self._pipeline >= 2:
             _lib.check(self.lib.xfr_engine_set_inputs_ready(self._h, 1 if ready else 0))
 

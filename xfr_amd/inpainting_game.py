@@ -8,8 +8,9 @@
                                      device, topk=1)                                                 :119-205
 
 Images are what `xfr.utils.image_loader` yields (H x W x 3 float in [0, 1]) or uint8 arrays; `wb` is an
-xfr_amd.models.whitebox.Whitebox.  Difference in execution, not in results: the k mate and k non-mate images are encoded as
-one batch instead of one forward each.  `net_name` is accepted for signature compatibility and unused, as in the reference.
+xfr_amd.models.whitebox.Whitebox.  The drop-in functions encode the k mate and k non-mate images one forward at a time like
+the reference (ENCODE_ONE_BY_ONE below), so they reproduce its arithmetic; run_jobs_batched is the fast, additive path that
+batches the encodes.  `net_name` is accepted for signature compatibility and unused, as in the reference.
 """
 import torch
 
@@ -20,9 +21,10 @@ SUBTREE_VERSIONS = {7: (True, True), 8: (False, True), 9: (True, False), 10: (Tr
 
 # The reference encodes the k images one forward at a time (:85-92).  Batching them changes the fp32 summation order of the
 # convolutions, i.e. the encodings in their last bits (2e-8 measured on the CPU path) -- harmless, except that with nearly
-# parallel mate / non-mate directions contrastive EBP amplifies classifier perturbations by ~5e4 (tests/test_c2.py).  Set to
-# True to reproduce the reference's forward-by-forward arithmetic exactly.
-ENCODE_ONE_BY_ONE = False
+# parallel mate / non-mate directions contrastive EBP amplifies classifier perturbations by ~5e4 (tests/test_c2.py).  The
+# drop-in callers therefore default to the reference's forward-by-forward arithmetic; set to False to encode each gallery as one
+# batch (run_jobs_batched always batches).
+ENCODE_ONE_BY_ONE = True
 
 
 def mean_encoding(wb, images, device):
@@ -71,8 +73,10 @@ def run_weighted_subtree_triplet_ebp(wb, im_mates, im_nonmates, probe_im, net_na
 
 def run_jobs_batched(wb, jobs, net_name, subtree_mode_weighted, ebp_version, device, topk=32, methods=None, timings=None):
     """Additive: the four saliency methods of generate_wb_smaps (:295-399) for a GROUP of independent jobs in shared launches.
-    jobs: list of (im_mates, im_nonmates, probe_im).  Per job the same calls as mean_ebp, run_contrastive_triplet_ebp
-    (truncate_percent None and 20) and run_weighted_subtree_triplet_ebp above; here all probes form one batch, all mate /
+    jobs: list of (im_mates, im_nonmates, probe_im).  Per job the calls of mean_ebp (always over the HOOKED N-way classifier,
+    which is what the generator's job loop has installed at that point; the drop-in mean_ebp uses whatever classifier is
+    current), run_contrastive_triplet_ebp (truncate_percent None and 20) and run_weighted_subtree_triplet_ebp above, with the
+    galleries encoded as batches (last-bit differences in the encodings, see ENCODE_ONE_BY_ONE); here all probes form one batch, all mate /
     non-mate images one encode batch, and each method one (or a few) engine calls: Whitebox.ebp at N probes,
     contrastive_triplet_ebp_batch, weighted_subtree_ebp_batch.  Returns {method: [map per job]} with the method keys
     'meanEBP', 'contrastive', 'truncated', 'weighted-subtree'.  Needs the hooked classifier for meanEBP (restored afterwards)
@@ -94,10 +98,12 @@ def run_jobs_batched(wb, jobs, net_name, subtree_mode_weighted, ebp_version, dev
     out = {}
     saved = wb.net._classifier
     if 'meanEBP' in methods:
-        wb.net._classifier = None
-        m = wb.ebp(probes, torch.ones((1, wb.net.num_classes())))
+        wb.net._classifier = None       # the hooked N-way classifier (mean_ebp above uses whatever classifier is current)
+        try:
+            m = wb.ebp(probes, torch.ones((1, wb.net.num_classes())))
+        finally:
+            wb.net._classifier = saved
         out['meanEBP'] = list(m.reshape((n,) + m.shape[-2:]))
-        wb.net._classifier = saved
         lap('meanEBP')
     if len(set(methods) - {'meanEBP'}) == 0:
         return out

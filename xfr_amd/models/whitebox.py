@@ -479,7 +479,7 @@ class Whitebox(object):
             w, idx = eng.subtree_weights(x, seed_tensor, torch.stack((s0, s1), dim=0), gate_ge0=do_mated_similarity_gating)
             nf = w.shape[0]
             vals = np.asarray(eng.ebp_capture(x, seed_tensor, sk.unsqueeze(0), idx)).reshape(nf, n)
-            order = [np.argsort(w[:, b]) for b in range(n)]                     # ascending (:697)
+            order = [np.argsort(w[:, b].astype(np.float64)) for b in range(n)]  # ascending (:697); float64 like the reference's list of Python floats (ties)
             J = int(sweep_batch or max(1, min((2 * eng.max_batch) // n, max(8, 2 * topk))))
             pos = [nf] * n
             valid = [[] for _ in range(n)]                                      # per probe: (k, P on the device), heaviest first
