@@ -218,6 +218,7 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--serial', action='store_true', help='run every step on ONE stream with per-GEMM HIP events (what the roofline figure is measured on); use under rocprofv3 so that kernel durations are not inflated by concurrent streams')
     ap.add_argument('--no-pipeline', action='store_true', help='do not overlap step i+1 forwards with step i backward')
+    ap.add_argument('--lanes', type=int, default=2, help='engines that take consecutive steps in turn, each on its own stream (xfr_amd.engine.EngineLanes); 1 = one engine')
     ap.add_argument('--profile-csv', default=None, help='with --serial: append one record per GEMM launch to this file (profiles/layer_table.py)')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 10 s sustained loop after the timed region')
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
@@ -270,8 +271,24 @@ def main():
     mates, nonmates, probes = imgs[0:B].to(dev), imgs[B:2 * B].to(dev), imgs[2 * B:3 * B].to(dev)
     gallery = torch.cat((mates, nonmates), dim=0)      # [2B,3,224,224] resident in HBM
 
+    lanes = None
+    if args.lanes > 1 and not args.serial and not args.no_pipeline:
+        # consecutive steps go to independent engines on their own streams: step i+1 fills the ramps of step i
+        from xfr_amd.engine import EngineLanes
+        lanes = EngineLanes.__new__(EngineLanes)
+        others = [Engine(wbn._program, 2 * B, dev) for _ in range(args.lanes - 1)]
+        lanes.engines = [eng] + others
+        lanes.device, lanes.program, lanes.max_batch, lanes._next = eng.device, wbn._program, 2 * B, 0
+        lanes.streams = [torch.cuda.Stream(device=dev) for _ in lanes.engines]
+        lanes.share_weights()
+        for e2 in others:
+            e2.set_mode(args.mode)
+            e2.set_pipeline(True)
+
     def step():
         # encode(mates), encode(nonmates); set_triplet_classifier(x_mate/2500, x_nonmate/2500); contrastive_ebp(probe,0,1)
+        if lanes is not None:
+            return lanes.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, None, inputs_ready=True)
         return eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, None, inputs_ready=True)
 
     def barrier():

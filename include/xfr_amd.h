@@ -303,7 +303,8 @@ xfr_status xfr_engine_get_trace(xfr_engine* e, double* sums, int32_t* kinds, int
 /* Test / tuning hook: one forward convolution through the engine's implicit-GEMM kernel, outside any engine.
  * in_dev/out_dev are CNHW device tensors ([C][NB][H][W]); w_host/bias_host are PyTorch-layout host arrays.
  * cfg % 100: 0 lets the launcher pick the tile configuration, 4 / 5 force the 16- / 32-deep 64x64 configuration;
- * cfg / 10000: tail balancing 0 = heuristic, 1 = off, S >= 2 = S parts per tail tile.  The kernel is run
+ * (cfg / 10000) % 100: tail balancing 0 = heuristic, 1 = off, S >= 2 = S parts per tail tile; cfg / 1000000 = n in 2..4: the
+ * launches go to n streams at once (aggregate rate of co-running launches; *ms_out is then the time per launch).  The kernel is run
  * `reps` times after one untimed launch; *ms_out receives the average duration (HIP events on the null stream). */
 xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float* bias_host, float* out_dev, int32_t cin,
                           int32_t h, int32_t w, int32_t nb, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
@@ -311,9 +312,16 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
 
 /* Tuning hook: while stamps_dev is non-NULL, every GEMM launch of this process records, per wave, 8 64-bit words at
  * stamps_dev[(block * 4 + wave) * 8]: s_memrealtime (100 MHz) at kernel entry / first operands landed / K loop done / epilogue entered / exit,
- * then HW_ID, XCC_ID, block index (tools/conv_sweep.py --stamps draws a launch's timeline from them).  The buffer must hold
+ * then HW_ID, XCC_ID, and the wave's life in shader-clock cycles (s_memtime; with the 100 MHz stamps: the effective clock) (tools/conv_sweep.py --stamps draws a launch's timeline from them).  The buffer must hold
  * 32 words per workgroup of the largest grid launched.  NULL switches it off (the default). */
 xfr_status xfr_debug_conv_stamps(void* stamps_dev);
+
+/* Tuning hook: a timeline of the GEMM launches as the device ran them, streams overlapped.  While log_dev is non-NULL (zero-filled
+ * device memory, 16 bytes per launch, `capacity` launches), every GEMM launch of this process records when its first workgroup
+ * started and its last one ended (s_memrealtime, 10 ns ticks) and the library notes its shape, stream and tile configuration.  A
+ * call with dump_path != NULL first writes what has been recorded so far as CSV (synchronise the device before); log_dev = NULL
+ * stops recording.  tools/gemm_timeline.py reads the file. */
+xfr_status xfr_debug_conv_log(void* log_dev, int32_t capacity, const char* dump_path);
 
 /* Bytes of device memory held by the engine (weights + workspace). */
 xfr_status xfr_engine_memory(xfr_engine* e, size_t* weight_bytes, size_t* workspace_bytes);

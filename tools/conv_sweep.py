@@ -45,6 +45,7 @@ def stamp_report(lib, _lib, torch, dev, a, cfg, ms_ref):
     _lib.check(lib.xfr_debug_conv_stamps(None))
     v = st.cpu().numpy().reshape(nwg, 4, 8)
     used = v[:, 0, 0] != 0
+    bidx = np.nonzero(used)[0]
     v = v[used]
     n = v.shape[0]
     xcc = v[:, 0, 6] & 15
@@ -75,6 +76,16 @@ def stamp_report(lib, _lib, torch, dev, a, cfg, ms_ref):
     cu_n = np.array([len(ix) for ix in per.values()])
     lines.append('      per CU: workgroups min/median/max %d/%d/%d; last end p10/50/90/100 %.1f/%.1f/%.1f/%.1f us' % (
         cu_n.min(), np.median(cu_n), cu_n.max(), *np.percentile(cu_end, [10, 50, 90, 100])))
+    late = np.argsort(-ends)[:6]
+    for i in late:
+        lines.append('      straggler block %d: start %.1f prologue %.1f K loop %.1f exchange %.1f epilogue %.1f end %.1f us' % (
+            bidx[i], t[i, 0, 0] * tick_us, (t[i, :, 1] - t[i, :, 0]).max() * tick_us, (t[i, :, 2] - t[i, :, 1]).max() * tick_us,
+            (t[i, :, 3] - t[i, :, 2]).max() * tick_us, (t[i, :, 4] - t[i, :, 3]).max() * tick_us, ends[i]))
+    life = t[:, 0, 4] - t[:, 0, 0]
+    okl = (t[:, 0, 4] > 0) & (life > 500)              # lives of at least 5 us: the 10 ns stamp resolution is then < 0.2 %
+    if okl.any():
+        ghz = v[okl][:, 0, 7].astype(np.float64) / (life[okl] * 10.0)
+        lines.append('      effective shader clock over a workgroup\'s life (s_memtime / s_memrealtime): p10/50/90 %.3f/%.3f/%.3f GHz' % tuple(np.percentile(ghz, [10, 50, 90])))
     if os.environ.get('XFR_STAMP_RAW'):
         lines.append('      raw wg0: %s' % v[0].tolist())
         lines.append('      raw wg1: %s' % v[1].tolist())

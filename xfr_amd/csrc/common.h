@@ -25,7 +25,13 @@ enum {
     EW_ADDP = 5,      // g += p0[g]                                 (gradient fan-in / residual add)
     EW_AFFINE_C = 6,  // g = g*p0[c] + p1[c]                        (eval BatchNorm forward)
     EW_RELU = 7,      // g = max(g, 0)
-    EW_FORK_POSBN = 8 // pstore[g] = max(g,0)*p0[c] + p1[c]         (positive-pass BatchNorm output, g unchanged)
+    EW_FORK_POSBN = 8,// pstore[g] = max(g,0)*p0[c] + p1[c]         (positive-pass BatchNorm output, g unchanged)
+    EW_MAXHALF_IN = 9,// chain HEAD only (stand-alone kernels): the VJP of torch.max(split[0], split[1]) (lightcnn.py:62).  The chain runs
+                      // over the 2*Co-channel Split tensor, the source gradient has Co channels: g = src[c % Co], routed by the true
+                      // forward halves a = p0[c % Co], b = p0[c % Co + Co] (ties split evenly like at::maximum); action = Co
+    EW_MAXPAIR = 10   // GEMM epilogue only, last step: g = max(g, value of the partner row c ^ 1) -- MaxFeatureMap of a convolution
+                      // whose output channels were packed interleaved (row 2c = channel c, row 2c+1 = channel c + Co); the even
+                      // rows then store g as channel c of the Co-channel output
 };
 enum { HOOK_DIV = 0, HOOK_RELU = 1, HOOK_PASS = 2 };
 enum { PRIOR_DIV = 0, PRIOR_PASS = 1, PRIOR_GATEZ = 2 };   // p/(x+eps) | gradient unchanged | (prior>0)*z
@@ -213,10 +219,17 @@ struct ConvParams {
     EwLoads chain_ld;   // its operand prefetch plan (set by launch_conv_gemm)
     int chain_sig;      // index of the chain's compiled epilogue (chain_sigs.inc), -1: interpreted (set by launch_conv_gemm)
     int chain_interpret; // 1: run the chain through the interpreted epilogue even if a compiled one exists (tests)
+    int prio_round;      // > 0: wave priority by dispatch round -- workgroup b runs at priority 3 - min(b / prio_round, 3) (0: all equal)
     unsigned long long* stamps;   // tuning hook (xfr_debug_conv_stamps): per wave 8 words -- s_memrealtime at kernel entry, first operands landed,
-                                  // K loop done, epilogue entered, exit; HW_ID; XCC_ID; blockIdx.  nullptr: off
+                                  // K loop done, epilogue entered, exit; HW_ID; XCC_ID; life in shader cycles.  nullptr: off
+    unsigned long long* span;     // tuning hook (xfr_debug_conv_log): two words of THIS launch -- max over workgroups of ~entry time and of exit time
+                                  // (s_memrealtime), i.e. when the launch really started and ended next to the other streams' launches
 };
-void conv_gemm_set_stamps(unsigned long long* dev_ptr);   // every later launch_conv_gemm records into dev_ptr (nullptr: stop)
+void conv_gemm_set_stamps(unsigned long long* dev_ptr);
+// launch log: every later launch_conv_gemm takes the next two-word record of log_dev (capacity records) and notes its shape and
+// stream on the host; conv_gemm_dump_log writes one CSV line per launch (seq, stream, shape, cfg, start and end in 10 ns ticks)
+void conv_gemm_set_log(unsigned long long* log_dev, int capacity);
+int conv_gemm_dump_log(const char* path);   // every later launch_conv_gemm records into dev_ptr (nullptr: stop)
 
 constexpr int XFR_TAIL_MAX_TILES = 256;
 constexpr size_t XFR_TAIL_WS_BYTES = (size_t)16 << 20;

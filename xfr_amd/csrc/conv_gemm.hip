@@ -30,6 +30,7 @@
 // no per-element address arithmetic and no branches.
 #include <algorithm>
 #include <atomic>
+#include <vector>
 #include "common.h"
 #include "ew_interp.h"
 #include <cstdio>
@@ -80,8 +81,14 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int wave, int lane, i
         if (slot == 0) {
             q[5] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);       // HW_REG_HW_ID
             q[6] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);       // HW_REG_XCC_ID
-            q[7] = blockIdx.x;
+            q[7] = __builtin_amdgcn_s_memtime();                        // shader-clock counter (per XCD): entry ...
         }
+        if (slot == 4) q[7] = __builtin_amdgcn_s_memtime() - q[7];      // ... to exit: shader cycles of this wave's life
+    }
+    // a sample of the workgroups reports (one atomic per workgroup on one address costs ~12 ns each: 30 us for a 3000-tile grid)
+    if (p.span && lane == 0 && wave == 0 && ((slot == 0 && blockIdx.x == 0) || (slot == 4 && ((blockIdx.x & 15) == 0 || blockIdx.x == gridDim.x - 1)))) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        atomicMax(p.span + (slot == 0 ? 0 : 1), slot == 0 ? ~t : t);
     }
 }
 
@@ -607,6 +614,14 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     const int wrow = wave >> 1, wcol = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     stamp(p, wave, lane, 0);
+    if (p.prio_round > 0) {
+        // staggered finish: the first round of workgroups on every CU outranks the second, the second the third (and the tail parts,
+        // dispatched last, rank with the first round: their tile's last arriver waits for them)
+        const int rnd = (p.tail_s > 1 && (int)blockIdx.x >= p.tail_q) ? 0 : (int)blockIdx.x / p.prio_round;
+        if (rnd == 0) __builtin_amdgcn_s_setprio(3);
+        else if (rnd == 1) __builtin_amdgcn_s_setprio(2);
+        else if (rnd == 2) __builtin_amdgcn_s_setprio(1);
+    }
 
     // n_co_tiles counts the tiles of BOTH halves of a dual launch (half 1 = relu(W) -> positive activations)
     const int n_tiles_all = n_co_tiles * n_m_tiles;
@@ -961,6 +976,14 @@ __global__ __launch_bounds__(NT, 3) void conv_gemm_ks_kernel(const ConvParams p,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
     stamp(p, wave, lane, 0);
+    if (p.prio_round > 0) {
+        // staggered finish: the first round of workgroups on every CU outranks the second, the second the third (and the tail parts,
+        // dispatched last, rank with the first round: their tile's last arriver waits for them)
+        const int rnd = (p.tail_s > 1 && (int)blockIdx.x >= p.tail_q) ? 0 : (int)blockIdx.x / p.prio_round;
+        if (rnd == 0) __builtin_amdgcn_s_setprio(3);
+        else if (rnd == 1) __builtin_amdgcn_s_setprio(2);
+        else if (rnd == 2) __builtin_amdgcn_s_setprio(1);
+    }
 
     const int n_tiles_all = n_co_tiles * n_m_tiles;
     int part, nparts, lid, tail_t = -1;
@@ -1341,9 +1364,15 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.
     // K >= 512: the intra-workgroup split-K kernel (tools/conv_sweep.py, round 3: +6..13 % on the 3x3 layers and the K = 512 /
     // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
-    static const int ks = [] { const char* e = getenv("XFR_KS"); return e ? atoi(e) : 8; }();
+    static const int ks = [] { const char* e = getenv("XFR_KS"); return e ? atoi(e) : 7; }();
     static const int ks_mink = [] { const char* e = getenv("XFR_KS_MINK"); return e ? atoi(e) : 512; }();
-    if (ks >= 6 && ks <= 10 && p.K >= ks_mink && ks_ok<16>(p)) return ks;
+    static const int ks_rule = [] { const char* e = getenv("XFR_KS_RULE"); return e ? atoi(e) : 1; }();
+    if (ks >= 6 && ks <= 10 && p.K >= ks_mink && ks_ok<16>(p)) {
+        // rule 1: only where the in-engine serial table shows a gain (tools/cmp_layers.py): deep-K 3x3 (ResNet layers 3 / 4: -4..-12 %)
+        // and the 1x1 layers with K = 512 or K >= 2048 (-3..-14 %); K = 1024 loses 4 %.  The choice depends on the LAYER only, never on
+        // the batch: the two kernels sum K in different orders, and a sample's map must not depend on how many samples share its launch
+        if (ks_rule == 0 || (p.kh > 1 && p.K >= 2048) || (p.kh == 1 && (p.K == 512 || p.K >= 2048))) return ks;
+    }
     // Deep-K launches of at most two tiles per CU (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers
     // per MFMA.  Their 48 KB ring allows three workgroups per CU, so larger grids (the W / relu(W) dual launch of the
     // same layer has twice the tiles) stay on the 24 KB ring where whole tiles and tail parts are all resident.
@@ -1355,13 +1384,45 @@ int conv_gemm_pick_cfg(const ConvParams& p)
 static unsigned long long* g_stamps = nullptr;
 void conv_gemm_set_stamps(unsigned long long* dev_ptr) { g_stamps = dev_ptr; }
 
+namespace {
+struct LogRec { void* stream; int cout, nhalves, K, M, kh, chain, cfg; };
+unsigned long long* g_log = nullptr;
+int g_log_cap = 0;
+std::vector<LogRec> g_log_recs;
+}
+void conv_gemm_set_log(unsigned long long* log_dev, int capacity)
+{
+    g_log = log_dev;
+    g_log_cap = log_dev ? capacity : 0;
+    g_log_recs.clear();
+}
+int conv_gemm_dump_log(const char* path)
+{
+    const size_t n = g_log_recs.size();
+    std::vector<unsigned long long> h(2 * n + 2);
+    if (n && hipMemcpy(h.data(), g_log, 2 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    FILE* f = fopen(path, "w");
+    if (!f) return -1;
+    fprintf(f, "seq,stream,Cout,nhalves,K,M,kh,chain,cfg,start_10ns,end_10ns\n");
+    for (size_t i = 0; i < n; ++i) {
+        const LogRec& r = g_log_recs[i];
+        fprintf(f, "%zu,%p,%d,%d,%d,%d,%d,%d,%d,%llu,%llu\n", i, r.stream, r.cout, r.nhalves, r.K, r.M, r.kh, r.chain, r.cfg, ~h[2 * i], h[2 * i + 1]);
+    }
+    fclose(f);
+    return (int)n;
+}
+
 bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
     p.stamps = g_stamps;
-    // cfg 4: 64x64 tile, 16-deep K-steps, 3-stage ring (24 KB of LDS: 6 workgroups per CU, room for a second stream's
-    // workgroups); cfg 5: 32-deep K-steps for deep-K launches of few tiles.  Larger tiles, deeper rings and split-K were
-    // measured slower on every ResNet / Light-CNN shape and are not built.
+    p.span = nullptr;
+    static const int prio = [] { const char* e = getenv("XFR_PRIO"); return e ? atoi(e) : 0; }();
+    p.prio_round = prio ? num_cus() * prio : 0;
+    if (g_log && (int)g_log_recs.size() < g_log_cap) {
+        p.span = g_log + 2 * g_log_recs.size();
+        g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
+    }
     const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
     // cfg 6..10: the intra-workgroup split-K kernel (BK, ring stages) = (8,3) (4,4) (4,5) (4,6) (16,3)
     if (cfg == 6 && ks_ok<8>(p)) return launch_cfg_ks<8, 3>(p, s);

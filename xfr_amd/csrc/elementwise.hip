@@ -51,7 +51,14 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
             const int hw = (int)(r - (long)sb * HW);
             const int b = sb % B;
             aidx = ((long)c * B + b) * HW + hw;
-            g = src[idx];
+            if (ch.n > 0 && ch.s[0].type == EW_MAXHALF_IN) {
+                const int Co = ch.s[0].action, cs = c % Co;
+                const long arow = (long)B * HW, apos = (long)b * HW + hw;
+                const float a = ch.s[0].p0[(long)cs * arow + apos], bb = ch.s[0].p0[(long)(cs + Co) * arow + apos];
+                g = ew_maxhalf_route(src[(long)cs * per_c + r], c < Co ? a : bb, c < Co ? bb : a);
+            } else {
+                g = src[idx];
+            }
         }
 #pragma unroll 1
         for (int i = 0; i < ch.n; ++i) {
@@ -110,6 +117,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 else if (st.type == EW_ADDP) g += st.p0[idx];
                 else if (st.type == EW_AFFINE_C) g = __fadd_rn(__fmul_rn(g, st.p0[c]), st.p1[c]);
                 else if (st.type == EW_RELU) g = fmaxf(g, 0.f);
+                else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR) { }      // applied at the load / compiled epilogues only
                 else st.pstore[idx] = __fadd_rn(__fmul_rn(fmaxf(g, 0.f), st.p0[c]), st.p1[c]);
             }
         }
@@ -145,6 +153,18 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
     if (ld.lp[2]) s2 = reinterpret_cast<const float4*>(ld.lp[2])[aidx];
     unsigned b = 0, hw = pos;
     if (PRIOR || SBa < SB) { b = pos / (unsigned)HW4; hw = pos - b * (unsigned)HW4; }
+    // chain head EW_MAXHALF_IN: the true forward halves of this position, shared by the gradient streams
+    const bool head_maxhalf = ch.n > 0 && ch.s[0].type == EW_MAXHALF_IN;
+    int cs = c;
+    float4 own = z4, oth = z4;
+    if (head_maxhalf) {
+        const int Co = ch.s[0].action;
+        cs = c % Co;
+        const float4* tin = reinterpret_cast<const float4*>(ch.s[0].p0);
+        const float4 ta = tin[(long)cs * per_ca + pos], tb = tin[(long)(cs + Co) * per_ca + pos];
+        own = c < Co ? ta : tb;
+        oth = c < Co ? tb : ta;
+    }
     float4 g[SG], od[SG], v3[SG];
     long idx[SG];
     int sb[SG];
@@ -155,7 +175,13 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
         sb[u] = (int)(st * (unsigned)B + b);
         ok[u] = st * (unsigned)B < (unsigned)SB && sb[u] < SBa;
         idx[u] = (long)c * per_c + (ok[u] ? st * per_ca + pos : pos);
-        g[u] = src[idx[u]];
+        if (head_maxhalf) {
+            const float4 gs = src[idx[u] - (long)(c - cs) * per_c];           // the Co-channel gradient, row c % Co
+            g[u] = make_float4(ew_maxhalf_route(gs.x, own.x, oth.x), ew_maxhalf_route(gs.y, own.y, oth.y),
+                               ew_maxhalf_route(gs.z, own.z, oth.z), ew_maxhalf_route(gs.w, own.w, oth.w));
+        } else {
+            g[u] = src[idx[u]];
+        }
         v3[u] = z4;
         if (ld.lp[3]) v3[u] = reinterpret_cast<const float4*>(ld.lp[3])[idx[u]];
         od[u] = z4;

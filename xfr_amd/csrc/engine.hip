@@ -1015,7 +1015,17 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan, bool plain)
                 target(d.in0, st); target(d.in1, st); break;
             case XFR_OP_CONCAT:
                 st.kind = ST_COPY; st.copy_elems_per_sb = e->tens[d.in0].C; target(d.in0, st); break;
-            case XFR_OP_G_MAXHALVES: st.kind = ST_MAXHALVES_BWD; target(d.in0, st); break;
+            case XFR_OP_G_MAXHALVES: {
+                // the VJP of max(split[0], split[1]) as the HEAD of an elementwise chain over the 2*Co-channel Split tensor: it then
+                // merges with the hook chain that follows (fuse_plan) instead of writing the routed gradient out and reading it back
+                st.kind = ST_EW;
+                st.ew_t = d.in0;
+                BwdStep::Sym sy;
+                sy.type = EW_MAXHALF_IN; sy.action = e->tens[d.out].C; sy.t0 = d.in0; sy.x_t = -1; sy.f = 0.f; sy.op = cur_op; sy.slot = -1; sy.tap = false;
+                st.chain.push_back(sy);
+                target(d.in0, st);
+                break;
+            }
             case XFR_OP_G_NORMALIZE: st.kind = ST_NORMALIZE_BWD; target(d.in0, st); break;
             default:
                 return fail(XFR_UNSUPPORTED_LAYER, "backward: unsupported kind %d", d.kind);
@@ -1081,7 +1091,8 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
                 // first physical writer of an aliased tensor: it was an accumulate; turn it into "+ alias source"
                 if (b.accumulate) {
                     b.accumulate = 0;
-                    b.chain.insert(b.chain.begin(), mk(EW_ADDP, alias[d]));
+                    // (behind a MaxFeatureMap head: that step defines the gradient the chain starts from)
+                    b.chain.insert(b.chain.begin() + ((!b.chain.empty() && b.chain[0].type == EW_MAXHALF_IN) ? 1 : 0), mk(EW_ADDP, alias[d]));
                     if (b.kind == ST_CONV_BWD) b.ew_t = d;
                 }
                 alias[d] = -1;
@@ -1210,6 +1221,7 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
                 }
                 break;
             case EW_MASK: q.p0 = e->T(sy.t0); break;
+            case EW_MAXHALF_IN: q.p0 = e->T(sy.t0); break;
             case EW_SCALE_C: q.p0 = e->arena + (plain ? e->ops[sy.op].bn_alpha_t : e->ops[sy.op].bn_alpha_p); break;
             case EW_STORE: q.pstore = e->G(sy.t0); break;
             case EW_ADDP: q.p0 = e->G(sy.t0); break;
@@ -2168,17 +2180,51 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     p.tail_ws = tws; p.tail_ws_bytes = XFR_TAIL_WS_BYTES;
     p.tail_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tws) + XFR_TAIL_WS_BYTES);
     HIP_TRY(hipMemset(p.tail_cnt, 0, XFR_TAIL_MAX_TILES * sizeof(unsigned)));
-    p.tail_force = cfg / 10000;          // 0 heuristic, 1 off, S >= 2 forced
+    p.tail_force = (cfg / 10000) % 100;  // 0 heuristic, 1 off, S >= 2 forced
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
+    const int nstreams = std::max(1, std::min(4, cfg / 1000000));     // > 1: the same launches on several streams at once
+    p.tail_force = (cfg / 10000) % 100;
     launch_conv_gemm(p, 0);
-    HIP_TRY(hipEventRecord(a, 0));
-    for (int r = 0; r < reps; ++r) launch_conv_gemm(p, 0);
-    HIP_TRY(hipEventRecord(b, 0));
-    HIP_TRY(hipDeviceSynchronize());
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    if (nstreams == 1) {
+        HIP_TRY(hipEventRecord(a, 0));
+        for (int r = 0; r < reps; ++r) launch_conv_gemm(p, 0);
+        HIP_TRY(hipEventRecord(b, 0));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    } else {
+        // every stream needs its own tail-balancing scratch; the outputs coincide (same values)
+        hipStream_t st[4];
+        float* tw[4];
+        ConvParams q[4];
+        for (int i = 0; i < nstreams; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+            HIP_TRY(hipMalloc(&tw[i], XFR_TAIL_WS_BYTES + XFR_TAIL_MAX_TILES * sizeof(unsigned)));
+            q[i] = p;
+            q[i].tail_ws = tw[i];
+            q[i].tail_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tw[i]) + XFR_TAIL_WS_BYTES);
+            HIP_TRY(hipMemset(q[i].tail_cnt, 0, XFR_TAIL_MAX_TILES * sizeof(unsigned)));
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipEventRecord(a, 0));
+        for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamWaitEvent(st[i], a, 0));
+        for (int r = 0; r < reps; ++r)
+            for (int i = 0; i < nstreams; ++i) launch_conv_gemm(q[i], st[i]);
+        for (int i = 0; i < nstreams; ++i) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(e, st[i]));
+            HIP_TRY(hipStreamWaitEvent(0, e, 0));
+            (void)hipEventDestroy(e);
+        }
+        HIP_TRY(hipEventRecord(b, 0));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        ms /= nstreams;                       // per launch, all streams' launches counted
+        for (int i = 0; i < nstreams; ++i) { (void)hipStreamDestroy(st[i]); (void)hipFree(tw[i]); }
+    }
     if (ms_out) *ms_out = ms / reps;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     (void)hipFree(wd);
@@ -2191,6 +2237,16 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
 xfr_status xfr_debug_conv_stamps(void* stamps_dev)
 {
     conv_gemm_set_stamps(reinterpret_cast<unsigned long long*>(stamps_dev));
+    return XFR_OK;
+}
+
+xfr_status xfr_debug_conv_log(void* log_dev, int32_t capacity, const char* dump_path)
+{
+    if (dump_path) {
+        const int n = conv_gemm_dump_log(dump_path);
+        if (n < 0) return fail(XFR_HIP_ERROR, "xfr_debug_conv_log: cannot write %s", dump_path);
+    }
+    conv_gemm_set_log(reinterpret_cast<unsigned long long*>(log_dev), capacity);
     return XFR_OK;
 }
 

@@ -18,6 +18,12 @@ __device__ __forceinline__ float4 pick_slot(float4 v0, float4 v1, float4 v2, flo
                        pick1(v0.z, v1.z, v2.z, v3.z, slot), pick1(v0.w, v1.w, v2.w, v3.w, slot));
 }
 
+// VJP of max(a, b) for the half that holds `own`: all of g to the larger input, half of it on ties (at::maximum backward)
+__device__ __forceinline__ float ew_maxhalf_route(float g, float own, float other)
+{
+    return own == other ? g * 0.5f : (own > other ? g : 0.f);
+}
+
 template <bool PRIOR>
 __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int sb, int el0, float4 gv, float4 od, float4 v0, float4 v1,
                                              float4 v2, float4 v3, float4* __restrict__ dst,
@@ -117,6 +123,8 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int s
         } else if (st.type == EW_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
+        } else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR) {
+            // MAXHALF_IN was applied where the gradient was loaded (ew_maxhalf_route); MAXPAIR only exists in compiled epilogues
         } else {
             const float al = st.p0[c], be = st.p1[c];
             reinterpret_cast<float4*>(st.pstore)[idx] =
