@@ -218,7 +218,7 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--serial', action='store_true', help='run every step on ONE stream with per-GEMM HIP events (what the roofline figure is measured on); use under rocprofv3 so that kernel durations are not inflated by concurrent streams')
     ap.add_argument('--no-pipeline', action='store_true', help='do not overlap step i+1 forwards with step i backward')
-    ap.add_argument('--lanes', type=int, default=2, help='engines that take consecutive steps in turn, each on its own stream (xfr_amd.engine.EngineLanes); 1 = one engine')
+    ap.add_argument('--lanes', type=int, default=1, help='engines that take consecutive steps in turn, each on its own stream (xfr_amd.engine.EngineLanes); 1 = one engine')
     ap.add_argument('--profile-csv', default=None, help='with --serial: append one record per GEMM launch to this file (profiles/layer_table.py)')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 10 s sustained loop after the timed region')
     ap.add_argument('--sustained-seconds', type=float, default=10.0)

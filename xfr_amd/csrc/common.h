@@ -134,7 +134,7 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld, int fwd_sl
 // chains outside the table run through the interpreter).  Code = op | s0 << 4 | s1 << 7 | store << 10 | step << 11 with
 // s0 / s1 the prefetch slot of p0 / p1 (0..3), 4 = load in place, 7 = none (a hook whose x is its a).
 enum { SIG_END = 0, SIG_HOOK_DIV = 1, SIG_HOOK_RELU = 2, SIG_HOOK_PASS = 3, SIG_RELU = 4, SIG_MASK = 5, SIG_SCALE_C = 6, SIG_SCALE = 7,
-       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11 };
+       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11, SIG_MAXPAIR = 12 };
 constexpr int sig_op(unsigned c) { return (int)(c & 15u); }
 constexpr int sig_s0(unsigned c) { return (int)((c >> 4) & 7u); }
 constexpr int sig_s1(unsigned c) { return (int)((c >> 7) & 7u); }
@@ -172,6 +172,7 @@ inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
             case EW_AFFINE_C: op = SIG_AFFINE_C; break;
             case EW_RELU: op = SIG_RELU; break;
             case EW_FORK_POSBN: op = SIG_FORK_POSBN; break;
+            case EW_MAXPAIR: op = SIG_MAXPAIR; break;
             default: return -1;
         }
         codes[n++] = (uint16_t)(op | (s0 << 4) | (s1 << 7) | (store << 10) | ((unsigned)i << 11));
@@ -219,6 +220,8 @@ struct ConvParams {
     EwLoads chain_ld;   // its operand prefetch plan (set by launch_conv_gemm)
     int chain_sig;      // index of the chain's compiled epilogue (chain_sigs.inc), -1: interpreted (set by launch_conv_gemm)
     int chain_interpret; // 1: run the chain through the interpreted epilogue even if a compiled one exists (tests)
+    int co_pair;         // Co > 0: MaxFeatureMap convolution whose 2*Co output channels are PACKED interleaved (GEMM row 2c = channel c, row
+                         // 2c+1 = channel c + Co): rows are stored at their channel's place, a chain may end in EW_MAXPAIR
     int prio_round;      // > 0: wave priority by dispatch round -- workgroup b runs at priority 3 - min(b / prio_round, 3) (0: all equal)
     unsigned long long* stamps;   // tuning hook (xfr_debug_conv_stamps): per wave 8 words -- s_memrealtime at kernel entry, first operands landed,
                                   // K loop done, epilogue entered, exit; HW_ID; XCC_ID; life in shader cycles.  nullptr: off

@@ -107,6 +107,9 @@ __device__ __forceinline__ float pick4(float a0, float a1, float a2, float a3, i
     return r;
 }
 
+// channel of GEMM row `co`: the identity, except for MaxFeatureMap convolutions packed interleaved (ConvParams::co_pair)
+__device__ __forceinline__ int out_row(const ConvParams& p, int co) { return p.co_pair ? (co & 1) * p.co_pair + (co >> 1) : co; }
+
 // ---- compiled chain epilogues -------------------------------------------------------------------------------------------
 // chain_sigs.inc (generated by tools/gen_chain_sigs.py from the layer programs of the three backbones in all four subtree
 // modes) lists the signatures of the chains the planner fuses behind GEMMs.  For a listed chain the epilogue below is
@@ -128,7 +131,16 @@ constexpr unsigned sig_live_slots()
     return m;
 }
 
+template <int SIG>
+constexpr bool sig_has_maxpair()
+{
+    for (int i = 0; i < XFR_MAX_EW_STEPS; ++i)
+        if (sig_op(kChainSigs[SIG][i]) == SIG_MAXPAIR) return true;
+    return false;
+}
+
 struct EpiOps {          // operands of one float4 piece; indexed by compile-time constants only (stays in registers)
+    float4 partner;      // SIG_MAXPAIR: the same positions of row c ^ 1 (bias included)
     float4 v[EW_NLOADS];
     float pc0[XFR_MAX_EW_STEPS], pc1[XFR_MAX_EW_STEPS];
 };
@@ -212,6 +224,11 @@ __device__ __forceinline__ void epi_steps(float (&g)[4], const EpiOps& o, const 
         } else if constexpr (op == SIG_AFFINE_C) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(__fmul_rn(g[q], o.pc0[I]), o.pc1[I]);
+        } else if constexpr (op == SIG_MAXPAIR) {
+            // torch.max(a, b): NaN propagates (lightcnn.py:62 through at::maximum)
+            const float w[4] = {o.partner.x, o.partner.y, o.partner.z, o.partner.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = (g[q] != g[q]) ? g[q] : ((w[q] != w[q]) ? w[q] : fmaxf(g[q], w[q]));
         } else {   // SIG_FORK_POSBN
             reinterpret_cast<float4*>(ch.s[st].pstore)[idx4] =
                 make_float4(__fadd_rn(__fmul_rn(fmaxf(g[0], 0.f), o.pc0[I]), o.pc1[I]), __fadd_rn(__fmul_rn(fmaxf(g[1], 0.f), o.pc0[I]), o.pc1[I]),
@@ -245,7 +262,7 @@ __device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& 
     for (int hf = 0; hf < 4; ++hf) {
         cos[hf] = co_base + hf * 8 + (lane >> 3);
         ok[hf] = cos[hf] < p.CoutTot && m_ok;
-        const int cc = ok[hf] ? cos[hf] : 0;
+        const int cc = ok[hf] ? out_row(p, cos[hf]) : 0;
         idx4[hf] = (unsigned)cc * row4 + (unsigned)mm / 4u;
         aidx4[hf] = (unsigned)cc * arow4 + acol4;
     }
@@ -270,9 +287,19 @@ __device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& 
         const float4 gv = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
         float g[4] = {gv.x, gv.y, gv.z, gv.w};
         if (bsel && ok[hf]) { const float b = bsel[cos[hf]]; g[0] += b; g[1] += b; g[2] += b; g[3] += b; }
+        if constexpr (sig_has_maxpair<SIG>()) {
+            float4 w = *reinterpret_cast<const float4*>(tile + (cl ^ 1) * LD + mq);
+            if (bsel && ok[hf]) { const float b = bsel[cos[hf] ^ 1]; w.x += b; w.y += b; w.z += b; w.w += b; }
+            ops[hf].partner = w;
+        }
         if (ok[hf]) {
             epi_steps<SIG, 0>(g, ops[hf], p.chain, idx4[hf], aidx4[hf], p.chain_eps);
-            out4[idx4[hf]] = make_float4(g[0], g[1], g[2], g[3]);
+            if constexpr (sig_has_maxpair<SIG>()) {
+                // both rows of a pair hold the maximum now; the even row stores it as channel cos / 2 of the Co-channel output
+                if ((cos[hf] & 1) == 0) out4[(unsigned)(cos[hf] >> 1) * row4 + (unsigned)mm / 4u] = make_float4(g[0], g[1], g[2], g[3]);
+            } else {
+                out4[idx4[hf]] = make_float4(g[0], g[1], g[2], g[3]);
+            }
         }
         if (hf + DEPTH < 4) epi_load<SIG>(ops[hf + DEPTH], p, idx4[hf + DEPTH], aidx4[hf + DEPTH], ok[hf + DEPTH] ? cos[hf + DEPTH] : 0);
     }
@@ -296,7 +323,7 @@ __device__ __forceinline__ void dense_epilogue(const ConvParams& p, const v16f& 
         const int co = co_base + cl;
         float4 v = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
         if (co < p.CoutTot && m < p.M) {
-            float4* dst = reinterpret_cast<float4*>(osel + (long)co * row_stride + m);
+            float4* dst = reinterpret_cast<float4*>(osel + (long)out_row(p, co) * row_stride + m);
             if (bsel) { const float b = bsel[co]; v.x += b; v.y += b; v.z += b; v.w += b; }
             if (p.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             *dst = v;
@@ -419,7 +446,7 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
                     const int cl = (hf + u) * 8 + (lane >> 3);
                     cos[u] = co0 + wrow * 32 + cl;
                     ok[u] = cos[u] < p.CoutTot && m < p.M;
-                    const int cc = ok[u] ? cos[u] : 0;
+                    const int cc = ok[u] ? out_row(p, cos[u]) : 0;
                     idx4[u] = (long)cc * row4 + mm / 4;
                     aidx4[u] = (long)cc * arow4 + acol4;
                     g[u] = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
@@ -460,7 +487,7 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
                         const int rg = hf, q = e8;
                         const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
                         ok[e8] = co < p.CoutTot;
-                        const int cc = ok[e8] ? co : 0;
+                        const int cc = ok[e8] ? out_row(p, co) : 0;
                         gi[e8] = (int)((long)cc * row_stride + col);
                         ai[e8] = (int)((long)cc * arow + acol);
                         pv0[e8] = pv1[e8] = pv2[e8] = pv3[e8] = 0.f;
@@ -582,7 +609,7 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wrow * (TCO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     if (co >= p.CoutTot) continue;
-                    const long gi = (long)co * row_stride + col;
+                    const long gi = (long)out_row(p, co) * row_stride + col;
                     float v = acc[i][j][r];
                     if (bsel) v += bsel[co];
                     if (p.accumulate) v += osel[gi];
@@ -1307,13 +1334,14 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
     return true;
 }
 
-// shapes the split-K kernel covers: the 1x1 float4 path and the tap-major gather with whole K-steps per tap
+// Layers the split-K kernel covers: stride-1 convolutions whose K-steps lie inside one filter tap -- 1x1 (float4 rows when the launch's
+// M allows, else the one-tap gather: same K order, same bits) and the tap-major KxK gather.  A property of the LAYER, not of the batch.
 template <int BK>
 bool ks_ok(const ConvParams& p)
 {
-    const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H && p.OW == p.W);
-    if (vec) return true;
-    return p.tap_major == 1 && (p.Cin % BK) == 0 && p.kh * p.kw <= 64;
+    if (p.stride != 1 || (p.Cin % BK) != 0 || p.out_stride != 1) return false;
+    if (p.kh == 1 && p.kw == 1) return p.pad == 0;
+    return p.tap_major == 1 && p.kh * p.kw <= 64;
 }
 
 template <int BK, int NST>

@@ -82,6 +82,9 @@ struct OpRec {
     int Cin = 0, K = 0, Kb = 0;
     size_t idx_off = 0;                      // maxpool argmax (bytes into idx workspace)
     size_t norm_off = 0;                     // normalize: norms (floats into misc workspace)
+    int pair = 0;                            // MaxFeatureMap convolution (Conv -> Split -> max of halves, lightcnn.py:48-62): Co = cout / 2; its forward
+                                             // pack (and bias) holds the output channels interleaved (column 2c = channel c, 2c+1 = channel c + Co)
+    int pair_split = -1, pair_max = -1;      // the Split and G_MAXHALVES ops behind it
     bool fuse_relu = false;                  // forward: the following in-place ReLU is applied in this op's kernel
     bool relu_fused_away = false;            // forward: this ReLU is executed by its producer
 };
@@ -392,6 +395,18 @@ xfr_status build(xfr_engine* e, const xfr_op_desc* ops, int n_ops)
             e->ops[k + 1].relu_fused_away = true;
         }
     }
+    // MaxFeatureMap: Conv -> Split -> torch.max(halves) with single consumers all the way
+    for (int k = 0; k + 2 < n_ops; ++k) {
+        const xfr_op_desc& d = e->ops[k].d;
+        if (d.kind != XFR_OP_CONV || (d.cout & 1) || e->tens[d.out].consumers.size() != 1) continue;
+        const int k1 = e->tens[d.out].consumers[0];
+        if (e->ops[k1].d.kind != XFR_OP_SPLIT || e->tens[e->ops[k1].d.out].consumers.size() != 1) continue;
+        const int k2 = e->tens[e->ops[k1].d.out].consumers[0];
+        if (e->ops[k2].d.kind != XFR_OP_G_MAXHALVES) continue;
+        e->ops[k].pair = d.cout / 2;
+        e->ops[k].pair_split = k1;
+        e->ops[k].pair_max = k2;
+    }
     return XFR_OK;
 }
 
@@ -591,6 +606,7 @@ void conv_geometry(xfr_engine* e, int k, int NB, ConvParams& p)
     p.in_nb = NB; p.out_nb = NB;
     p.in_bytes = (unsigned)((size_t)NB * a.per_n() * sizeof(float));
     p.tap_major = o.tap4_fwd ? 2 : (o.tap_fwd ? 1 : 0);
+    p.co_pair = o.pair;
 }
 
 // Forward-only runs (encode, embeddings, the gallery of a triplet step) never need the raw convolution output:
@@ -696,6 +712,36 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
     e->fwd_done[k1] = 1;
 }
 
+// MaxFeatureMap in the convolution's epilogue (lightcnn.py:48-62: Conv -> Split -> torch.max of the halves).  The forward pack holds
+// the two halves interleaved, so a channel and its partner are neighbouring rows of one accumulator tile: the epilogue stores the raw
+// rows where the Split hook and the VJP expect them (keep_raw; a forward-only run needs neither) and the even rows store the maximum.
+// Returns false -- nothing fused, the three ops run as before -- where the float4 epilogue does not apply.
+bool fuse_mfm_forward(xfr_engine* e, int k, int B, bool keep_raw, ConvParams& p)
+{
+    const OpRec& o = e->ops[k];
+    if (!o.pair || o.pair_max > e->fwd_last_op || e->interpret_chains) return false;      // the interpreter has no EW_MAXPAIR
+    const Tensor& t = e->tens[o.d.out];
+    EwChain ch;
+    ch.n = 0;
+    auto push = [&](int type) -> EwStep& { EwStep& q = ch.s[ch.n++]; memset(&q, 0, sizeof(q)); q.type = type; q.prior_sb = -1; return q; };
+    if (keep_raw) push(EW_STORE).pstore = e->T(o.d.out);
+    push(EW_MAXPAIR);
+    float* dst = e->T(e->ops[o.pair_max].d.out);
+    {
+        EwChain probe = ch;
+        EwLoads ld;
+        ew_plan_loads(probe, dst, ld, EW_FWD_SLOTS_WIDE);
+        if (!e->planning_only && ((((long)B * t.HW()) & 3) != 0 || conv_gemm_chain_sig(probe) < 0)) return false;
+    }
+    p.chain = ch;
+    p.out0 = dst;
+    p.chain_B = B;
+    p.chain_eps = e->eps;
+    e->fwd_done[o.pair_split] = 1;
+    e->fwd_done[o.pair_max] = 1;
+    return true;
+}
+
 // forward of op k on true values (and, for "dual" convolutions, the positive output in the same launch)
 xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
 {
@@ -724,7 +770,8 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
                 p.out1 = e->Pv(d.out);
                 p.nhalves = 2;
             } else p.nhalves = 1;
-            if (!want_pos && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p);
+            if (o.pair && e->fuse_fwd_only && !dual && !p.relu_in && fuse_mfm_forward(e, k, B, want_pos, p)) { }
+            else if (!want_pos && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p);
             else if (want_pos && e->fuse_probe_fwd && !p.relu_in) fuse_probe_forward(e, k, B, p);
             return run_conv(e, p, s);
         }
@@ -1524,14 +1571,17 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
             float* wt = host.data() + o.w_true;
             float* wp = host.data() + o.w_pos;
             // forward pack: [k][co], k = (ci,kh,kw) or tap-major (kh,kw,ci)
+            // column of output channel co in the forward pack: interleaved halves for MaxFeatureMap convolutions (OpRec::pair)
+            auto col_of = [&](int co) { return o.pair ? (co % o.pair) * 2 + co / o.pair : co; };
             for (int co = 0; co < d.cout; ++co) {
                 const float* src = wv.data + (size_t)co * o.K;
+                const int col = col_of(co);
                 for (int ci = 0; ci < o.Cin; ++ci)
                     for (int tp = 0; tp < khw; ++tp) {
                         const float v = src[ci * khw + tp];
                         const size_t kk = o.tap4_fwd ? (size_t)tp * 4 + ci : (o.tap_fwd ? (size_t)tp * o.Cin + ci : (size_t)ci * khw + tp);
-                        wt[kk * o.ldw + co] = v;
-                        wp[kk * o.ldw + co] = v > 0.f ? v : 0.f;   // relu(W): whitebox.py:319
+                        wt[kk * o.ldw + col] = v;
+                        wp[kk * o.ldw + col] = v > 0.f ? v : 0.f;   // relu(W): whitebox.py:319
                     }
             }
             if (o.w_bwd >= 0) {
@@ -1554,8 +1604,8 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
                 const xfr_tensor_view& bv = w[d.w_bias];
                 if (!bv.data || bv.numel != d.cout) return fail(XFR_INVALID_ARG, "op %zu: bad bias size", k);
                 for (int co = 0; co < d.cout; ++co) {
-                    host[o.b_true + co] = bv.data[co];
-                    host[o.b_pos + co] = bv.data[co] > 0.f ? bv.data[co] : 0.f;   // whitebox.py:323 (with_bias)
+                    host[o.b_true + col_of(co)] = bv.data[co];
+                    host[o.b_pos + col_of(co)] = bv.data[co] > 0.f ? bv.data[co] : 0.f;   // whitebox.py:323 (with_bias)
                 }
             }
         } else if (d.kind == XFR_OP_BATCHNORM) {
@@ -2411,7 +2461,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
         ConvParams p;
         conv_geometry(e, k, batch, p);
         p.out0 = e->T(d.out);
-        fuse_forward_only(e, k, batch, p);
+        if (!fuse_mfm_forward(e, k, batch, false, p)) fuse_forward_only(e, k, batch, p);
         if (p.chain.n == 0) continue;
         EwLoads ld;
         ew_plan_loads(p.chain, p.out0, ld, EW_FWD_SLOTS_WIDE);
@@ -2429,7 +2479,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
         ConvParams p;
         conv_geometry(e, k, batch, p);
         p.out0 = e->T(d.out);
-        fuse_probe_forward(e, k, batch, p);
+        if (!fuse_mfm_forward(e, k, batch, true, p)) fuse_probe_forward(e, k, batch, p);
         if (p.chain.n == 0) continue;
         EwLoads ld;
         ew_plan_loads(p.chain, p.out0, ld, EW_FWD_SLOTS_WIDE);
