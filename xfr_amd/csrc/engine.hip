@@ -329,6 +329,7 @@ xfr_status build(xfr_engine* e, const xfr_op_desc* ops, int n_ops)
                 if (d.kh != d.kw || d.kh <= 0 || d.stride <= 0 || d.pad != 0) return fail(XFR_INVALID_ARG, "op %d: bad avgpool", k);
                 t.C = a.C; t.H = (a.H - d.kh) / d.stride + 1; t.W = (a.W - d.kw) / d.stride + 1;
                 t.nonneg = a.nonneg; t.pstate = a.nonneg ? PS_EQ : PS_OTHER;
+                if (d.kh == 1 && d.stride == 1) t.alias = d.in0;       // AvgPool2d(1, 1) (resnet.py:210): the identity -- same storage, no launch
                 break;
             case XFR_OP_ADD:
             case XFR_OP_G_ADD: {
@@ -787,6 +788,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
             launch_maxpool_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->idx_base() + o.idx_off, a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, d.pad, s);
             return XFR_OK;
         case XFR_OP_AVGPOOL:
+            if (t.alias >= 0) return XFR_OK;
             launch_avgpool_fwd(e->T(d.in0), e->T(d.out), a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, 0, s);
             return XFR_OK;
         case XFR_OP_ADD:
@@ -1055,7 +1057,11 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan, bool plain)
                 }
                 st.kind = ST_CONV_BWD; target(d.in0, st); break;
             case XFR_OP_MAXPOOL: st.kind = ST_MAXPOOL_BWD; target(d.in0, st); break;
-            case XFR_OP_AVGPOOL: st.kind = ST_AVGPOOL_BWD; target(d.in0, st); break;
+            case XFR_OP_AVGPOOL:
+                if (d.kh == 1 && d.stride == 1) { st.kind = ST_COPY; st.copy_elems_per_sb = e->tens[cur_t].C; }    // identity: a gradient copy (often forwarded away)
+                else st.kind = ST_AVGPOOL_BWD;
+                target(d.in0, st);
+                break;
             case XFR_OP_ADD:
             case XFR_OP_G_ADD:
                 st.kind = ST_COPY; st.copy_elems_per_sb = e->tens[cur_t].C;

@@ -25,20 +25,28 @@ __global__ __launch_bounds__(NT) void channel_pool_kernel(const float* __restric
     }
 }
 
-// sums[sb] = sum_{c,hw} P[c][sb][hw]   (torch.sum(P[-2]), whitebox.py:524).  grid = (chunks, SB)
+// sums[sb] = sum_{c,hw} P[c][sb][hw]   (torch.sum(P[-2]), whitebox.py:524).  grid = (C, SB): a block walks one (channel, row) run of
+// HW floats (float4 when HW % 4 == 0), fp64 accumulation, one atomic per block
 __global__ __launch_bounds__(NT) void sample_sums_kernel(const float* __restrict__ P, double* __restrict__ sums, int C,
                                                         int SB, int HW)
 {
-    const int sb = blockIdx.y;
-    const long total = (long)C * HW;
+    const int c = blockIdx.x, sb = blockIdx.y;
+    const float* __restrict__ row = P + ((size_t)c * SB + sb) * HW;
     double acc = 0.0;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i / HW);
-        const int hw = (int)(i - (long)c * HW);
-        acc += (double)P[((long)c * SB + sb) * HW + hw];
+    if ((HW & 3) == 0) {
+        const float4* __restrict__ r4 = reinterpret_cast<const float4*>(row);
+        for (int i = threadIdx.x; i < (HW >> 2); i += NT) {
+            const float4 v = r4[i];
+            acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += NT) acc += (double)row[i];
     }
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[sb], acc);
+    __shared__ double part[NT / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[sb], (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 // out[n][hw] = sum_c relu(keep*m - keep*q),  m = P[c][n][hw]/S_n, q = P[c][N+n][hw]/S_{N+n},
@@ -219,10 +227,7 @@ void launch_channel_pool(const float* P, float* pooled, int C, int SB, int HW, h
 void launch_sample_sums(const float* P, double* sums, int C, int SB, int HW, hipStream_t s)
 {
     (void)hipMemsetAsync(sums, 0, sizeof(double) * SB, s);
-    long chunks = ((long)C * HW + NT * 4 - 1) / (NT * 4);
-    if (chunks > 64) chunks = 64;
-    if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(sample_sums_kernel, dim3((int)chunks, SB), dim3(NT), 0, s, P, sums, C, SB, HW);
+    hipLaunchKernelGGL(sample_sums_kernel, dim3(C, SB), dim3(NT), 0, s, P, sums, C, SB, HW);
 }
 
 void launch_contrast(const float* P, const double* sums, const float* thr, float* out, int C, int N, int HW, hipStream_t s)
