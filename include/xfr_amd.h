@@ -312,12 +312,12 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
 
 /* Tuning hook: while stamps_dev is non-NULL, every GEMM launch of this process records, per wave, 8 64-bit words at
  * stamps_dev[(block * 4 + wave) * 8]: s_memrealtime (100 MHz) at kernel entry / first operands landed / K loop done / epilogue entered / exit,
- * then HW_ID, XCC_ID, and the wave's life in shader-clock cycles (s_memtime; with the 100 MHz stamps: the effective clock) (tools/conv_sweep.py --stamps draws a launch's timeline from them).  The buffer must hold
- * 32 words per workgroup of the largest grid launched.  NULL switches it off (the default). */
-xfr_status xfr_debug_conv_stamps(void* stamps_dev);
+ * then HW_ID, XCC_ID, and the wave's life in shader-clock cycles (s_memtime; with the 100 MHz stamps: the effective clock) (tools/conv_sweep.py --stamps draws a launch's timeline from them).  The buffer holds
+ * 32 words for each of capacity_workgroups workgroups; workgroups beyond that do not record.  NULL switches it off (the default). */
+xfr_status xfr_debug_conv_stamps(void* stamps_dev, int32_t capacity_workgroups);
 
 /* Tuning hook: a timeline of the GEMM launches as the device ran them, streams overlapped.  While log_dev is non-NULL (zero-filled
- * device memory, 16 bytes per launch, `capacity` launches), every GEMM launch of this process records when its first workgroup
+ * device memory, 64 bytes per launch, `capacity` launches), every GEMM launch of this process records when its first workgroup
  * started and its last one ended (s_memrealtime, 10 ns ticks) and the library notes its shape, stream and tile configuration.  A
  * call with dump_path != NULL first writes what has been recorded so far as CSV (synchronise the device before); log_dev = NULL
  * stops recording.  tools/gemm_timeline.py reads the file. */

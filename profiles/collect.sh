@@ -1,32 +1,51 @@
 #!/bin/bash
 # Collect one round's rocprofv3 evidence for bench.py on the GPU box (run from the repo root, e.g. through gpurun):
-#   bash profiles/collect.sh r2      -> gpurun_out/prof_r2/..., summaries copied to profiles/r2/
+#   bash profiles/collect.sh r3      -> gpurun_out/prof_r3/..., summaries copied to profiles/r3/
 # Counters are collected in their own passes (--pmc never together with a trace domain other than the kernel trace).
+# Every BASELINE.json single-GPU configuration gets the same set: resnet101 (no suffix), resnet50_128 (_r50), lightcnn (_lcnn).
 set -u
-R=${1:-r2}
+R=${1:-r3}
 D=gpurun_out/prof_$R
 P=profiles/$R
 export TMPDIR=/tmp
 mkdir -p "$D" "$P"
 ST="--kernel-trace --stats --output-format csv"
-rocprofv3 $ST -d $D/serial -o $R -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --serial --no-unfused-ref --no-sustained > $P/bench_serial_under_rocprof.json 2> $D/serial.err
+for spec in resnet101: resnet50_128:_r50 lightcnn:_lcnn; do
+  M=${spec%%:*}; T=${spec##*:}
+  B="python bench.py --model $M"
+  # one stream: the schedule whose kernel durations a profiler can attribute
+  rocprofv3 $ST -d $D/serial$T -o $R -- $B --steps 5 --warmup 2 --no-cpu-baseline --serial --no-unfused-ref --no-sustained --no-profile > $P/bench_serial_under_rocprof$T.json 2> $D/serial$T.err
+  cp $D/serial$T/${R}_kernel_stats.csv $P/kernel_stats_serial$T.csv
+  rm -f $D/serial$T/${R}_kernel_trace.csv
+  PB="$B --steps 2 --warmup 1 --no-cpu-baseline --no-profile --serial --no-sustained"
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $D/pmc_mfma$T -o $R -- $PB > /dev/null 2> $D/pmc_mfma$T.err
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch$T -o $R -- $PB > /dev/null 2> $D/pmc_fetch$T.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write$T -o $R -- $PB > /dev/null 2> $D/pmc_write$T.err
+  python profiles/pmc_summary.py $D/pmc_mfma$T > $P/pmc_mfma$T.txt
+  python profiles/pmc_summary.py $D/pmc_fetch$T > $P/pmc_FETCH_SIZE$T.txt
+  python profiles/pmc_summary.py $D/pmc_write$T > $P/pmc_WRITE_SIZE$T.txt
+  rm -f $D/pmc_*$T/${R}_counter_collection.csv
+  # per-layer GEMM table (HIP events inside the engine, serial schedule)
+  rm -f $D/layers$T.csv; $B --steps 3 --warmup 2 --no-cpu-baseline --serial --no-sustained --no-profile --profile-csv $D/layers$T.csv > /dev/null 2>&1
+  python profiles/layer_table.py $D/layers$T.csv > $P/gemm_layers_serial$T.txt
+  # the plain bench line (timed three-stream schedule, launch-log roofline, clock, CPU baseline) + the timeline it came from
+  $B --timeline-json $P/gemm_timeline$T.json > $P/bench_default$T.json 2> $D/bench_default$T.err
+done
+# the timed schedule under the profiler (rocprofv3 serialises the queues: kernel mix only)
 rocprofv3 $ST -d $D/pipelined -o $R -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-sustained > $P/bench_pipelined_under_rocprof.json 2> $D/pipelined.err
-cp $D/serial/${R}_kernel_stats.csv $P/kernel_stats_serial.csv
 cp $D/pipelined/${R}_kernel_stats.csv $P/kernel_stats_pipelined.csv
-rm -f $D/*/${R}_kernel_trace.csv
-PB="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --serial --no-sustained"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $D/pmc_mfma -o $R -- $PB > /dev/null 2> $D/pmc_mfma.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o $R -- $PB > /dev/null 2> $D/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o $R -- $PB > /dev/null 2> $D/pmc_write.err
-python profiles/pmc_summary.py $D/pmc_mfma > $P/pmc_mfma.txt
-python profiles/pmc_summary.py $D/pmc_fetch > $P/pmc_FETCH_SIZE.txt
-python profiles/pmc_summary.py $D/pmc_write > $P/pmc_WRITE_SIZE.txt
-rm -f $D/pmc_*/${R}_counter_collection.csv
-# per-layer GEMM table (HIP events inside the engine, serial schedule) and the plain bench line
-rm -f $D/layers.csv; python bench.py --steps 3 --warmup 2 --no-cpu-baseline --serial --no-sustained --no-profile --profile-csv $D/layers.csv > /dev/null 2>&1
-python profiles/layer_table.py $D/layers.csv > $P/gemm_layers_serial.txt
-python bench.py > $P/bench_default.json 2> $D/bench_default.err
-python bench.py --model resnet50_128 --no-cpu-baseline > $P/bench_resnet50_128.json 2> /dev/null
-python bench.py --model lightcnn --no-cpu-baseline > $P/bench_lightcnn.json 2> /dev/null
+rm -f $D/pipelined/${R}_kernel_trace.csv
+# clocks and power: rocm-smi sampled once a second (a) during the sustained loop of the bench, (b) during back-to-back GEMM launches
+# on three streams (the chip at its power limit); the in-kernel clock measurements next to them
+smi() { while true; do date +%s.%N; rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power|power" ; sleep 1; done; }
+smi > $P/smi_bench_sustained.txt & SMI=$!
+python bench.py --no-cpu-baseline --no-profile --sustained-seconds 15 > /dev/null 2>&1
+kill $SMI; wait $SMI 2>/dev/null
+smi > $P/smi_gemm_saturated.txt & SMI=$!
+python tools/conv_sweep.py --cfgs 3000007,3000004 --reps 6000 --only 0 > $P/gemm_saturated.txt 2>&1
+kill $SMI; wait $SMI 2>/dev/null
+python tools/conv_sweep.py --cfgs 7,3000007,4,3000004 --reps 300 --only 0,1 --stamps > $P/gemm_stamps.txt 2>&1
+python tools/clock_probe.py --steps 20 > $P/clock_probe_timed.json 2> /dev/null
+python tools/clock_probe.py --steps 10 --serial > $P/clock_probe_serial.json 2> /dev/null
 mkdir -p gpurun_out/$P && cp -r $P/. gpurun_out/$P/
 echo "collected: $(ls $P | tr '\n' ' ')"

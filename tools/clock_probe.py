@@ -51,25 +51,13 @@ def main():
     for _ in range(5):
         step()
     torch.cuda.synchronize()
-    nwg = 16384
-    st = torch.zeros((nwg * 32,), dtype=torch.int64, device=dev)
-    _lib.check(lib.xfr_debug_conv_stamps(st.data_ptr()))
+    from xfr_amd import tuning
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
+    clk = tuning.shader_clock(step, args.steps, dev)
     dt = time.perf_counter() - t0
-    _lib.check(lib.xfr_debug_conv_stamps(None))
-    v = st.cpu().numpy().reshape(nwg, 4, 8)
-    life = (v[:, 0, 4] - v[:, 0, 0]).astype(np.float64)         # 10 ns ticks
-    ok = (v[:, 0, 4] > 0) & (v[:, 0, 0] > 0) & (life > 1000)    # lives of at least 10 us
-    ghz = v[ok][:, 0, 7].astype(np.float64) / (life[ok] * 10.0)
-    p = np.percentile(ghz, [5, 25, 50, 75, 95])
     out = {'schedule': 'serial (one stream)' if args.serial else 'timed (three streams, pipelined)', 'steps': args.steps,
-           'ms_per_step_with_stamps': 1e3 * dt / args.steps, 'workgroup_records': int(ok.sum()),
-           'shader_clock_GHz': {'p5': p[0], 'p25': p[1], 'p50': p[2], 'p75': p[3], 'p95': p[4], 'mean': float(ghz.mean())},
-           'fp32_mfma_peak_at_median_clock_TFLOPs': 64 * 1024 * p[2] * 1e9 / 1e12,
-           'nominal_peak_TFLOPs': 157.3}
+           'ms_per_step_with_stamps': 1e3 * dt / args.steps, 'shader_clock_GHz': clk,
+           'fp32_mfma_peak_at_median_clock_TFLOPs': 64 * 1024 * clk['p50'] * 1e9 / 1e12, 'nominal_peak_TFLOPs': 157.3}
     print(json.dumps(out))
 
 

@@ -37,12 +37,12 @@ def stamp_report(lib, _lib, torch, dev, a, cfg, ms_ref):
     x, wt, b, out, cin, h, w, nbb, cout, k, stride, pad = a
     nwg = 16384
     st = torch.zeros((nwg * 32,), dtype=torch.int64, device=dev)
-    _lib.check(lib.xfr_debug_conv_stamps(st.data_ptr()))
+    _lib.check(lib.xfr_debug_conv_stamps(st.data_ptr(), nwg))
     ms = ctypes.c_float()
     _lib.check(lib.xfr_debug_conv(x.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), cin, h, w, nbb, cout, k, k, stride, pad, 0,
                                   cfg, 1, ctypes.byref(ms)))
     torch.cuda.synchronize()
-    _lib.check(lib.xfr_debug_conv_stamps(None))
+    _lib.check(lib.xfr_debug_conv_stamps(None, 0))
     v = st.cpu().numpy().reshape(nwg, 4, 8)
     used = v[:, 0, 0] != 0
     bidx = np.nonzero(used)[0]

@@ -46,52 +46,14 @@ def record(steps, batch=32, serial=False, csv_path='/tmp/gemm_log.csv', model='r
     for _ in range(5):
         step()
     torch.cuda.synchronize()
-    cap = 400 * (steps + 2)
-    log = torch.zeros((cap * 2,), dtype=torch.int64, device=dev)
-    _lib.check(lib.xfr_debug_conv_log(log.data_ptr(), cap, None))
-    for _ in range(steps + 2):
-        step()
-    torch.cuda.synchronize()
-    _lib.check(lib.xfr_debug_conv_log(None, 0, csv_path.encode()))
+    from xfr_amd import tuning
+    tuning.record_launch_log(step, steps, dev, csv_path)
     return csv_path
 
 
 def analyse(csv_path, steps, flop_per_step):
-    import numpy as np
-    rows = [l.strip().split(',') for l in open(csv_path)][1:]
-    recs = [(int(r[0]), r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]), int(r[9]), int(r[10])) for r in rows]
-    per_step = len(recs) // (steps + 2)
-    recs = recs[per_step:per_step * (steps + 1)]           # drop the first and the last recorded step (pipeline fill / drain)
-    t0 = min(r[6] for r in recs)
-    ev = []
-    for r in recs:
-        ev.append((r[6] - t0, 1))
-        ev.append((r[7] - t0, -1))
-    ev.sort()
-    depth, last, hist = 0, 0, collections.Counter()
-    for t, d in ev:
-        hist[depth] += t - last
-        last = t
-        depth += d
-    span = max(r[7] for r in recs) - t0
-    busy = sum(v for k, v in hist.items() if k > 0)
-    streams = collections.OrderedDict()
-    for r in recs:
-        streams.setdefault(r[1], []).append(r)
-    out = {'steps': steps, 'launches_per_step': per_step, 'window_ms': span * 1e-5, 'ms_per_step': span * 1e-5 / steps,
-           'gemm_union_busy_ms_per_step': busy * 1e-5 / steps, 'gemm_union_busy_frac': busy / span,
-           'concurrency_ms_per_step': {str(k): v * 1e-5 / steps for k, v in sorted(hist.items())},
-           'achieved_over_union_TFLOPs': flop_per_step / (busy * 1e-8 / steps) / 1e12,
-           'achieved_over_window_TFLOPs': flop_per_step / (span * 1e-8 / steps) / 1e12, 'streams': []}
-    for sname, rs in streams.items():
-        rs.sort(key=lambda r: r[6])
-        dur = sum(r[7] - r[6] for r in rs)
-        gaps = [max(0, b[6] - a[7]) for a, b in zip(rs, rs[1:])]
-        big = sorted(gaps)[-max(1, len(gaps) // 100):]
-        out['streams'].append({'stream': sname, 'launches_per_step': len(rs) / steps, 'sum_launch_ms_per_step': dur * 1e-5 / steps,
-                               'sum_gap_ms_per_step': sum(gaps) * 1e-5 / steps, 'median_gap_us': float(np.median(gaps)) * 1e-2,
-                               'p90_gap_us': float(np.percentile(gaps, 90)) * 1e-2, 'largest_1pct_gaps_ms_per_step': sum(big) * 1e-5 / steps})
-    return out
+    from xfr_amd import tuning
+    return tuning.analyse_launch_log(csv_path, steps, flop_per_step)
 
 
 def main():

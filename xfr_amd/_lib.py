@@ -60,7 +60,7 @@ SYMBOLS = [
     ('xfr_engine_trace_size', _I, [_P, ctypes.POINTER(_I)]),
     ('xfr_engine_get_trace', _I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), _I]),
     ('xfr_debug_conv', _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_F)]),
-    ('xfr_debug_conv_stamps', _I, [_P]),
+    ('xfr_debug_conv_stamps', _I, [_P, _I]),
     ('xfr_debug_conv_log', _I, [_P, _I, ctypes.c_char_p]),
     ('xfr_engine_memory', _I, [_P, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     ('xfr_engine_set_profile', _I, [_P, _I]),

@@ -225,11 +225,12 @@ struct ConvParams {
     int prio_round;      // > 0: wave priority by dispatch round -- workgroup b runs at priority 3 - min(b / prio_round, 3) (0: all equal)
     unsigned long long* stamps;   // tuning hook (xfr_debug_conv_stamps): per wave 8 words -- s_memrealtime at kernel entry, first operands landed,
                                   // K loop done, epilogue entered, exit; HW_ID; XCC_ID; life in shader cycles.  nullptr: off
-    unsigned long long* span;     // tuning hook (xfr_debug_conv_log): two words of THIS launch -- max over workgroups of ~entry time and of exit time
+    int stamps_cap;               // workgroups the stamp buffer holds (later ones do not record)
+    unsigned long long* span;     // tuning hook (xfr_debug_conv_log): eight words of THIS launch -- block 0's entry time, then exit times of a sample of the workgroups
                                   // (s_memrealtime), i.e. when the launch really started and ended next to the other streams' launches
 };
-void conv_gemm_set_stamps(unsigned long long* dev_ptr);
-// launch log: every later launch_conv_gemm takes the next two-word record of log_dev (capacity records) and notes its shape and
+void conv_gemm_set_stamps(unsigned long long* dev_ptr, int capacity_workgroups);
+// launch log: every later launch_conv_gemm takes the next eight-word record of log_dev (capacity records) and notes its shape and
 // stream on the host; conv_gemm_dump_log writes one CSV line per launch (seq, stream, shape, cfg, start and end in 10 ns ticks)
 void conv_gemm_set_log(unsigned long long* log_dev, int capacity);
 int conv_gemm_dump_log(const char* path);   // every later launch_conv_gemm records into dev_ptr (nullptr: stop)

@@ -75,7 +75,7 @@ enum { MODE_VEC = 0, MODE_TAP = 1, MODE_GEN = 2, MODE_TAP4 = 3 };
 // tuning hook: phase stamps of a wave (ConvParams::stamps)
 __device__ __forceinline__ void stamp(const ConvParams& p, int wave, int lane, int slot)
 {
-    if (p.stamps && lane == 0) {
+    if (p.stamps && lane == 0 && (int)blockIdx.x < p.stamps_cap) {
         unsigned long long* q = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
         q[slot] = __builtin_amdgcn_s_memrealtime();      // the 100 MHz reference clock: one time base for all XCDs
         if (slot == 0) {
@@ -85,10 +85,11 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int wave, int lane, i
         }
         if (slot == 4) q[7] = __builtin_amdgcn_s_memtime() - q[7];      // ... to exit: shader cycles of this wave's life
     }
-    // a sample of the workgroups reports (one atomic per workgroup on one address costs ~12 ns each: 30 us for a 3000-tile grid)
-    if (p.span && lane == 0 && wave == 0 && ((slot == 0 && blockIdx.x == 0) || (slot == 4 && ((blockIdx.x & 15) == 0 || blockIdx.x == gridDim.x - 1)))) {
-        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-        atomicMax(p.span + (slot == 0 ? 0 : 1), slot == 0 ? ~t : t);
+    // launch log: block 0 notes the start, a sample of the workgroups their end -- plain stores into the launch's 8-word record (slot
+    // 1 + (block / 16) % 7: the last writer of a slot is one of the late workgroups; the host takes the maximum over the slots)
+    if (p.span && lane == 0 && wave == 0) {
+        if (slot == 0 && blockIdx.x == 0) p.span[0] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 4 && ((blockIdx.x & 15) == 0 || blockIdx.x == gridDim.x - 1)) p.span[1 + (blockIdx.x >> 4) % 7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1410,7 +1411,8 @@ int conv_gemm_pick_cfg(const ConvParams& p)
 }
 
 static unsigned long long* g_stamps = nullptr;
-void conv_gemm_set_stamps(unsigned long long* dev_ptr) { g_stamps = dev_ptr; }
+static int g_stamps_cap = 0;
+void conv_gemm_set_stamps(unsigned long long* dev_ptr, int capacity_workgroups) { g_stamps = dev_ptr; g_stamps_cap = dev_ptr ? capacity_workgroups : 0; }
 
 namespace {
 struct LogRec { void* stream; int cout, nhalves, K, M, kh, chain, cfg; };
@@ -1427,14 +1429,14 @@ void conv_gemm_set_log(unsigned long long* log_dev, int capacity)
 int conv_gemm_dump_log(const char* path)
 {
     const size_t n = g_log_recs.size();
-    std::vector<unsigned long long> h(2 * n + 2);
-    if (n && hipMemcpy(h.data(), g_log, 2 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    std::vector<unsigned long long> h(8 * n + 8);
+    if (n && hipMemcpy(h.data(), g_log, 8 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     FILE* f = fopen(path, "w");
     if (!f) return -1;
     fprintf(f, "seq,stream,Cout,nhalves,K,M,kh,chain,cfg,start_10ns,end_10ns\n");
     for (size_t i = 0; i < n; ++i) {
         const LogRec& r = g_log_recs[i];
-        fprintf(f, "%zu,%p,%d,%d,%d,%d,%d,%d,%d,%llu,%llu\n", i, r.stream, r.cout, r.nhalves, r.K, r.M, r.kh, r.chain, r.cfg, ~h[2 * i], h[2 * i + 1]);
+        fprintf(f, "%zu,%p,%d,%d,%d,%d,%d,%d,%d,%llu,%llu\n", i, r.stream, r.cout, r.nhalves, r.K, r.M, r.kh, r.chain, r.cfg, h[8 * i], *std::max_element(h.begin() + 8 * i + 1, h.begin() + 8 * i + 8));
     }
     fclose(f);
     return (int)n;
@@ -1444,11 +1446,12 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
     p.stamps = g_stamps;
+    p.stamps_cap = g_stamps_cap;
     p.span = nullptr;
     static const int prio = [] { const char* e = getenv("XFR_PRIO"); return e ? atoi(e) : 0; }();
     p.prio_round = prio ? num_cus() * prio : 0;
     if (g_log && (int)g_log_recs.size() < g_log_cap) {
-        p.span = g_log + 2 * g_log_recs.size();
+        p.span = g_log + 8 * g_log_recs.size();
         g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
     }
     const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);

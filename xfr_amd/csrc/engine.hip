@@ -2290,9 +2290,10 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     return XFR_OK;
 }
 
-xfr_status xfr_debug_conv_stamps(void* stamps_dev)
+xfr_status xfr_debug_conv_stamps(void* stamps_dev, int32_t capacity_workgroups)
 {
-    conv_gemm_set_stamps(reinterpret_cast<unsigned long long*>(stamps_dev));
+    if (stamps_dev && capacity_workgroups < 1) return fail(XFR_INVALID_ARG, "xfr_debug_conv_stamps: capacity must be positive");
+    conv_gemm_set_stamps(reinterpret_cast<unsigned long long*>(stamps_dev), capacity_workgroups);
     return XFR_OK;
 }
 

@@ -345,77 +345,3 @@ class Engine(object):
         _lib.check(self.lib.xfr_engine_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
         return ms.value, n.value, fl.value
 
-
-class EngineLanes(object):
-    """Several engines ("lanes") of ONE backbone on ONE device that take consecutive triplet calls in turn, every lane on a HIP
-    stream of its own.
-
-    Why: a step is three dependent chains of a few hundred kernels (gallery forward, probe forward, backward sweep); each
-    kernel of a 32-triplet batch fills the chip for 50-150 us and ramps up and down in lock-step, so one step in flight keeps
-    the MFMA pipes busy about two thirds of the time.  The reference's job loop hands INDEPENDENT jobs to its workers
-    (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:200-215); with two lanes, call i+1 runs next to call i and
-    fills those ramps (measured on MI355X, ResNet-101, 32 triplets per call: see DESIGN.md section 6).  Results are the same
-    bits as a single engine's: every call still runs alone inside its lane.
-
-    Ordering: the caller's current stream waits for a lane's call before it can touch the returned maps (they are allocated on
-    the lane's stream and recorded for the caller's); inputs follow the inputs_ready contract of Engine.triplet_contrastive --
-    without it the lane first waits for the caller's stream, which serialises the lanes.  C hosts do the same with two
-    xfr_engine handles and two streams.  Costs one workspace per lane (288 GB of HBM3E: 50 GB per ResNet-101
-    lane at 64 images)."""
-
-    def __init__(self, program, max_batch, device, lanes=2):
-        self.engines = [Engine(program, max_batch, device) for _ in range(int(lanes))]
-        self.device = self.engines[0].device
-        self.program = program
-        self.max_batch = int(max_batch)
-        with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.engines]
-        self._next = 0
-
-    @property
-    def lanes(self):
-        return len(self.engines)
-
-    def load_weights(self, state_dict):
-        self.engines[0].load_weights(state_dict)
-        self.share_weights()
-
-    def share_weights(self):
-        """Lane 0 holds the packed parameters (loaded, or received by broadcast): copy its arena to the other lanes."""
-        src = self.engines[0].weight_arena()
-        for e in self.engines[1:]:
-            e.weight_arena().copy_(src)
-            e.mark_weights_loaded()
-        torch.cuda.synchronize(self.device)
-
-    def _all(self, name, *a, **k):
-        for e in self.engines:
-            getattr(e, name)(*a, **k)
-
-    def set_mode(self, *a, **k):
-        self._all('set_mode', *a, **k)
-
-    def set_pipeline(self, on):
-        self._all('set_pipeline', on)
-
-    def set_epilogue_fusion(self, on):
-        self._all('set_epilogue_fusion', on)
-
-    def set_tail_balance(self, on):
-        self._all('set_tail_balance', on)
-
-    def tensor_shape(self, tid):
-        return self.engines[0].tensor_shape(tid)
-
-    def triplet_contrastive(self, probes, gallery, encode_tensor, scale=1.0 / 2500.0, percentile=None, inputs_ready=False):
-        k = self._next
-        self._next = (k + 1) % len(self.engines)
-        main = torch.cuda.current_stream(self.device)
-        st = self.streams[k]
-        if not inputs_ready:
-            st.wait_stream(main)
-        with torch.cuda.stream(st):
-            sal = self.engines[k].triplet_contrastive(probes, gallery, encode_tensor, scale, percentile, inputs_ready=inputs_ready)
-        sal.record_stream(main)
-        main.wait_stream(st)
-        return sal
