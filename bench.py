@@ -275,6 +275,7 @@ def main():
     ap.add_argument('--timeline-json', default=None, help='write the launch-log analysis of the timed schedule (roofline.timeline) to this file')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 10 s sustained loop after the timed region')
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
+    ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
     args = ap.parse_args()
 
@@ -311,6 +312,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.fusion is not None:
+        eng.set_epilogue_fusion(args.fusion)
     if not args.no_pipeline and not args.serial:
         eng.set_pipeline(W.pipeline)      # inputs are resident and never modified: the pipelining contract holds
     step = W.step

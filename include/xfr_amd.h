@@ -222,14 +222,15 @@ xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
  * tensors moved with .to(device) on one stream. */
 xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
 
-/* Epilogue fusion.  Bit 0 (on by default): the hook chain that follows a backward-data GEMM, and BatchNorm / residual add /
- * ReLU after a convolution of a forward-only run (encode, the gallery of a triplet step), execute in the GEMM's epilogue on
- * the LDS-transposed accumulator tile instead of in their own launches -- same arithmetic in the same order, bit-identical
- * maps, about 8 % more triplet maps per second.  Bit 1 (off by default; enable = 3): also BatchNorm / ReLU after a convolution
- * of the PROBE forward, which additionally keeps the raw output and, where a hook needs it, the positive-pass BatchNorm output
- * (measured: bit-identical, +0.3 % per step, 100 launches fewer, 0.5 ms more inside the GEMM launches).  Bit 2 (tests): fused
- * chains run through the INTERPRETED epilogue -- the path a network outside the compiled signature table takes.  enable = 0 gives every elementwise segment its own kernel again (the GEMM launches
- * then contain convolution work only, which is what one wants when profiling the MFMA kernel by itself). */
+/* Epilogue fusion (default: enable = 3).  Bit 0: the hook chain that follows a backward-data GEMM, BatchNorm / residual add /
+ * ReLU after a convolution of a forward-only run (encode, the gallery of a triplet step) and MaxFeatureMap after a Light-CNN
+ * convolution execute in the GEMM's epilogue on the LDS-transposed accumulator tile instead of in their own launches -- same
+ * arithmetic in the same order, bit-identical maps, about 8 % more triplet maps per second.  Bit 1: also BatchNorm / ReLU after a
+ * convolution of the PROBE forward, which additionally keeps the raw output and, where a hook needs it, the positive-pass BatchNorm
+ * output (bit-identical; +0.6 % on ResNet-101, +2.2 % on ResNet-50-128d).  Bit 2 (tests): fused chains run through the
+ * INTERPRETED epilogue -- the path a network outside the compiled signature table takes; the probe-forward and MaxFeatureMap
+ * fusions, which only exist compiled, are then off.  enable = 0 gives every elementwise segment its own kernel again (the GEMM
+ * launches then contain convolution work only, which is what one wants when profiling the MFMA kernel by itself). */
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable);
 
 /* Share one forward pass between consecutive calls on the same input (off by default).  While hold = 1, a run call

@@ -503,7 +503,7 @@ def test_epilogue_fusion_is_bit_identical(gpu_device, arch, mode):
         res[fused] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
                       wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone(),
                       wb.triplet_images_ebp_batch(x[:2], x[2:4], x[1:3]).clone())
-    eng.set_epilogue_fusion(1)
+    eng.set_epilogue_fusion(3)
     for level in (0, 3, 5):
         for a, b in zip(res[1], res[level]):
             assert torch.equal(a, b), level

@@ -29,6 +29,9 @@ enum {
     EW_MAXHALF_IN = 9,// chain HEAD only (stand-alone kernels): the VJP of torch.max(split[0], split[1]) (lightcnn.py:62).  The chain runs
                       // over the 2*Co-channel Split tensor, the source gradient has Co channels: g = src[c % Co], routed by the true
                       // forward halves a = p0[c % Co], b = p0[c % Co + Co] (ties split evenly like at::maximum); action = Co
+    EW_MAXHALF_OUT = 11,// compiled GEMM epilogue only: the same VJP as a FAN-OUT in the epilogue of the GEMM that produces the Co-channel
+                      // gradient: for both halves h the routed gradient runs the REST of the chain as channel c + h*Co of the 2*Co-channel
+                      // tensor (operands loaded in place at that channel) and is stored there; p0 = true forward halves, action = Co
     EW_MAXPAIR = 10   // GEMM epilogue only, last step: g = max(g, value of the partner row c ^ 1) -- MaxFeatureMap of a convolution
                       // whose output channels were packed interleaved (row 2c = channel c, row 2c+1 = channel c + Co); the even
                       // rows then store g as channel c of the Co-channel output
@@ -112,10 +115,16 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld, int fwd_sl
         }
         return -1;
     };
+    bool fanned = false;       // behind EW_MAXHALF_OUT the steps run per half at another channel: their operands are loaded in place
     for (int i = 0; i < ch.n; ++i) {
         EwStep& st = ch.s[i];
         st.ls0 = -1;
         st.ls1 = -1;
+        if (st.type == EW_MAXHALF_OUT) { fanned = true; continue; }
+        if (fanned) {
+            if (st.type == EW_HOOK && !st.pstore && !st.trace && st.action != HOOK_DIV && !st.prior_elem && !st.prior_dense && !st.cap_dst) st.ls0 = -2;
+            continue;
+        }
         if (st.type == EW_HOOK) {
             if (!st.pstore && !st.trace && st.action != HOOK_DIV && !st.prior_elem && !st.prior_dense && !st.cap_dst) { st.ls0 = -2; continue; }
             st.ls0 = slot_for(st.p0, 0);
@@ -134,7 +143,7 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld, int fwd_sl
 // chains outside the table run through the interpreter).  Code = op | s0 << 4 | s1 << 7 | store << 10 | step << 11 with
 // s0 / s1 the prefetch slot of p0 / p1 (0..3), 4 = load in place, 7 = none (a hook whose x is its a).
 enum { SIG_END = 0, SIG_HOOK_DIV = 1, SIG_HOOK_RELU = 2, SIG_HOOK_PASS = 3, SIG_RELU = 4, SIG_MASK = 5, SIG_SCALE_C = 6, SIG_SCALE = 7,
-       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11, SIG_MAXPAIR = 12 };
+       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11, SIG_MAXPAIR = 12, SIG_MAXHALF_OUT = 13 };
 constexpr int sig_op(unsigned c) { return (int)(c & 15u); }
 constexpr int sig_s0(unsigned c) { return (int)((c >> 4) & 7u); }
 constexpr int sig_s1(unsigned c) { return (int)((c >> 7) & 7u); }
@@ -173,6 +182,7 @@ inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
             case EW_RELU: op = SIG_RELU; break;
             case EW_FORK_POSBN: op = SIG_FORK_POSBN; break;
             case EW_MAXPAIR: op = SIG_MAXPAIR; break;
+            case EW_MAXHALF_OUT: op = SIG_MAXHALF_OUT; break;
             default: return -1;
         }
         codes[n++] = (uint16_t)(op | (s0 << 4) | (s1 << 7) | (store << 10) | ((unsigned)i << 11));

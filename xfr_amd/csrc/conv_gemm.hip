@@ -140,8 +140,18 @@ constexpr bool sig_has_maxpair()
     return false;
 }
 
+template <int SIG>
+constexpr bool sig_has_fanout()
+{
+    for (int i = 0; i < XFR_MAX_EW_STEPS; ++i)
+        if (sig_op(kChainSigs[SIG][i]) == SIG_MAXHALF_OUT) return true;
+    return false;
+}
+
 struct EpiOps {          // operands of one float4 piece; indexed by compile-time constants only (stays in registers)
     float4 partner;      // SIG_MAXPAIR: the same positions of row c ^ 1 (bias included)
+    float4* out4;        // SIG_MAXHALF_OUT: the fan-out stores its two halves itself
+    unsigned row4, arow4;
     float4 v[EW_NLOADS];
     float pc0[XFR_MAX_EW_STEPS], pc1[XFR_MAX_EW_STEPS];
 };
@@ -225,6 +235,22 @@ __device__ __forceinline__ void epi_steps(float (&g)[4], const EpiOps& o, const 
         } else if constexpr (op == SIG_AFFINE_C) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(__fmul_rn(g[q], o.pc0[I]), o.pc1[I]);
+        } else if constexpr (op == SIG_MAXHALF_OUT) {
+            // VJP of torch.max(split[0], split[1]) as a fan-out: both halves run the rest of the chain at their own channel and store
+            const int Co = ch.s[st].action;
+            const float4* tin = reinterpret_cast<const float4*>(ch.s[st].p0);
+            const float4 ta = tin[aidx4], tb = tin[aidx4 + (unsigned)Co * o.arow4];
+            const float av[4] = {ta.x, ta.y, ta.z, ta.w}, bv[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float gh[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gh[q] = ew_maxhalf_route(g[q], h ? bv[q] : av[q], h ? av[q] : bv[q]);
+                const unsigned i4 = idx4 + (unsigned)(h * Co) * o.row4, a4 = aidx4 + (unsigned)(h * Co) * o.arow4;
+                if constexpr (I + 1 < XFR_MAX_EW_STEPS) epi_steps<SIG, I + 1>(gh, o, ch, i4, a4, eps);
+                o.out4[i4] = make_float4(gh[0], gh[1], gh[2], gh[3]);
+            }
+            return;
         } else if constexpr (op == SIG_MAXPAIR) {
             // torch.max(a, b): NaN propagates (lightcnn.py:62 through at::maximum)
             const float w[4] = {o.partner.x, o.partner.y, o.partner.z, o.partner.w};
@@ -293,9 +319,12 @@ __device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& 
             if (bsel && ok[hf]) { const float b = bsel[cos[hf] ^ 1]; w.x += b; w.y += b; w.z += b; w.w += b; }
             ops[hf].partner = w;
         }
+        if constexpr (sig_has_fanout<SIG>()) { ops[hf].out4 = out4; ops[hf].row4 = row4; ops[hf].arow4 = arow4; }
         if (ok[hf]) {
             epi_steps<SIG, 0>(g, ops[hf], p.chain, idx4[hf], aidx4[hf], p.chain_eps);
-            if constexpr (sig_has_maxpair<SIG>()) {
+            if constexpr (sig_has_fanout<SIG>()) {
+                // stored by the fan-out
+            } else if constexpr (sig_has_maxpair<SIG>()) {
                 // both rows of a pair hold the maximum now; the even row stores it as channel cos / 2 of the Co-channel output
                 if ((cos[hf] & 1) == 0) out4[(unsigned)(cos[hf] >> 1) * row4 + (unsigned)mm / 4u] = make_float4(g[0], g[1], g[2], g[3]);
             } else {
@@ -1274,6 +1303,8 @@ bool launch_one(const ConvParams& p, hipStream_t s)
             q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
             if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
             if (q.nhalves == 2 && q.chain_sig < 0) return false;      // a dual launch can only carry a compiled chain: the caller un-fuses
+            for (int i = 0; i < q.chain.n && q.chain_sig < 0; ++i)
+                if (q.chain.s[i].type == EW_MAXPAIR || q.chain.s[i].type == EW_MAXHALF_OUT) return false;   // steps the interpreter does not have
             g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
             if (q.chain_sig >= 0)
                 hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 1>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
@@ -1321,6 +1352,8 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
         q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
         if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
         if (q.nhalves == 2 && q.chain_sig < 0) return false;      // a dual launch can only carry a compiled chain: the caller un-fuses
+        for (int i = 0; i < q.chain.n && q.chain_sig < 0; ++i)
+            if (q.chain.s[i].type == EW_MAXPAIR || q.chain.s[i].type == EW_MAXHALF_OUT) return false;   // steps the interpreter does not have
         g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
         if (q.chain_sig >= 0)
             hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 1>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 else if (st.type == EW_ADDP) g += st.p0[idx];
                 else if (st.type == EW_AFFINE_C) g = __fadd_rn(__fmul_rn(g, st.p0[c]), st.p1[c]);
                 else if (st.type == EW_RELU) g = fmaxf(g, 0.f);
-                else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR) { }      // applied at the load / compiled epilogues only
+                else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_MAXHALF_OUT) { }      // applied at the load / compiled epilogues only
                 else st.pstore[idx] = __fadd_rn(__fmul_rn(fmaxf(g, 0.f), st.p0[c]), st.p1[c]);
             }
         }

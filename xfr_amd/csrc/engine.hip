@@ -113,6 +113,7 @@ struct BwdPlan {
     std::vector<BwdStep> steps;      // one launch per step, no cross-kernel fusion (used when tracing)
     std::vector<BwdStep> fused;      // after copy forwarding and chain -> chain merging
     std::vector<BwdStep> fused_gemm; // ... and with the chains that follow a backward GEMM run in its epilogue
+    std::vector<BwdStep> fused_gemm_nofan; // the same without the MaxFeatureMap fan-out (a compiled-only epilogue step): what the interpreted epilogues run
     std::vector<int> firing_kinds;   // xfr_op_kind per firing, reference order
     int n_firings = 0;
 };
@@ -193,8 +194,8 @@ struct xfr_engine {
     bool tail_balance = true;          // xfr_engine_set_tail_balance
     bool interpret_chains = false;     // xfr_engine_set_epilogue_fusion bit 2: fused chains run through the interpreted epilogue (tests)
     bool planning_only = false;        // xfr_plan_describe: list what the planner WOULD fuse, whatever the signature table holds
-    bool fuse_probe_fwd = false;       // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue.  Off by
-                                       // default: measured +0.3 % per step, bit-identical -- and 0.5 ms more inside the GEMM launches
+    bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue (STORE raw, [FORK positive
+                                       // BatchNorm], affine, clamp).  Round 3, MI355X: +0.6 % maps/s on ResNet-101, +2.2 % on ResNet-50-128d, bit-identical
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
                                        // (both: xfr_engine_set_epilogue_fusion; DESIGN.md section 6 has the measurements)
@@ -1156,15 +1157,17 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
     }
     // ---- 2 + 3, to a fixed point: first among the chain launches only (plan.fused: the schedule of the sweeps that carry
     // priors / captures), then with the backward GEMMs as heads of chains too (plan.fused_gemm)
-    for (int pass = 0; pass < 2; ++pass) {
+    // pass 2: additionally the MaxFeatureMap VJP as a fan-out in the epilogue of the GEMM that produces its gradient
+    for (int pass = 0; pass < 3; ++pass) {
     if (pass == 1) plan.fused = st;
+    if (pass == 2) plan.fused_gemm_nofan = st;
     bool changed = true;
     while (changed) {
         changed = false;
         for (size_t i = 0; i < st.size() && !changed; ++i) {
             BwdStep& a = st[i];
             const bool a_ew = a.kind == ST_EW;
-            const bool a_conv = pass == 1 && a.kind == ST_CONV_BWD && !scatter_conv(a);
+            const bool a_conv = pass >= 1 && a.kind == ST_CONV_BWD && !scatter_conv(a);
             if (!a_ew && !a_conv) continue;
             const int b_t = a.dst_t;
             if (b_t < 0) continue;
@@ -1177,11 +1180,23 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
                 if (reads(st[j], b_t) || writes(st[j], b_t)) break;
             if (j >= st.size()) continue;
             BwdStep& c = st[j];
-            if (c.kind != ST_EW || c.src_t != b_t || writes(c, b_t)) continue;
-            if (e->tens[c.ew_t].C != e->tens[b_t].C || e->tens[c.ew_t].HW() != e->tens[b_t].HW()) continue;
+            // an IN-PLACE chain on b_t (hooks flushed where the producer is glue) merges too: the merged launch simply ends in b_t
+            bool inplace = c.kind == ST_EW && c.dst_t == b_t && !c.accumulate;
+            for (const Sym& y : c.chain) if (y.type == EW_STORE && y.t0 == b_t) inplace = false;
+            if (c.kind != ST_EW || c.src_t != b_t || (writes(c, b_t) && !inplace)) continue;
+            // fan-out: GEMM (-> Co channels) followed by the chain whose head is the MaxFeatureMap VJP (over 2 * Co channels)
+            bool fan = false;
+            if (pass == 2 && a_conv && !c.chain.empty() && c.chain[0].type == EW_MAXHALF_IN && e->tens[c.ew_t].C == 2 * e->tens[b_t].C &&
+                e->tens[c.ew_t].HW() == e->tens[b_t].HW() && (e->tens[b_t].HW() & 3) == 0) {
+                fan = true;
+                for (const Sym& y : a.chain) if (y.type == EW_MAXHALF_OUT) fan = false;
+                for (size_t q = 1; q < c.chain.size(); ++q)
+                    if (c.chain[q].type == EW_SCALE_C || c.chain[q].type == EW_AFFINE_C || c.chain[q].type == EW_FORK_POSBN) fan = false;   // per-channel
+            }                                                                                                                        // parameters of row c
+            if (!fan && (e->tens[c.ew_t].C != e->tens[b_t].C || e->tens[c.ew_t].HW() != e->tens[b_t].HW())) continue;
             // does anything after j still read b_t?
             bool other_readers = false;
-            for (size_t k = j + 1; k < st.size(); ++k) {
+            for (size_t k = j + 1; k < st.size() && !inplace; ++k) {      // (in place: later readers want the chain's result, which is what stays)
                 if (reads(st[k], b_t)) { other_readers = true; break; }
                 if (writes(st[k], b_t)) break;
             }
@@ -1202,8 +1217,15 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
                 // a accumulates into b_t (partial sums already there): fold as an addend, then continue
                 merged.push_back(mk(EW_ADDP, b_t));
             }
-            if (other_readers || a.accumulate) merged.push_back(mk(EW_STORE, b_t));
-            merged.insert(merged.end(), c.chain.begin(), c.chain.end());
+            if ((other_readers || a.accumulate) && !inplace) merged.push_back(mk(EW_STORE, b_t));
+            if (fan) {
+                Sym f = c.chain[0];
+                f.type = EW_MAXHALF_OUT;
+                merged.push_back(f);
+                merged.insert(merged.end(), c.chain.begin() + 1, c.chain.end());
+            } else {
+                merged.insert(merged.end(), c.chain.begin(), c.chain.end());
+            }
             if (c.accumulate) merged.push_back(mk(EW_ADDP, u));
             if ((int)merged.size() > XFR_MAX_EW_STEPS) continue;
             a.chain = merged;
@@ -1275,6 +1297,7 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
                 break;
             case EW_MASK: q.p0 = e->T(sy.t0); break;
             case EW_MAXHALF_IN: q.p0 = e->T(sy.t0); break;
+            case EW_MAXHALF_OUT: q.p0 = e->T(sy.t0); break;
             case EW_SCALE_C: q.p0 = e->arena + (plain ? e->ops[sy.op].bn_alpha_t : e->ops[sy.op].bn_alpha_p); break;
             case EW_STORE: q.pstore = e->G(sy.t0); break;
             case EW_ADDP: q.p0 = e->G(sy.t0); break;
@@ -1301,7 +1324,7 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
     const bool prefix = !e->rc_active.empty() && (int)e->rc_active.size() * e->rc_n == SB;
     int run_max = -1;
     const bool use_gemm_fusion = use_fused && e->fuse_gemm_epilogue && !special && !plan.fused_gemm.empty();
-    for (const BwdStep& st : (use_gemm_fusion ? plan.fused_gemm : use_fused ? plan.fused : plan.steps)) {
+    for (const BwdStep& st : (use_gemm_fusion ? (e->interpret_chains ? plan.fused_gemm_nofan : plan.fused_gemm) : use_fused ? plan.fused : plan.steps)) {
         int SBa = SB;
         if (prefix) {
             for (const auto& sy : st.chain)

@@ -123,7 +123,7 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int s
         } else if (st.type == EW_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
-        } else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR) {
+        } else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_MAXHALF_OUT) {
             // MAXHALF_IN was applied where the gradient was loaded (ew_maxhalf_route); MAXPAIR only exists in compiled epilogues
         } else {
             const float al = st.p0[c], be = st.p1[c];

@@ -194,7 +194,7 @@ class Engine(object):
 
     def set_epilogue_fusion(self, on):
         """Hook chains / BatchNorm+add+ReLU inside the GEMM epilogue (default on) or as their own launches."""
-        level = int(on) if not isinstance(on, bool) else (1 if on else 0)      # 0 off, 1 default, 3 = also the probe forward
+        level = int(on) if not isinstance(on, bool) else (3 if on else 0)      # 0 off, 3 default (1: without the probe forward's BatchNorm / ReLU)
         _lib.check(self.lib.xfr_engine_set_epilogue_fusion(self._h, level))
         self.options['epilogue_fusion'] = level
 
