@@ -283,11 +283,26 @@ def test_rccl_backend_of_the_python_path_world_size_1(gpu_device):
     """The torch.distributed calls bench.py and the tools make at N > 1 -- broadcast of the arena, all_gather of maps, all_reduce
     MAX, barrier -- through the RCCL backend itself (one rank: that is what one GPU allows; the 2-rank tests above use gloo)."""
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29677', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-               HSA_ENABLE_IPC_MODE_LEGACY='0')
+               HSA_ENABLE_IPC_MODE_LEGACY='0', NCCL_DEBUG='INFO')
     env.pop('XFR_DIST_BACKEND', None)
     out = subprocess.run([sys.executable, '-c', NCCL_WORLD1 % (ROOT, os.path.join(ROOT, 'tests'))], cwd=ROOT, env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and 'NCCL_WORLD1_OK 1.5' in out.stdout, out.stderr[-3000:]
+    # NCCL_DEBUG=INFO: the communicator that carried the collectives is RCCL's (its banner and its init lines), not a stand-in
+    log = out.stdout + out.stderr
+    assert 'RCCL version' in log and 'NCCL INFO' in log and 'Init COMPLETE' in log, log[-3000:]
+
+
+def test_bench_dry_run_and_rank_report(gpu_device):
+    """bench.py --gpus 2 --dry-run: rendezvous, ONE arena broadcast, per-rank report (device, arena checksum, RCCL version), one
+    step, barrier, exit -- the fast failure check for a multi-GPU box.  Both ranks must end up with the same arena bits."""
+    outs = _run_ranks(['bench.py', '--gpus', '2', '--batch', '4', '--dry-run'], 2, 29663)
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j['dry_run'] is True and j['n_gpus'] == 2 and j['outputs_finite'] is True and len(j['ranks']) == 2
+    assert [r['rank'] for r in j['ranks']] == [0, 1] and len({r['arena_checksum48'] for r in j['ranks']}) == 1
+    assert all(r['arena_bytes'] > 0 and r['rccl'] for r in j['ranks'])
 
 
 def test_rccl_entry_points_world_size_1(gpu_device):

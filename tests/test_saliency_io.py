@@ -120,3 +120,68 @@ def test_create_save_smap_format_and_resume(tmp_path):
     assert SIO.create_save_smap(name, out, False, smap_fn, '00003', probe) is True and len(calls) == 2
     assert SIO.create_save_smap(name, out, True, smap_fn, '00003', probe) is True and len(calls) == 3
     np.testing.assert_array_equal(SIO.load_smap(out, '00003', name), sm)
+
+
+def _bspline3(t):
+    """Cubic B-spline basis, written out (support [-2, 2])."""
+    t = np.abs(t)
+    return np.where(t < 1, 2.0 / 3.0 - t * t + 0.5 * t ** 3, np.where(t < 2, (2.0 - t) ** 3 / 6.0, 0.0))
+
+
+def _spline_resize_by_hand(img, out_shape):
+    """Cubic-spline resampling derived from first principles, independent of scipy.ndimage: (1) the B-spline coefficients c of
+    every row / column solve the tridiagonal system (c[k-1] + 4 c[k] + c[k+1]) / 6 = s[k] (dense solve, 'not-a-knot-free' ends:
+    rows of the matrix truncated at the border, whose influence decays like (sqrt(3) - 2)^d, i.e. 4e-12 at 20 pixels); (2) output
+    pixel i samples the spline at x = (i + 0.5) * n_in / n_out - 0.5 (pixel centres map to pixel centres: what skimage >= 0.19
+    obtains from zoom(..., grid_mode=True))."""
+    out = np.asarray(img, dtype=np.float64)
+    for ax, n_out in enumerate(out_shape):
+        n_in = out.shape[ax]
+        A = (np.diag(np.full(n_in, 4.0)) + np.diag(np.ones(n_in - 1), 1) + np.diag(np.ones(n_in - 1), -1)) / 6.0
+        c = np.linalg.solve(A, np.moveaxis(out, ax, 0).reshape(n_in, -1))
+        x = (np.arange(n_out) + 0.5) * n_in / n_out - 0.5
+        Wm = _bspline3(x[:, None] - np.arange(n_in)[None, :])
+        res = (Wm @ c).reshape((n_out,) + tuple(np.delete(out.shape, ax)))
+        out = np.moveaxis(res, 0, ax)
+    return out
+
+
+@pytest.mark.parametrize('out', [(224, 224), (160, 160), (160, 224)])
+def test_cubic_resize_equals_the_hand_derived_spline_in_the_interior(out):
+    """processSaliency's resize (show.py:136: skimage.transform.resize(order=3, mode='constant')) at the generator's sizes
+    (112 -> 224) and a non-integer factor (112 -> 160): away from the border -- where the 'constant' padding has decayed -- the
+    module's restatement equals cubic-spline resampling written out by hand.  Parity with skimage ITSELF stays unpinned (the
+    package cannot be installed in this image); this pins the restatement to the mathematics skimage's release notes and source
+    (v0.19.0, skimage/transform/_warps.py: resize -> scipy.ndimage.zoom(order=3, grid_mode=True)) describe."""
+    rng = np.random.default_rng(3)
+    sm = ndi_smooth(rng.random((112, 112)))
+    got = SIO._resize_cubic(sm, out)
+    want = _spline_resize_by_hand(sm, out)
+    m = 48                                           # output pixels: 24 input pixels at the 2x zoom
+    assert got.shape == out
+    np.testing.assert_allclose(got[m:-m, m:-m], np.clip(want, min(sm.min(), 0), max(sm.max(), 0))[m:-m, m:-m], rtol=0, atol=1e-9)
+
+
+def ndi_smooth(a):
+    import scipy.ndimage as ndi
+    return ndi.gaussian_filter(a, 3.0)
+
+
+def test_cubic_resize_analytic_cases():
+    """What cubic-spline resampling must do exactly: a constant stays constant and a linear ramp stays the same ramp in the
+    interior (splines reproduce polynomials up to degree 3), the same size is the identity everywhere, and the zero padding of
+    mode='constant' can only darken the border, never brighten it."""
+    c = SIO._resize_cubic(np.full((112, 112), 0.37), (224, 224))
+    np.testing.assert_allclose(c[40:-40, 40:-40], 0.37, atol=1e-12)
+    assert c.max() <= 0.37 + 1e-12 and c[0, 0] < 0.37                      # zero border bleeds in, clipping keeps the range
+    yy, xx = np.mgrid[0:112, 0:112].astype(np.float64)
+    ramp = 0.25 * yy + 0.5 * xx + 3.0
+    for out in ((224, 224), (160, 160)):
+        up = SIO._resize_cubic(ramp, out)
+        fy, fx = 112.0 / out[0], 112.0 / out[1]
+        oy, ox = np.mgrid[0:out[0], 0:out[1]].astype(np.float64)
+        want = 0.25 * ((oy + 0.5) * fy - 0.5) + 0.5 * ((ox + 0.5) * fx - 0.5) + 3.0
+        m = int(30 / min(fy, fx))
+        np.testing.assert_allclose(up[m:-m, m:-m], want[m:-m, m:-m], atol=1e-9)
+    sm = np.random.default_rng(5).random((112, 112))
+    np.testing.assert_array_equal(SIO._resize_cubic(sm, (112, 112)), sm)

@@ -564,10 +564,10 @@ class Whitebox(object):
         if not isinstance(imagesT, torch.Tensor):
             imagesT = torch.stack(list(imagesT))
         batches = torch.split(imagesT, self.batch_size, dim=0)
-        embeds = []
-        for k, batch in enumerate(batches):
-            embeds.append(self.encode(batch).detach().cpu().numpy())
-        embeds = np.concatenate(embeds)
+        # the reference moves every batch to the host as it goes (:776); here the encodings stay on the device until the last batch
+        # is enqueued -- one synchronisation per call instead of one per batch (6500 masked probes per image at RISE scale)
+        embeds = [self.encode(batch).detach() for batch in batches]
+        embeds = torch.cat(embeds, dim=0).cpu().numpy()
         if norm:
             embeds = (embeds.reshape((embeds.shape[0], -1)) /
                       np.linalg.norm(embeds.reshape((embeds.shape[0], -1)), axis=1, keepdims=True)).reshape(embeds.shape)

@@ -16,9 +16,12 @@ that release computes `factors = in_shape / out_shape`; when any factor > 1 and 
 `ndi.gaussian_filter(image, (factors - 1) / 2, cval=0, mode='constant')`; then `ndi.zoom(image, 1 / factors, order=3,
 mode='grid-constant' (_to_ndimage_mode('constant')), cval=0, grid_mode=True)`; then `_clip_warp_output`: clip to
 [min(in.min, cval), max(in.max, cval)].  (skimage < 0.19 went through `warp`, whose border handling differs; README.md:37 of
-the reference only asks for >= 0.17.2, so the reference itself is not pinned to one behaviour here.)  tests/test_saliency_io.py
-checks the stated properties (identity, pixel-centre mapping, clipping, shrinking, non-square outputs); the jet table is
-checked against matplotlib itself.
+the reference only asks for >= 0.17.2, so the reference itself is not pinned to one behaviour here.)  Source restated: scikit-image release tag v0.19.0,
+`skimage/transform/_warps.py`, functions `resize` and `_clip_warp_output` (no network here: the tag is cited, not a commit hash
+that could not be checked).  What IS pinned (tests/test_saliency_io.py): the restatement equals cubic-spline resampling written
+out by hand -- tridiagonal B-spline coefficients, pixel-centre coordinate map -- to 1e-9 in the interior at 112 -> 224, 112 -> 160
+and 112 -> 160 x 224; constants and linear ramps are reproduced exactly there; the same size is the identity; the zero padding
+only darkens the border; clipping, shrinking and non-square outputs behave as stated; the jet table equals matplotlib's.
 """
 import os
 
