@@ -119,6 +119,16 @@ __device__ __forceinline__ int out_row(const ConvParams& p, int co) { return p.c
 // accumulator tile has even been turned through LDS, and the per-step descriptor fields are scalar loads at fixed offsets.
 #include "chain_sigs.inc"
 
+// host side: does compiled signature `sig` belong to the MaxFeatureMap kernel family (chain_epilogue_dispatch)
+inline bool chain_sig_is_mfm(int sig)
+{
+    for (int i = 0; i < XFR_MAX_EW_STEPS; ++i) {
+        const int op = sig_op(kChainSigs[sig][i]);
+        if (op == SIG_MAXPAIR || op == SIG_MAXHALF_OUT) return true;
+    }
+    return false;
+}
+
 template <int SIG>
 constexpr unsigned sig_live_slots()
 {
@@ -361,13 +371,21 @@ __device__ __forceinline__ void dense_epilogue(const ConvParams& p, const v16f& 
     }
 }
 
+// The compiled epilogues live in two kernel families: the MaxFeatureMap signatures (pair maximum, fan-out VJP: two more operand
+// loads and a chain tail that runs twice) need ~10 registers more than the rest, and a kernel's register count -- hence how many
+// workgroups share a CU -- is the maximum over everything it contains.  MFM = false: every other signature (all ResNet chains).
 template <int SIG>
+constexpr bool sig_is_mfm() { return sig_has_maxpair<SIG>() || sig_has_fanout<SIG>(); }
+
+template <int SIG, bool MFM>
 __device__ __forceinline__ void chain_epilogue_dispatch(int sig, const ConvParams& p, const v16f& acc, float* tile, int lane, int l31,
                                                         int lhi, int co_base, int m, float* __restrict__ osel, const float* __restrict__ bsel)
 {
     if constexpr (SIG < kNumChainSigs) {
-        if (sig == SIG) chain_epilogue<SIG>(p, acc, tile, lane, l31, lhi, co_base, m, osel, bsel);
-        else chain_epilogue_dispatch<SIG + 1>(sig, p, acc, tile, lane, l31, lhi, co_base, m, osel, bsel);
+        if constexpr (sig_is_mfm<SIG>() == MFM) {
+            if (sig == SIG) { chain_epilogue<SIG>(p, acc, tile, lane, l31, lhi, co_base, m, osel, bsel); return; }
+        }
+        chain_epilogue_dispatch<SIG + 1, MFM>(sig, p, acc, tile, lane, l31, lhi, co_base, m, osel, bsel);
     }
 }
 
@@ -426,12 +444,12 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
     // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
     // Optional fused micro-program (half 0 only): forward = bias -> [store raw] -> BatchNorm -> [+residual] -> ReLU;
     // backward = [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP -> next GEMM's input.
-    if constexpr (CHAIN == 1) {
-        // compiled chain epilogue; launch_one only selects this instantiation when the float4 layout conditions hold.  The chain
+    if constexpr (CHAIN == 1 || CHAIN == 3) {
+        // compiled chain epilogue (CHAIN 3: the MaxFeatureMap signatures); launch_one only selects this instantiation when the float4 layout conditions hold.  The chain
         // belongs to half 0; the relu(W) half of a dual launch (positive activations) leaves as plain dense rows.
         if constexpr (MI == 1 && NJ == 1) {
             if (half == 0)
-                chain_epilogue_dispatch<0>(p.chain_sig, p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
+                chain_epilogue_dispatch<0, CHAIN == 3>(p.chain_sig, p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
                                            m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
             else
                 dense_epilogue(p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32, m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
@@ -1306,7 +1324,9 @@ bool launch_one(const ConvParams& p, hipStream_t s)
             for (int i = 0; i < q.chain.n && q.chain_sig < 0; ++i)
                 if (q.chain.s[i].type == EW_MAXPAIR || q.chain.s[i].type == EW_MAXHALF_OUT) return false;   // steps the interpreter does not have
             g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
-            if (q.chain_sig >= 0)
+            if (q.chain_sig >= 0 && chain_sig_is_mfm(q.chain_sig))
+                hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 3>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+            else if (q.chain_sig >= 0)
                 hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 1>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
             else
                 hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 2>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
@@ -1355,7 +1375,9 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
         for (int i = 0; i < q.chain.n && q.chain_sig < 0; ++i)
             if (q.chain.s[i].type == EW_MAXPAIR || q.chain.s[i].type == EW_MAXHALF_OUT) return false;   // steps the interpreter does not have
         g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
-        if (q.chain_sig >= 0)
+        if (q.chain_sig >= 0 && chain_sig_is_mfm(q.chain_sig))
+            hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 3>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+        else if (q.chain_sig >= 0)
             hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 1>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
         else
             hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 2>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
@@ -1373,9 +1395,11 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
 template <int BK>
 bool ks_ok(const ConvParams& p)
 {
-    if (p.stride != 1 || (p.Cin % BK) != 0 || p.out_stride != 1) return false;
-    if (p.kh == 1 && p.kw == 1) return p.pad == 0;
-    return p.tap_major == 1 && p.kh * p.kw <= 64;
+    if ((p.Cin % BK) != 0) return false;
+    if (p.kh == 1 && p.kw == 1) return p.pad == 0 && p.stride <= 2;      // strided 1x1 (projection / reduce convolutions): the one-tap gather;
+                                                                         // their backward-data GEMM scatters in the epilogue (out_stride)
+    if (p.out_stride != 1) return false;
+    return p.stride == 1 && p.tap_major == 1 && p.kh * p.kw <= 64;
 }
 
 template <int BK, int NST>
@@ -1413,6 +1437,7 @@ int conv_gemm_chain_sig(const EwChain& ch)
     return -1;
 }
 int conv_gemm_num_chain_sigs() { return kNumChainSigs; }
+
 void conv_gemm_chain_launch_counts(long* compiled, long* interpreted)
 {
     if (compiled) *compiled = g_chain_launches[0].load();
@@ -1429,11 +1454,13 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     static const int ks = [] { const char* e = getenv("XFR_KS"); return e ? atoi(e) : 7; }();
     static const int ks_mink = [] { const char* e = getenv("XFR_KS_MINK"); return e ? atoi(e) : 512; }();
     static const int ks_rule = [] { const char* e = getenv("XFR_KS_RULE"); return e ? atoi(e) : 1; }();
-    if (ks >= 6 && ks <= 10 && p.K >= ks_mink && ks_ok<16>(p)) {
+    if ((ks == 6 || ks == 7) && ks_ok<8>(p)) {
         // rule 1: only where the in-engine serial table shows a gain (tools/cmp_layers.py): deep-K 3x3 (ResNet layers 3 / 4: -4..-12 %)
         // and the 1x1 layers with K = 512 or K >= 2048 (-3..-14 %); K = 1024 loses 4 %.  The choice depends on the LAYER only, never on
         // the batch: the two kernels sum K in different orders, and a sample's map must not depend on how many samples share its launch
-        if (ks_rule == 0 || (p.kh > 1 && p.K >= 2048) || (p.kh == 1 && (p.K == 512 || p.K >= 2048))) return ks;
+        // strided 1x1 convolutions (forward: gathered input; backward: scattered output) gain 60-70 % over the generic-gather kernel
+        if (p.kh == 1 && (p.stride == 2 || p.out_stride == 2)) return ks;
+        if (p.K >= ks_mink && (ks_rule == 0 || (p.kh > 1 && p.K >= 2048) || (p.kh == 1 && (p.K == 512 || p.K >= 2048)))) return ks;
     }
     // Deep-K launches of at most two tiles per CU (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers
     // per MFMA.  Their 48 KB ring allows three workgroups per CU, so larger grids (the W / relu(W) dual launch of the
@@ -1488,12 +1515,10 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
         g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
     }
     const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
-    // cfg 6..10: the intra-workgroup split-K kernel (BK, ring stages) = (8,3) (4,4) (4,5) (4,6) (16,3)
+    // cfg 6 / 7: the intra-workgroup split-K kernel, (BK, ring stages) = (8, 3): 48 KB of LDS, three workgroups per CU; (4, 4): 32 KB, five.
+    // Round 3 sweep (tools/conv_sweep.py): (4, 5) and (4, 6) tie with (4, 4), (16, 3) -- one workgroup per CU -- loses 15 %.
     if (cfg == 6 && ks_ok<8>(p)) return launch_cfg_ks<8, 3>(p, s);
     if (cfg == 7 && ks_ok<4>(p)) return launch_cfg_ks<4, 4>(p, s);
-    if (cfg == 8 && ks_ok<4>(p)) return launch_cfg_ks<4, 5>(p, s);
-    if (cfg == 9 && ks_ok<4>(p)) return launch_cfg_ks<4, 6>(p, s);
-    if (cfg == 10 && ks_ok<16>(p)) return launch_cfg_ks<16, 3>(p, s);
     if (cfg == 5) return launch_cfg<64, 64, 32, 3>(p, s);
     return launch_cfg<64, 64, 16, 3>(p, s);
 }
