@@ -669,7 +669,7 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
 
 // CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue (p.chain_sig), 2 = interpreted chain epilogue
 template <int TCO, int TM, int BK, int NST, int MODE, bool RELU, int CHAIN>
-__global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
+__global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : 6)) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     constexpr int MI = TCO / 64;   // MFMA tiles per wave along co
     constexpr int NJ = TM / 64;    // MFMA tiles per wave along m
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvParams p, const
     stamp(p, wave, lane, 2);
     stamp(p, wave, lane, 3);
 
-    block_epilogue<CHAIN, (NST * STAGE >= 4 * 32 * 36)>(p, acc, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel);
+    block_epilogue<CHAIN, true>(p, acc, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel);      // the launcher allocates at least the four 32 x 36 tiles
     stamp(p, wave, lane, 4);
 }
 
@@ -1030,7 +1030,7 @@ __device__ __forceinline__ void ks_exchange(float* smem, const v16f (&acc)[2][2]
 }
 
 template <int BK, int NST, int MODE, bool RELU, int CHAIN>
-__global__ __launch_bounds__(NT, 3) void conv_gemm_ks_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
+__global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     static_assert(MODE == MODE_VEC || MODE == MODE_TAP, "the split-K kernel covers the 1x1 float4 path and the tap-major gather");
     constexpr int TCO = 64, TM = 64;
@@ -1295,7 +1295,7 @@ bool launch_one(const ConvParams& p, hipStream_t s)
 {
     const int n_co = ((p.CoutTot + TCO - 1) / TCO) * p.nhalves;
     const int n_m = (p.M + TM - 1) / TM;
-    const size_t lds = (size_t)NST * BK * (TCO + TM) * sizeof(float) + (MODE == MODE_GEN ? 512 * sizeof(int2) : 0);
+    const size_t lds = std::max((size_t)NST * BK * (TCO + TM) * sizeof(float) + (MODE == MODE_GEN ? 512 * sizeof(int2) : 0), (size_t)4 * 32 * 36 * sizeof(float));
     ConvParams q = p;
     int grid = n_co * n_m;
     q.tail_q = 0;
@@ -1316,7 +1316,7 @@ bool launch_one(const ConvParams& p, hipStream_t s)
             ew_plan_loads(wide, q.out0, wide_ld, EW_FWD_SLOTS_WIDE);
             ew_plan_loads(q.chain, q.out0, q.chain_ld);
             const int ohw = q.OH * q.OW;
-            const bool vec_ok = (size_t)NST * BK * (TCO + TM) >= 4 * 32 * 36 && (q.M & 3) == 0 && ((q.chain_B * ohw) & 3) == 0 &&
+            const bool vec_ok = (q.M & 3) == 0 && ((q.chain_B * ohw) & 3) == 0 &&
                                 ((q.out_nb * ohw) & 3) == 0;
             q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
             if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
