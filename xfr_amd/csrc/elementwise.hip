@@ -321,6 +321,22 @@ __global__ __launch_bounds__(NT) void copy_acc_kernel(const float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(NT) void copy_acc_kernel_v4(const float4* __restrict__ src, float4* __restrict__ dst, long n4, int accumulate)
+{
+    const long i0 = (long)blockIdx.x * (NT * ST_U) + threadIdx.x;
+    float4 v[ST_U], d[ST_U];
+#pragma unroll
+    for (int u = 0; u < ST_U; ++u)
+        if (i0 + u * NT < n4) { v[u] = src[i0 + u * NT]; if (accumulate) d[u] = dst[i0 + u * NT]; }
+#pragma unroll
+    for (int u = 0; u < ST_U; ++u) {
+        if (i0 + u * NT >= n4) continue;
+        float4 o = v[u];
+        if (accumulate) { o.x += d[u].x; o.y += d[u].y; o.z += d[u].z; o.w += d[u].w; }
+        dst[i0 + u * NT] = o;
+    }
+}
+
 __global__ __launch_bounds__(NT) void fill_kernel(float* __restrict__ p, long n, float v)
 {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) p[i] = v;
@@ -442,10 +458,12 @@ __global__ __launch_bounds__(NT) void avgpool_bwd_kernel(const float* __restrict
 // float4 variants of the pool VJPs and the average pool: blockIdx.y = plane (channel x gradient row), a thread owns four consecutive
 // pixels of one row, 32-bit index arithmetic only (the scalar kernels above pay a 64-bit division per element: the 3x3/2 max-pool
 // VJP of a 32-triplet step -- 205 MB written -- ran at 0.9 TB/s).  W % 4 == 0.
+template <int KK, int SS>     // compile-time window / stride (0: run-time values): the window bounds are divisions by the stride
 __global__ __launch_bounds__(NT) void maxpool_bwd_kernel_v4(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
                                                            float4* __restrict__ gin, int accumulate, int SB, int B, int H, int W,
-                                                           int OH, int OW, int k, int stride, int pad)
+                                                           int OH, int OW, int k_rt, int stride_rt, int pad)
 {
+    const int k = KK ? KK : k_rt, stride = SS ? SS : stride_rt;
     const int plane = blockIdx.y;                       // c * SB + sb
     const int c = plane / SB, sb = plane - c * SB;
     const int W4 = W >> 2;
@@ -459,6 +477,34 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel_v4(const float* __restr
     int oh_hi = (ih + pad) / stride;
     if (oh_hi > OH - 1) oh_hi = OH - 1;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KK > 0 && SS > 0) {
+        // the windows that can hold one of the four pixels: ow in [ow_lo(iw0), ow_hi(iw0 + 3)] -- at most NOW of them; their argmax
+        // bytes and gradients are loaded once per row and handed to the pixels they point at
+        constexpr int NOW = (KK + 2) / SS + 2;
+        int ow_b = iw0 + pad - KK + 1;
+        ow_b = ow_b > 0 ? (ow_b + SS - 1) / SS : 0;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            const int dh = ih - (oh * SS - pad);
+            int id[NOW];
+            float g[NOW];
+#pragma unroll
+            for (int t = 0; t < NOW; ++t) {
+                const int ow = ow_b + t;
+                const bool in = ow < OW;
+                id[t] = in ? (int)ix[oh * OW + ow] : -1;
+                g[t] = in ? go[oh * OW + ow] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < NOW; ++t) {
+                const int dw0 = iw0 - ((ow_b + t) * SS - pad);          // window-local column of pixel 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int dw = dw0 + j;
+                    if (dw >= 0 && dw < KK && id[t] == dh * KK + dw) acc[j] += g[t];
+                }
+            }
+        }
+    } else {
     for (int oh = oh_lo; oh <= oh_hi; ++oh) {
         const int dh = ih - (oh * stride - pad);
 #pragma unroll
@@ -472,15 +518,18 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel_v4(const float* __restr
                 if ((int)ix[oh * OW + ow] == dh * k + (iw - (ow * stride - pad))) acc[j] += go[oh * OW + ow];
         }
     }
+    }
     const size_t o = (size_t)plane * H * W4 + q;
     float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
     if (accumulate) { const float4 d = gin[o]; v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w; }
     gin[o] = v;
 }
 
+template <int KK, int SS>
 __global__ __launch_bounds__(NT) void avgpool_bwd_kernel_v4(const float* __restrict__ gout, float4* __restrict__ gin, int accumulate,
-                                                           int H, int W, int OH, int OW, int k, int stride)
+                                                           int H, int W, int OH, int OW, int k_rt, int stride_rt)
 {
+    const int k = KK ? KK : k_rt, stride = SS ? SS : stride_rt;
     const int plane = blockIdx.y;
     const int W4 = W >> 2;
     const int q = blockIdx.x * NT + threadIdx.x;
@@ -511,9 +560,11 @@ __global__ __launch_bounds__(NT) void avgpool_bwd_kernel_v4(const float* __restr
 }
 
 // OW % 4 == 0: a thread owns four consecutive outputs of one row
+template <int KK, int SS>
 __global__ __launch_bounds__(NT) void avgpool_fwd_kernel_v4(const float* __restrict__ in, float4* __restrict__ out, int H, int W, int OH,
-                                                           int OW, int k, int stride, int relu_in)
+                                                           int OW, int k_rt, int stride_rt, int relu_in)
 {
+    const int k = KK ? KK : k_rt, stride = SS ? SS : stride_rt;
     const int plane = blockIdx.y;
     const int OW4 = OW >> 2;
     const int q = blockIdx.x * NT + threadIdx.x;
@@ -772,6 +823,11 @@ void launch_add2(const float* a, const float* b, float* out, long n, int relu_a,
 }
 void launch_copy_acc(const float* src, float* dst, long n, int accumulate, hipStream_t s)
 {
+    if ((n & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        hipLaunchKernelGGL(copy_acc_kernel_v4, dim3((unsigned)((n / 4 + NT * ST_U - 1) / (NT * ST_U))), dim3(NT), 0, s, reinterpret_cast<const float4*>(src),
+                           reinterpret_cast<float4*>(dst), n / 4, accumulate);
+        return;
+    }
     hipLaunchKernelGGL(copy_acc_kernel, dim3(grid_for(n)), dim3(NT), 0, s, src, dst, n, accumulate);
 }
 void launch_fill(float* p, long n, float v, hipStream_t s)
@@ -788,8 +844,11 @@ void launch_maxpool_bwd(const float* gout, const uint8_t* idx, float* gin, int a
                         int OH, int OW, int k, int stride, int pad, hipStream_t s)
 {
     if ((W & 3) == 0 && (long)C * SB <= 65535) {
-        hipLaunchKernelGGL(maxpool_bwd_kernel_v4, dim3((H * (W / 4) + NT - 1) / NT, C * SB), dim3(NT), 0, s, gout, idx,
-                           reinterpret_cast<float4*>(gin), accumulate, SB, B, H, W, OH, OW, k, stride, pad);
+        const dim3 g((H * (W / 4) + NT - 1) / NT, C * SB);
+        float4* gin4 = reinterpret_cast<float4*>(gin);
+        if (k == 3 && stride == 2) hipLaunchKernelGGL((maxpool_bwd_kernel_v4<3, 2>), g, dim3(NT), 0, s, gout, idx, gin4, accumulate, SB, B, H, W, OH, OW, k, stride, pad);
+        else if (k == 2 && stride == 2) hipLaunchKernelGGL((maxpool_bwd_kernel_v4<2, 2>), g, dim3(NT), 0, s, gout, idx, gin4, accumulate, SB, B, H, W, OH, OW, k, stride, pad);
+        else hipLaunchKernelGGL((maxpool_bwd_kernel_v4<0, 0>), g, dim3(NT), 0, s, gout, idx, gin4, accumulate, SB, B, H, W, OH, OW, k, stride, pad);
         return;
     }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)C * SB * H * W)), dim3(NT), 0, s, gout, idx, gin, accumulate,
@@ -799,8 +858,10 @@ void launch_avgpool_fwd(const float* in, float* out, int CN, int H, int W, int O
                         hipStream_t s)
 {
     if ((OW & 3) == 0 && CN <= 65535) {
-        hipLaunchKernelGGL(avgpool_fwd_kernel_v4, dim3((OH * (OW / 4) + NT - 1) / NT, CN), dim3(NT), 0, s, in, reinterpret_cast<float4*>(out),
-                           H, W, OH, OW, k, stride, relu_in);
+        const dim3 g((OH * (OW / 4) + NT - 1) / NT, CN);
+        float4* out4 = reinterpret_cast<float4*>(out);
+        if (k == 2 && stride == 2) hipLaunchKernelGGL((avgpool_fwd_kernel_v4<2, 2>), g, dim3(NT), 0, s, in, out4, H, W, OH, OW, k, stride, relu_in);
+        else hipLaunchKernelGGL((avgpool_fwd_kernel_v4<0, 0>), g, dim3(NT), 0, s, in, out4, H, W, OH, OW, k, stride, relu_in);
         return;
     }
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)CN * OH * OW)), dim3(NT), 0, s, in, out, CN, H, W, OH, OW, k,
@@ -810,8 +871,10 @@ void launch_avgpool_bwd(const float* gout, float* gin, int accumulate, int CN, i
                         hipStream_t s)
 {
     if ((W & 3) == 0 && CN <= 65535) {
-        hipLaunchKernelGGL(avgpool_bwd_kernel_v4, dim3((H * (W / 4) + NT - 1) / NT, CN), dim3(NT), 0, s, gout, reinterpret_cast<float4*>(gin),
-                           accumulate, H, W, OH, OW, k, stride);
+        const dim3 g((H * (W / 4) + NT - 1) / NT, CN);
+        float4* gin4 = reinterpret_cast<float4*>(gin);
+        if (k == 2 && stride == 2) hipLaunchKernelGGL((avgpool_bwd_kernel_v4<2, 2>), g, dim3(NT), 0, s, gout, gin4, accumulate, H, W, OH, OW, k, stride);
+        else hipLaunchKernelGGL((avgpool_bwd_kernel_v4<0, 0>), g, dim3(NT), 0, s, gout, gin4, accumulate, H, W, OH, OW, k, stride);
         return;
     }
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)CN * H * W)), dim3(NT), 0, s, gout, gin, accumulate, CN, H, W,
