@@ -372,6 +372,39 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const float* __restrict
     }
 }
 
+// OW % 4 == 0: a thread owns four consecutive outputs of one row and writes one float4 and one packed word of argmax bytes
+template <int KK, int SS>
+__global__ __launch_bounds__(NT) void maxpool_fwd_kernel_v4(const float* __restrict__ in, float4* __restrict__ out, uint32_t* __restrict__ idx,
+                                                           int H, int W, int OH, int OW, int k_rt, int stride_rt, int pad)
+{
+    const int k = KK ? KK : k_rt, stride = SS ? SS : stride_rt;
+    const int plane = blockIdx.y;
+    const int OW4 = OW >> 2;
+    const int q = blockIdx.x * NT + threadIdx.x;
+    if (q >= OH * OW4) return;
+    const int oh = q / OW4, ow0 = (q - oh * OW4) * 4;
+    const float* __restrict__ src = in + (size_t)plane * H * W;
+    float best[4];
+    int bi[4];
+    bool first[4] = {true, true, true, true};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int dh = 0; dh < k; ++dh) {
+        const int ih = oh * stride - pad + dh;
+        if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (int dw = 0; dw < k; ++dw) {
+                const int iw = (ow0 + j) * stride - pad + dw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float v = src[ih * W + iw];
+                if (first[j] || v > best[j] || v != v) { best[j] = v; bi[j] = dh * k + dw; first[j] = false; }
+            }
+    }
+    out[(size_t)plane * OH * OW4 + q] = make_float4(best[0], best[1], best[2], best[3]);
+    if (idx) idx[(size_t)plane * OH * OW4 + q] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+}
+
 __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
                                                         float* __restrict__ gin, int accumulate, int C, int SB, int B,
                                                         int H, int W, int OH, int OW, int k, int stride, int pad)
@@ -837,6 +870,15 @@ void launch_fill(float* p, long n, float v, hipStream_t s)
 void launch_maxpool_fwd(const float* in, float* out, uint8_t* idx, int CN, int H, int W, int OH, int OW, int k, int stride,
                         int pad, hipStream_t s)
 {
+    if ((OW & 3) == 0 && CN <= 65535 && (((uintptr_t)idx) & 3) == 0) {
+        const dim3 g((OH * (OW / 4) + NT - 1) / NT, CN);
+        float4* out4 = reinterpret_cast<float4*>(out);
+        uint32_t* idx4 = reinterpret_cast<uint32_t*>(idx);
+        if (k == 3 && stride == 2) hipLaunchKernelGGL((maxpool_fwd_kernel_v4<3, 2>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW, k, stride, pad);
+        else if (k == 2 && stride == 2) hipLaunchKernelGGL((maxpool_fwd_kernel_v4<2, 2>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW, k, stride, pad);
+        else hipLaunchKernelGGL((maxpool_fwd_kernel_v4<0, 0>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW, k, stride, pad);
+        return;
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long)CN * OH * OW)), dim3(NT), 0, s, in, out, idx, CN, H, W, OH, OW,
                        k, stride, pad);
 }

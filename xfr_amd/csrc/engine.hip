@@ -180,6 +180,7 @@ struct xfr_engine {
     int store_slot = -1;                              // firing whose full P tensor is kept in store_dev
     float* store_dev = nullptr;
     int store_tensor = -1, store_sb = 0;
+    std::vector<char> is_hook_a;       // per tensor: some hook takes its a (and x) from this tensor's forward values
     std::vector<char> fwd_done;        // per forward pass: ops whose work was folded into an earlier GEMM epilogue
     std::vector<char> pos_done;        // ... and whose positive-pass output was produced there too
     int fwd_last_op = 0;
@@ -387,6 +388,9 @@ xfr_status build(xfr_engine* e, const xfr_op_desc* ops, int n_ops)
             e->tens[ht].hooks.push_back(h);
         }
     }
+    e->is_hook_a.assign(e->tens.size(), 0);
+    for (auto& x : e->tens)
+        for (const Hook& h : x.hooks) e->is_hook_a[h.a_tensor] = 1;
     // forward fusion: <BatchNorm | Add | functional add> followed by an in-place ReLU on its output
     for (int k = 0; k + 1 < n_ops; ++k) {
         const xfr_op_desc& d = e->ops[k].d;
@@ -694,24 +698,43 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
         q.p0 = e->arena + bn.bn_alpha_t;
         q.p1 = e->arena + bn.bn_beta_t;
     }
-    if (bn.fuse_relu) push(EW_RELU);
+    // The residual add behind the BatchNorm joins the chain where the pre-add tensor is nobody's business afterwards: no hook takes its
+    // (a, x) from it (the reference's Add hooks both use the LAST input, the residual: whitebox.py:379-381), and the positive pass
+    // does not need the sum's inputs (modes that divide by a ReLU input's X compute it from them: then the add keeps its kernel).
+    int final_t = bn_out, k2 = -1;
+    bool fused_add = false;
+    if (!bn.fuse_relu && e->tens[bn_out].consumers.size() == 1 && !e->is_hook_a[bn_out]) {
+        k2 = e->tens[bn_out].consumers[0];
+        const OpRec& ad = e->ops[k2];
+        if (k2 <= e->fwd_last_op && (ad.d.kind == XFR_OP_ADD || ad.d.kind == XFR_OP_G_ADD) && !e->tens[ad.d.out].need_pv) {
+            const int other = (ad.d.in0 == bn_out) ? ad.d.in1 : ad.d.in0;
+            if (other != bn_out && e->tens[other].producer < k) {
+                push(EW_ADDP).p0 = e->T(other);
+                if (ad.fuse_relu) push(EW_RELU);
+                final_t = ad.d.out;
+                fused_add = true;
+            }
+        }
+    }
+    if (!fused_add && bn.fuse_relu) push(EW_RELU);
     // a dual launch can only carry a chain through the compiled float4 epilogue (conv_gemm.hip): rows that are a multiple of 4
     // long and a signature that is in the table; otherwise the BatchNorm keeps its own kernel
     {
         const Tensor& t = e->tens[d.out];
         EwChain probe = ch;
         EwLoads ld;
-        ew_plan_loads(probe, e->T(bn_out), ld, EW_FWD_SLOTS_WIDE);
+        ew_plan_loads(probe, e->T(final_t), ld, EW_FWD_SLOTS_WIDE);
         if (!e->planning_only && ((((long)B * t.HW()) & 3) != 0 || conv_gemm_chain_sig(probe) < 0)) {
             ch.n = 0;
             e->pos_done[k1] = 0;
             return;
         }
     }
-    p.out0 = e->T(bn_out);
+    p.out0 = e->T(final_t);
     p.chain_B = B;
     p.chain_eps = e->eps;
     e->fwd_done[k1] = 1;
+    if (fused_add) e->fwd_done[k2] = 1;
 }
 
 // MaxFeatureMap in the convolution's epilogue (lightcnn.py:48-62: Conv -> Split -> torch.max of the halves).  The forward pack holds
