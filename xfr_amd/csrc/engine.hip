@@ -706,7 +706,8 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
     if (!bn.fuse_relu && e->tens[bn_out].consumers.size() == 1 && !e->is_hook_a[bn_out]) {
         k2 = e->tens[bn_out].consumers[0];
         const OpRec& ad = e->ops[k2];
-        if (k2 <= e->fwd_last_op && (ad.d.kind == XFR_OP_ADD || ad.d.kind == XFR_OP_G_ADD) && !e->tens[ad.d.out].need_pv) {
+        // (the positive pass of a functional add reads its inputs' POSITIVE values, never the true ones: only the Add module's does)
+        if (k2 <= e->fwd_last_op && (ad.d.kind == XFR_OP_G_ADD || (ad.d.kind == XFR_OP_ADD && !e->tens[ad.d.out].need_pv))) {
             const int other = (ad.d.in0 == bn_out) ? ad.d.in1 : ad.d.in0;
             if (other != bn_out && e->tens[other].producer < k) {
                 push(EW_ADDP).p0 = e->T(other);
