@@ -232,7 +232,6 @@ struct ConvParams {
     int chain_interpret; // 1: run the chain through the interpreted epilogue even if a compiled one exists (tests)
     int co_pair;         // Co > 0: MaxFeatureMap convolution whose 2*Co output channels are PACKED interleaved (GEMM row 2c = channel c, row
                          // 2c+1 = channel c + Co): rows are stored at their channel's place, a chain may end in EW_MAXPAIR
-    int prio_round;      // > 0: wave priority by dispatch round -- workgroup b runs at priority 3 - min(b / prio_round, 3) (0: all equal)
     unsigned long long* stamps;   // tuning hook (xfr_debug_conv_stamps): per wave 8 words -- s_memrealtime at kernel entry, first operands landed,
                                   // K loop done, epilogue entered, exit; HW_ID; XCC_ID; life in shader cycles.  nullptr: off
     int stamps_cap;               // workgroups the stamp buffer holds (later ones do not record)

@@ -689,14 +689,6 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : 6)) void con
     const int wrow = wave >> 1, wcol = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     stamp(p, wave, lane, 0);
-    if (p.prio_round > 0) {
-        // staggered finish: the first round of workgroups on every CU outranks the second, the second the third (and the tail parts,
-        // dispatched last, rank with the first round: their tile's last arriver waits for them)
-        const int rnd = (p.tail_s > 1 && (int)blockIdx.x >= p.tail_q) ? 0 : (int)blockIdx.x / p.prio_round;
-        if (rnd == 0) __builtin_amdgcn_s_setprio(3);
-        else if (rnd == 1) __builtin_amdgcn_s_setprio(2);
-        else if (rnd == 2) __builtin_amdgcn_s_setprio(1);
-    }
 
     // n_co_tiles counts the tiles of BOTH halves of a dual launch (half 1 = relu(W) -> positive activations)
     const int n_tiles_all = n_co_tiles * n_m_tiles;
@@ -1051,14 +1043,6 @@ __global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
     stamp(p, wave, lane, 0);
-    if (p.prio_round > 0) {
-        // staggered finish: the first round of workgroups on every CU outranks the second, the second the third (and the tail parts,
-        // dispatched last, rank with the first round: their tile's last arriver waits for them)
-        const int rnd = (p.tail_s > 1 && (int)blockIdx.x >= p.tail_q) ? 0 : (int)blockIdx.x / p.prio_round;
-        if (rnd == 0) __builtin_amdgcn_s_setprio(3);
-        else if (rnd == 1) __builtin_amdgcn_s_setprio(2);
-        else if (rnd == 2) __builtin_amdgcn_s_setprio(1);
-    }
 
     const int n_tiles_all = n_co_tiles * n_m_tiles;
     int part, nparts, lid, tail_t = -1;
@@ -1451,16 +1435,14 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.
     // K >= 512: the intra-workgroup split-K kernel (tools/conv_sweep.py, round 3: +6..13 % on the 3x3 layers and the K = 512 /
     // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
-    static const int ks = [] { const char* e = getenv("XFR_KS"); return e ? atoi(e) : 7; }();
-    static const int ks_mink = [] { const char* e = getenv("XFR_KS_MINK"); return e ? atoi(e) : 512; }();
-    static const int ks_rule = [] { const char* e = getenv("XFR_KS_RULE"); return e ? atoi(e) : 1; }();
-    if ((ks == 6 || ks == 7) && ks_ok<8>(p)) {
-        // rule 1: only where the in-engine serial table shows a gain (tools/cmp_layers.py): deep-K 3x3 (ResNet layers 3 / 4: -4..-12 %)
-        // and the 1x1 layers with K = 512 or K >= 2048 (-3..-14 %); K = 1024 loses 4 %.  The choice depends on the LAYER only, never on
-        // the batch: the two kernels sum K in different orders, and a sample's map must not depend on how many samples share its launch
-        // strided 1x1 convolutions (forward: gathered input; backward: scattered output) gain 60-70 % over the generic-gather kernel
-        if (p.kh == 1 && (p.stride == 2 || p.out_stride == 2)) return ks;
-        if (p.K >= ks_mink && (ks_rule == 0 || (p.kh > 1 && p.K >= 2048) || (p.kh == 1 && (p.K == 512 || p.K >= 2048)))) return ks;
+    if (ks_ok<8>(p)) {
+        // The choice depends on the LAYER only, never on the batch: the two kernels sum K in different orders, and a sample's map must
+        // not depend on how many samples share its launch.  In-engine serial table (tools/cmp_layers.py): deep-K 3x3 (ResNet layers
+        // 3 / 4) -4..-12 %, 1x1 with K = 512 or K >= 2048 -3..-14 %, K = 1024 +4 % (stays on K1); strided 1x1 convolutions (forward:
+        // gathered input, backward: scattered output) -35 % against the generic-gather kernel.  Split-K for every K >= 512 layer is
+        // 0.4 % slower in the timed three-stream schedule (32 KB rings crowd out the other streams' workgroups).
+        if (p.kh == 1 && (p.stride == 2 || p.out_stride == 2)) return 7;
+        if ((p.kh > 1 && p.K >= 2048) || (p.kh == 1 && (p.K == 512 || p.K >= 2048))) return 7;
     }
     // Deep-K launches of at most two tiles per CU (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers
     // per MFMA.  Their 48 KB ring allows three workgroups per CU, so larger grids (the W / relu(W) dual launch of the
@@ -1508,8 +1490,6 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     p.stamps = g_stamps;
     p.stamps_cap = g_stamps_cap;
     p.span = nullptr;
-    static const int prio = [] { const char* e = getenv("XFR_PRIO"); return e ? atoi(e) : 0; }();
-    p.prio_round = prio ? num_cus() * prio : 0;
     if (g_log && (int)g_log_recs.size() < g_log_cap) {
         p.span = g_log + 8 * g_log_recs.size();
         g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
