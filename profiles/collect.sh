@@ -42,9 +42,9 @@ smi > $P/smi_bench_sustained.txt & SMI=$!
 python bench.py --no-cpu-baseline --no-profile --sustained-seconds 15 > /dev/null 2>&1
 kill $SMI; wait $SMI 2>/dev/null
 smi > $P/smi_gemm_saturated.txt & SMI=$!
-python tools/conv_sweep.py --cfgs 3000007,3000004 --reps 6000 --only 0 > $P/gemm_saturated.txt 2>&1
+python tools/conv_sweep.py --cfgs 3000007,3000004 --reps 30000 --only 0 --clock > $P/gemm_saturated.txt 2>&1
 kill $SMI; wait $SMI 2>/dev/null
-python tools/conv_sweep.py --cfgs 7,3000007,4,3000004 --reps 300 --only 0,1 --stamps > $P/gemm_stamps.txt 2>&1
+python tools/conv_sweep.py --cfgs 7,4 --reps 300 --only 0,1 --stamps > $P/gemm_stamps.txt 2>&1
 python tools/clock_probe.py --steps 20 > $P/clock_probe_timed.json 2> /dev/null
 python tools/clock_probe.py --steps 10 --serial > $P/clock_probe_serial.json 2> /dev/null
 mkdir -p gpurun_out/$P && cp -r $P/. gpurun_out/$P/

@@ -101,6 +101,7 @@ def main():
     ap.add_argument('--set', default='r101', choices=['r101', 'lcnn', 'all'])
     ap.add_argument('--only', default=None, help='comma list of shape indices')
     ap.add_argument('--stamps', action='store_true', help='per-wave phase stamps of ONE launch per (shape, cfg): where the time goes')
+    ap.add_argument('--clock', action='store_true', help='stamps ON during the timed launches: the effective shader clock (s_memtime cycles / s_memrealtime) over the workgroup records left in the buffer')
     args = ap.parse_args()
     import torch
     from xfr_amd import _lib
@@ -126,9 +127,24 @@ def main():
         for c in cfgs:
             out = torch.zeros((cout, nbb, oh, ow), device=dev)
             ms = ctypes.c_float()
+            if args.clock:
+                nwg = 16384
+                stc = torch.zeros((nwg * 32,), dtype=torch.int64, device=dev)
+                _lib.check(lib.xfr_debug_conv_stamps(stc.data_ptr(), nwg))
             _lib.check(lib.xfr_debug_conv(x.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), cin, h, w, nbb, cout, k, k, stride,
                                           pad, 0, c, args.reps, ctypes.byref(ms)))
             torch.cuda.synchronize()
+            if args.clock:
+                import numpy as np
+                _lib.check(lib.xfr_debug_conv_stamps(None, 0))
+                v = stc.cpu().numpy().reshape(nwg, 4, 8)
+                life = (v[:, :, 4] - v[:, :, 0]).astype(np.float64).ravel()
+                cyc = v[:, :, 7].astype(np.float64).ravel()
+                ok = (life > 1000) & (cyc > 0)
+                ghz = cyc[ok] / (life[ok] * 10.0)
+                ghz = ghz[(ghz > 0.5) & (ghz < 4.0)]      # concurrent streams overwrite each other's records: mixed ones fall outside
+                print('    cfg %d: effective shader clock during the %d timed launches p10/50/90 %.3f/%.3f/%.3f GHz (%d records)' % (
+                    (c, args.reps) + tuple(np.percentile(ghz, [10, 50, 90])) + (len(ghz),)))
             if args.stamps:
                 print(stamp_report(lib, _lib, torch, dev, (x, wt, b, out, cin, h, w, nbb, cout, k, stride, pad), c, ms.value))
             if first is None:
