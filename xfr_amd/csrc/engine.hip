@@ -1156,6 +1156,8 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
                     const BwdStep& c = st[j];
                     if (c.dst_t == d) {
                         later_writer = true;
+                        // a chain flushed IN PLACE on d (hooks of d where its producer is glue) reads the copy's source instead
+                        if (!c.accumulate && c.kind == ST_EW && c.src_t == d) break;
                         if (!c.accumulate) { ok = false; break; }
                         if (!(c.kind == ST_EW || (c.kind == ST_CONV_BWD && !scatter_conv(c)))) ok = false;
                         break;   // after the first physical writer the tensor is real again
@@ -1206,8 +1208,12 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             BwdStep& c = st[j];
             // an IN-PLACE chain on b_t (hooks flushed where the producer is glue) merges too: the merged launch simply ends in b_t
             bool inplace = c.kind == ST_EW && c.dst_t == b_t && !c.accumulate;
-            for (const Sym& y : c.chain) if (y.type == EW_STORE && y.t0 == b_t) inplace = false;
-            if (c.kind != ST_EW || c.src_t != b_t || (writes(c, b_t) && !inplace)) continue;
+            // ... and so does a chain that stores its own intermediate value back into b_t on the way (a chain -> chain merge of an
+            // in-place flush with its reader): that store is then the one b_t's later readers see
+            bool restores = false;
+            for (const Sym& y : c.chain) if (y.type == EW_STORE && y.t0 == b_t) { inplace = false; restores = true; }
+            if (c.dst_t == b_t) restores = false;
+            if (c.kind != ST_EW || c.src_t != b_t || (writes(c, b_t) && !inplace && !restores)) continue;
             // fan-out: GEMM (-> Co channels) followed by the chain whose head is the MaxFeatureMap VJP (over 2 * Co channels)
             bool fan = false;
             if (pass == 2 && a_conv && !c.chain.empty() && c.chain[0].type == EW_MAXHALF_IN && e->tens[c.ew_t].C == 2 * e->tens[b_t].C &&
@@ -1241,7 +1247,7 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
                 // a accumulates into b_t (partial sums already there): fold as an addend, then continue
                 merged.push_back(mk(EW_ADDP, b_t));
             }
-            if ((other_readers || a.accumulate) && !inplace) merged.push_back(mk(EW_STORE, b_t));
+            if ((other_readers || a.accumulate) && !inplace && !restores) merged.push_back(mk(EW_STORE, b_t));
             if (fan) {
                 Sym f = c.chain[0];
                 f.type = EW_MAXHALF_OUT;
