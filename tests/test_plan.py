@@ -69,6 +69,34 @@ def test_plan_shapes_resnet101():
     assert sum(ln.startswith('bwd CONV_BWD') for ln in text.splitlines()) == 100       # 100 convs + fc, minus the first layer's backward-data GEMM
 
 
+def test_residual_blocks_leave_no_glue_launches():
+    """The Add VJP's gradient copy forwards into the in-place hook flush behind it, and a backward GEMM merges with a chain that
+    stores its intermediate value back (fuse_plan): a Light-CNN residual block is two GEMM launches, and the ResNet-101 sweep
+    keeps no copy in front of a hook flush."""
+    prog = PROGRAMS['lightcnn29v2']
+    lines = prog.describe('affineonly', prog.marks['encode']).splitlines()
+    bwd = [ln.split()[1] for ln in lines if ln.startswith('bwd ')]
+    # the twelve residual blocks' sweeps: GEMM, GEMM, GEMM, ... with nothing in between except around the four pooling stages
+    runs, cur = [], 0
+    for k in bwd:
+        if k == 'CONV_BWD':
+            cur += 1
+        else:
+            runs.append(cur)
+            cur = 0
+    runs.append(cur)
+    assert max(runs) >= 8, runs
+    assert 'COPY' not in bwd, bwd
+    assert any(' 2bfd' in ln for ln in lines)          # store-back + fan-out chains behind a GEMM exist and ...
+    assert all('compiled=-1' not in ln for ln in lines)    # ... every one of them has a compiled epilogue
+    prog = PROGRAMS['stresnet101']
+    lines = prog.describe('affineonly_with_prior', prog.marks['encode']).splitlines()
+    kinds = [ln.split()[1] for ln in lines if ln.startswith('bwd ')]
+    assert kinds.count('COPY') == 4, kinds               # the AvgPool2d(1,1) shortcuts of the four downsample blocks
+    m = re.match(r'plan seed_tensor (\d+) mode 1 firings (\d+) launches (\d+)', lines[0])
+    assert int(m.group(3)) <= 124
+
+
 def test_plan_describe_argument_checks():
     lib = _lib.load()
     prog = PROGRAMS['stresnet_mini']
