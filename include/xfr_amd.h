@@ -314,7 +314,9 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
 /* Tuning hook: while stamps_dev is non-NULL, every GEMM launch of this process records, per wave, 8 64-bit words at
  * stamps_dev[(block * 4 + wave) * 8]: s_memrealtime (100 MHz) at kernel entry / first operands landed / K loop done / epilogue entered / exit,
  * then HW_ID, XCC_ID, and the wave's life in shader-clock cycles (s_memtime; with the 100 MHz stamps: the effective clock) (tools/conv_sweep.py --stamps draws a launch's timeline from them).  The buffer holds
- * 32 words for each of capacity_workgroups workgroups; workgroups beyond that do not record.  NULL switches it off (the default). */
+ * 32 words for each of capacity_workgroups workgroups; workgroups beyond that do not record.  NULL switches it off (the default).
+ * capacity_workgroups < 0: sampled mode for whole steps (tools/phase_probe.py) -- the buffer holds -capacity_workgroups records in regions
+ * of 256; the n-th launch writes up to 256 evenly spaced workgroups into region n % regions, word 6 also carries K, M and Cout of the launch. */
 xfr_status xfr_debug_conv_stamps(void* stamps_dev, int32_t capacity_workgroups);
 
 /* Tuning hook: a timeline of the GEMM launches as the device ran them, streams overlapped.  While log_dev is non-NULL (zero-filled

@@ -235,6 +235,7 @@ struct ConvParams {
     unsigned long long* stamps;   // tuning hook (xfr_debug_conv_stamps): per wave 8 words -- s_memrealtime at kernel entry, first operands landed,
                                   // K loop done, epilogue entered, exit; HW_ID; XCC_ID; life in shader cycles.  nullptr: off
     int stamps_cap;               // workgroups the stamp buffer holds (later ones do not record)
+    int stamp_regions, stamp_seq; // sampled mode (regions > 0): launch `seq` records up to 256 evenly spaced workgroups into region seq % regions
     unsigned long long* span;     // tuning hook (xfr_debug_conv_log): eight words of THIS launch -- block 0's entry time, then exit times of a sample of the workgroups
                                   // (s_memrealtime), i.e. when the launch really started and ended next to the other streams' launches
 };

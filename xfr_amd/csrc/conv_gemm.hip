@@ -73,14 +73,25 @@ constexpr unsigned OOB = 0x80000000u;
 enum { MODE_VEC = 0, MODE_TAP = 1, MODE_GEN = 2, MODE_TAP4 = 3 };
 
 // tuning hook: phase stamps of a wave (ConvParams::stamps)
-__device__ __forceinline__ void stamp(const ConvParams& p, int wave, int lane, int slot)
+__device__ __forceinline__ void stamp(const ConvParams& p, int wave, int lane, int slot, int kind = 0)
 {
-    if (p.stamps && lane == 0 && (int)blockIdx.x < p.stamps_cap) {
-        unsigned long long* q = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+    bool rec = p.stamps && lane == 0;
+    int idx = blockIdx.x;
+    if (rec) {
+        if (p.stamp_regions > 0) {
+            const int stride = (gridDim.x + 255) >> 8;
+            rec = (blockIdx.x % stride) == 0;
+            idx = (p.stamp_seq % p.stamp_regions) * 256 + blockIdx.x / stride;
+        } else rec = (int)blockIdx.x < p.stamps_cap;
+    }
+    if (rec) {
+        unsigned long long* q = p.stamps + ((size_t)idx * 4 + wave) * 8;
         q[slot] = __builtin_amdgcn_s_memrealtime();      // the 100 MHz reference clock: one time base for all XCDs
         if (slot == 0) {
             q[5] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);       // HW_REG_HW_ID
-            q[6] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);       // HW_REG_XCC_ID
+            q[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20)       // HW_REG_XCC_ID
+                   | (unsigned long long)(p.K & 0xffff) << 8 | (unsigned long long)(p.M & 0x3fffff) << 24 | (unsigned long long)(p.CoutTot & 0x1fff) << 46
+                   | (unsigned long long)kind << 60;   // which launch shape (and which of the two kernels) wrote the record
             q[7] = __builtin_amdgcn_s_memtime();                        // shader-clock counter (per XCD): entry ...
         }
         if (slot == 4) q[7] = __builtin_amdgcn_s_memtime() - q[7];      // ... to exit: shader cycles of this wave's life
@@ -1042,7 +1053,7 @@ __global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p,
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
-    stamp(p, wave, lane, 0);
+    stamp(p, wave, lane, 0, 1);
 
     const int n_tiles_all = n_co_tiles * n_m_tiles;
     int part, nparts, lid, tail_t = -1;
@@ -1454,7 +1465,15 @@ int conv_gemm_pick_cfg(const ConvParams& p)
 
 static unsigned long long* g_stamps = nullptr;
 static int g_stamps_cap = 0;
-void conv_gemm_set_stamps(unsigned long long* dev_ptr, int capacity_workgroups) { g_stamps = dev_ptr; g_stamps_cap = dev_ptr ? capacity_workgroups : 0; }
+static int g_stamp_regions = 0, g_stamp_seq = 0;
+// capacity < 0: sampled mode -- |capacity| / 256 regions of 256 records, launch n writes up to 256 evenly spaced workgroups into region n % regions
+void conv_gemm_set_stamps(unsigned long long* dev_ptr, int capacity_workgroups)
+{
+    g_stamps = dev_ptr;
+    g_stamps_cap = dev_ptr ? (capacity_workgroups < 0 ? -capacity_workgroups : capacity_workgroups) : 0;
+    g_stamp_regions = (dev_ptr && capacity_workgroups < 0) ? (-capacity_workgroups) / 256 : 0;
+    g_stamp_seq = 0;
+}
 
 namespace {
 struct LogRec { void* stream; int cout, nhalves, K, M, kh, chain, cfg; };
@@ -1489,6 +1508,8 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     ConvParams p = p_in;
     p.stamps = g_stamps;
     p.stamps_cap = g_stamps_cap;
+    p.stamp_regions = g_stamp_regions;
+    p.stamp_seq = g_stamps ? g_stamp_seq++ : 0;
     p.span = nullptr;
     if (g_log && (int)g_log_recs.size() < g_log_cap) {
         p.span = g_log + 8 * g_log_recs.size();

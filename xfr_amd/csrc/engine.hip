@@ -2345,7 +2345,8 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
 
 xfr_status xfr_debug_conv_stamps(void* stamps_dev, int32_t capacity_workgroups)
 {
-    if (stamps_dev && capacity_workgroups < 1) return fail(XFR_INVALID_ARG, "xfr_debug_conv_stamps: capacity must be positive");
+    if (stamps_dev && (capacity_workgroups == 0 || (capacity_workgroups < 0 && -capacity_workgroups < 256)))
+        return fail(XFR_INVALID_ARG, "xfr_debug_conv_stamps: capacity must be positive (or <= -256: sampled mode)");
     conv_gemm_set_stamps(reinterpret_cast<unsigned long long*>(stamps_dev), capacity_workgroups);
     return XFR_OK;
 }
