@@ -47,5 +47,14 @@ kill $SMI; wait $SMI 2>/dev/null
 python tools/conv_sweep.py --cfgs 7,4 --reps 300 --only 0,1 --stamps > $P/gemm_stamps.txt 2>&1
 python tools/clock_probe.py --steps 20 > $P/clock_probe_timed.json 2> /dev/null
 python tools/clock_probe.py --steps 10 --serial > $P/clock_probe_serial.json 2> /dev/null
+# where a workgroup's life goes while the step runs (sampled stamps per launch), do different layers' launches help each other,
+# the step against the batch size, the RISE-scale forward sweep, the isolated kernels on every layer shape
+python tools/phase_probe.py 2> /dev/null | grep -v amdgpu > $P/phase_probe_timed.txt
+python tools/phase_probe.py --serial 2> /dev/null | grep -v amdgpu > $P/phase_probe_serial.txt
+python tools/pair_probe.py 2> /dev/null | grep -v amdgpu > $P/pair_probe.txt
+for b in 32 64 96; do python bench.py --batch $b --steps 20 --warmup 4 --no-cpu-baseline --no-sustained 2> /dev/null; done > $P/bench_batch_sweep.jsonl
+python tools/embeddings_sweep.py --masks 6500 > $P/embeddings_sweep.json 2> /dev/null
+python tools/conv_sweep.py --cfgs 4,5,7 --reps 100 --set r101 2> /dev/null | grep -v amdgpu > $P/conv_sweep.txt
+python tools/conv_sweep.py --cfgs 4,7 --reps 100 --set lcnn --nb 128 2> /dev/null | grep -v amdgpu >> $P/conv_sweep.txt
 mkdir -p gpurun_out/$P && cp -r $P/. gpurun_out/$P/
 echo "collected: $(ls $P | tr '\n' ' ')"
