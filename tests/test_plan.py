@@ -113,6 +113,19 @@ def test_plan_describe_argument_checks():
     assert len(buf.value) == 31
 
 
+def test_tuning_hook_argument_checks():
+    """xfr_debug_conv_stamps: a buffer needs a capacity -- positive (one record per workgroup index) or <= -256 (sampled mode, regions
+    of 256 records per launch); NULL switches the hook off whatever the capacity says.  No device is touched."""
+    lib = _lib.load()
+    fake = ctypes.c_void_p(0x1000)
+    assert lib.xfr_debug_conv_stamps(fake, 0) == _lib.XFR_INVALID_ARG
+    assert lib.xfr_debug_conv_stamps(fake, -255) == _lib.XFR_INVALID_ARG
+    assert b'xfr_debug_conv_stamps' in lib.xfr_last_error()
+    assert lib.xfr_debug_conv_stamps(fake, -512) == _lib.XFR_OK
+    assert lib.xfr_debug_conv_stamps(fake, 16) == _lib.XFR_OK
+    assert lib.xfr_debug_conv_stamps(None, 0) == _lib.XFR_OK          # off again: nothing was launched in between
+
+
 def test_inplace_relu_with_second_reader_is_rejected():
     """An in-place ReLU may not share its input with another consumer, whichever comes first in call order."""
     from xfr_amd.program import Program
