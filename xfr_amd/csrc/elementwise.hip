@@ -405,6 +405,52 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel_v4(const float* __restr
     if (idx) idx[(size_t)plane * OH * OW4 + q] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
 }
 
+// The pools of the backbones (3x3 stride 2 pad 1; 3x3 stride 2 pad 0 with ceil_mode; 2x2 stride 2 pad 0) on planes with W = 2 OW,
+// W % 8 == 0: the eight input columns under a thread's four windows are two aligned float4 loads per row (plus the column left or
+// right of them for the 3x3 pools) instead of one dword load per window element; candidates are compared in the same (dh, dw)
+// order: first maximum wins, NaN sticks.
+template <int KK, int PAD>
+__global__ __launch_bounds__(NT) void maxpool_fwd_kernel_rows(const float* __restrict__ in, float4* __restrict__ out, uint32_t* __restrict__ idx,
+                                                             int H, int W, int OH, int OW)
+{
+    const int plane = blockIdx.y;
+    const int OW4 = OW >> 2;
+    const int q = blockIdx.x * NT + threadIdx.x;
+    if (q >= OH * OW4) return;
+    const int oh = q / OW4, ow0 = (q - oh * OW4) * 4;
+    const float* __restrict__ src = in + (size_t)plane * H * W;
+    float best[4];
+    int bi[4];
+    bool first[4] = {true, true, true, true};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    const bool left_ok = PAD == 1 && ow0 > 0;                          // column 2 ow0 - 1
+    const bool right_ok = KK == 3 && PAD == 0 && 2 * ow0 + 8 < W;      // column 2 ow0 + 8
+#pragma unroll
+    for (int dh = 0; dh < KK; ++dh) {
+        const int ih = oh * 2 - PAD + dh;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        const float* row = src + (size_t)ih * W + 2 * ow0;
+        const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+        float c[10];      // c[1 + i] = column 2 ow0 + i, i = -1 .. 8
+        c[1] = a.x; c[2] = a.y; c[3] = a.z; c[4] = a.w; c[5] = b.x; c[6] = b.y; c[7] = b.z; c[8] = b.w;
+        c[0] = left_ok ? row[-1] : 0.f;
+        c[9] = right_ok ? row[8] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int dw = 0; dw < KK; ++dw) {
+                const int ci = 1 + 2 * j - PAD + dw;
+                if (ci == 0 && !left_ok) continue;
+                if (ci == 9 && !right_ok) continue;
+                const float v = c[ci];
+                if (first[j] || v > best[j] || v != v) { best[j] = v; bi[j] = dh * KK + dw; first[j] = false; }
+            }
+    }
+    out[(size_t)plane * OH * OW4 + q] = make_float4(best[0], best[1], best[2], best[3]);
+    if (idx) idx[(size_t)plane * OH * OW4 + q] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+}
+
 __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
                                                         float* __restrict__ gin, int accumulate, int C, int SB, int B,
                                                         int H, int W, int OH, int OW, int k, int stride, int pad)
@@ -874,7 +920,11 @@ void launch_maxpool_fwd(const float* in, float* out, uint8_t* idx, int CN, int H
         const dim3 g((OH * (OW / 4) + NT - 1) / NT, CN);
         float4* out4 = reinterpret_cast<float4*>(out);
         uint32_t* idx4 = reinterpret_cast<uint32_t*>(idx);
-        if (k == 3 && stride == 2) hipLaunchKernelGGL((maxpool_fwd_kernel_v4<3, 2>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW, k, stride, pad);
+        const bool rows = stride == 2 && W == 2 * OW && (W & 7) == 0 && (((uintptr_t)in) & 15) == 0 && ((k == 3 && pad <= 1) || (k == 2 && pad == 0));
+        if (rows && k == 3 && pad == 1) hipLaunchKernelGGL((maxpool_fwd_kernel_rows<3, 1>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW);
+        else if (rows && k == 3) hipLaunchKernelGGL((maxpool_fwd_kernel_rows<3, 0>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW);
+        else if (rows) hipLaunchKernelGGL((maxpool_fwd_kernel_rows<2, 0>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW);
+        else if (k == 3 && stride == 2) hipLaunchKernelGGL((maxpool_fwd_kernel_v4<3, 2>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW, k, stride, pad);
         else if (k == 2 && stride == 2) hipLaunchKernelGGL((maxpool_fwd_kernel_v4<2, 2>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW, k, stride, pad);
         else hipLaunchKernelGGL((maxpool_fwd_kernel_v4<0, 0>), g, dim3(NT), 0, s, in, out4, idx4, H, W, OH, OW, k, stride, pad);
         return;
