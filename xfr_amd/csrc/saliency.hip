@@ -87,6 +87,10 @@ struct TruncState {       // one per sample
     unsigned cnt[256];
 };
 
+// One pass of the radix select: the histogram (value sums in fp64, counts) of the digit `pass` over the values whose higher digits match the
+// prefix.  A block walks whole channel rows of its map with float4 loads; a thread keeps the running (digit, sum, count) of the run of equal
+// digits it is in and only touches the LDS histogram when the digit changes -- neighbouring pixels share their leading digit almost always,
+// and in the first pass all 256 threads of a block would otherwise queue on a handful of bins.
 __global__ __launch_bounds__(NT) void trunc_hist_kernel(const float* __restrict__ P, const double* __restrict__ sums,
                                                        TruncState* __restrict__ st, int C, int N, int HW, int pass)
 {
@@ -99,19 +103,36 @@ __global__ __launch_bounds__(NT) void trunc_hist_kernel(const float* __restrict_
     const float s = (float)sums[n];
     const unsigned prefix = st[n].prefix;
     const int shift = 24 - 8 * pass;
-    const long total = (long)C * HW;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i / HW);
-        const int hw = (int)(i - (long)c * HW);
-        const float m = __fdiv_rn(P[((long)c * 2 * N + n) * HW + hw], s);
+    int cur = -1;
+    double acc = 0.0;
+    unsigned cnt = 0u;
+    auto take = [&](float p) {
+        const float m = __fdiv_rn(p, s);
         const unsigned bits = __float_as_uint(m);
         const bool match = (pass == 0) || ((bits >> (shift + 8)) == (prefix >> (shift + 8)));
-        if (match) {
-            const unsigned d = (bits >> shift) & 255u;
-            atomicAdd(&h[d], (double)m);
-            atomicAdd(&cn[d], 1u);
+        if (!match) return;
+        const int d = (int)((bits >> shift) & 255u);
+        if (d != cur) {
+            if (cnt) { atomicAdd(&h[cur], acc); atomicAdd(&cn[cur], cnt); }
+            cur = d; acc = 0.0; cnt = 0u;
+        }
+        acc += (double)m;
+        cnt += 1u;
+    };
+    const bool vec = (HW & 3) == 0 && (((uintptr_t)P) & 15) == 0;
+    for (int c = blockIdx.x; c < C; c += gridDim.x) {
+        const float* __restrict__ row = P + ((long)c * 2 * N + n) * HW;
+        if (vec) {
+            const float4* __restrict__ row4 = reinterpret_cast<const float4*>(row);
+            for (int i = threadIdx.x; i < (HW >> 2); i += NT) {
+                const float4 v = row4[i];
+                take(v.x); take(v.y); take(v.z); take(v.w);
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += NT) take(row[i]);
         }
     }
+    if (cnt) { atomicAdd(&h[cur], acc); atomicAdd(&cn[cur], cnt); }
     __syncthreads();
     if (cn[threadIdx.x]) {
         atomicAdd(&st[n].hist[threadIdx.x], h[threadIdx.x]);
@@ -242,9 +263,7 @@ void launch_truncation_threshold(const float* P, const double* sums, float perce
 {
     TruncState* st = reinterpret_cast<TruncState*>(scratch);
     hipLaunchKernelGGL(trunc_init_kernel, dim3(N), dim3(NT), 0, s, st);
-    long chunks = ((long)C * HW + NT * 16 - 1) / (NT * 16);
-    if (chunks > 256) chunks = 256;
-    if (chunks < 1) chunks = 1;
+    const long chunks = std::max(1, std::min(C, 64));      // blocks per map: whole channel rows each
     for (int pass = 0; pass < 4; ++pass) {
         hipLaunchKernelGGL(trunc_hist_kernel, dim3((int)chunks, N), dim3(NT), 0, s, P, sums, st, C, N, HW, pass);
         hipLaunchKernelGGL(trunc_select_kernel, dim3(N), dim3(64), 0, s, st, percentile, thr, pass);
