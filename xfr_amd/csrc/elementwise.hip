@@ -534,6 +534,42 @@ __global__ __launch_bounds__(NT) void avgpool_bwd_kernel(const float* __restrict
     }
 }
 
+// Global average pool (one window = the whole H x W plane, ResNet's 7x7 pool): a block stages GP consecutive planes through LDS with
+// coalesced loads, then one thread per plane adds its HW values in the same row-major order as avgpool_fwd_kernel (bit-identical); the
+// VJP hands every pixel (0 + g) / (H W) like the generic kernel, without its window arithmetic.
+constexpr int GP = 128;
+__global__ __launch_bounds__(NT) void avgpool_global_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int CN, int HW, int relu_in)
+{
+    extern __shared__ float tile[];
+    const long p0 = (long)blockIdx.x * GP;
+    const int np = (int)((CN - p0) < GP ? (CN - p0) : GP);
+    const float* __restrict__ src = in + p0 * HW;
+    for (int i = threadIdx.x; i < np * HW; i += NT) {
+        const float v = src[i];
+        tile[i] = relu_in ? fmaxf(v, 0.f) : v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < np) {
+        const float inv = 1.0f / (float)HW;
+        const float* t = tile + threadIdx.x * HW;
+        float acc = 0.f;
+        for (int i = 0; i < HW; ++i) acc += t[i];
+        out[p0 + threadIdx.x] = (HW == 1) ? acc : acc * inv;
+    }
+}
+
+__global__ __launch_bounds__(NT) void avgpool_global_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, int accumulate, long total, int HW)
+{
+    const float inv = 1.0f / (float)HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        float acc = 0.f;
+        acc += gout[i / HW];
+        acc = (HW == 1) ? acc : acc * inv;
+        if (accumulate) acc += gin[i];
+        gin[i] = acc;
+    }
+}
+
 // float4 variants of the pool VJPs and the average pool: blockIdx.y = plane (channel x gradient row), a thread owns four consecutive
 // pixels of one row, 32-bit index arithmetic only (the scalar kernels above pay a 64-bit division per element: the 3x3/2 max-pool
 // VJP of a 32-triplet step -- 205 MB written -- ran at 0.9 TB/s).  W % 4 == 0.
@@ -949,6 +985,10 @@ void launch_maxpool_bwd(const float* gout, const uint8_t* idx, float* gin, int a
 void launch_avgpool_fwd(const float* in, float* out, int CN, int H, int W, int OH, int OW, int k, int stride, int relu_in,
                         hipStream_t s)
 {
+    if (OH == 1 && OW == 1 && k == H && k == W && (size_t)GP * H * W * sizeof(float) <= 64 * 1024) {
+        hipLaunchKernelGGL(avgpool_global_fwd_kernel, dim3((CN + GP - 1) / GP), dim3(NT), (size_t)GP * H * W * sizeof(float), s, in, out, CN, H * W, relu_in);
+        return;
+    }
     if ((OW & 3) == 0 && CN <= 65535) {
         const dim3 g((OH * (OW / 4) + NT - 1) / NT, CN);
         float4* out4 = reinterpret_cast<float4*>(out);
@@ -962,6 +1002,11 @@ void launch_avgpool_fwd(const float* in, float* out, int CN, int H, int W, int O
 void launch_avgpool_bwd(const float* gout, float* gin, int accumulate, int CN, int H, int W, int OH, int OW, int k, int stride,
                         hipStream_t s)
 {
+    if (OH == 1 && OW == 1 && k == H && k == W) {
+        const long total = (long)CN * H * W;
+        hipLaunchKernelGGL(avgpool_global_bwd_kernel, dim3(grid_for(total)), dim3(NT), 0, s, gout, gin, accumulate, total, H * W);
+        return;
+    }
     if ((W & 3) == 0 && CN <= 65535) {
         const dim3 g((H * (W / 4) + NT - 1) / NT, CN);
         float4* gin4 = reinterpret_cast<float4*>(gin);
