@@ -12,6 +12,10 @@ configs[2] / configs[3] under the same contract and emit the same objects.
 Multi-GPU: one process per GPU (torch.distributed.run), triplets sharded embarrassingly, weights packed on rank 0
 and broadcast once over RCCL; no steady-state collective => "scaling": "weak" (B triplets per GPU).
 
+At N = 1 the default run also times BASELINE.json configs[2] (ResNet-50-128d truncated contrastive, B=64, 'norelu') and configs[3]
+(Light-CNN-29v2 EBP, B=128, 'affineonly') for a few steps each and appends them as `"secondary": [...]` (--no-secondary skips them;
+absent at N > 1 and when --model selects one of them as the main workload).
+
 Prints ONE JSON line on rank 0.  The `roofline` object describes the TIMED schedule: `achieved` is the algorithmic FLOPs over
 the union of the GEMM launches' busy intervals, taken from timestamps the kernels themselves record while the step runs on its
 three streams exactly as it was timed (xfr_amd/tuning.py); the one-stream figure rocprofv3 can reproduce is `frac_serial`.
@@ -85,6 +89,63 @@ def time_port(unit, what, n_units, budget_s):
             'sample': '%d %s, batch 1, %.1f s, %d threads (best of 8/16/32; host has %d)' % (n, what, dt, best_t, ncpu)}
 
 
+def cpu_worker_main(model, seconds, threads, batch, mode):
+    """`python bench.py --cpu-worker ...`: one worker of the whole-host CPU baseline.  Builds the port for `model`, runs units until
+    `seconds` have passed after a start line read from stdin (so that all workers measure the same window), prints the count."""
+    import torch
+    torch.set_num_threads(threads)
+
+    class A(object):
+        pass
+    a = A()
+    a.model, a.batch, a.mode = model, batch, mode
+    W = make_workload(a, torch.device('cpu'), 0, cpu_only=True)
+    unit, n_units = W.cpu_unit()
+    unit(0)                                   # warm: thread pool, allocator, oneDNN primitives
+    sys.stdout.write('ready\n'); sys.stdout.flush()
+    sys.stdin.readline()
+    n, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        unit(n % n_units)
+        n += 1
+    print(json.dumps({'units': n, 'seconds': time.time() - t0}))
+
+
+def whole_host(model, batch, mode, threads, budget_s):
+    """north_star: "next to the reference's CPU-only path timed on the same box's host cores".  One worker cannot use the host (the
+    batch-1 convolutions stop scaling at ~16 threads), so P = cpu_count // threads worker PROCESSES of `threads` threads each run the
+    port side by side for `budget_s` seconds; value = all units finished / the common window."""
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    P = max(1, ncpu // max(threads, 1))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', '--model', model, '--cpu-worker-seconds', str(budget_s),
+           '--cpu-worker-threads', str(threads)] + (['--batch', str(batch)] if batch else []) + (['--mode', mode] if mode else [])
+    procs = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(P)]
+    try:
+        for q in procs:                        # every worker has built its model and run one unit
+            if q.stdout.readline().strip() != 'ready':
+                raise RuntimeError('a CPU worker died during start-up')
+        t0 = time.time()
+        for q in procs:
+            q.stdin.write('go\n'); q.stdin.flush()
+        outs = [json.loads(q.stdout.readline()) for q in procs]
+        dt = time.time() - t0
+    except Exception as ex:
+        for q in procs:
+            q.kill()
+        return {'error': repr(ex)}
+    finally:
+        for q in procs:
+            try:
+                q.wait(timeout=30)
+            except Exception:
+                q.kill()
+    units = sum(o['units'] for o in outs)
+    return {'value': units / dt, 'unit': 'maps/s', 'cores': P * threads, 'processes': P, 'threads_per_process': threads, 'kind': 'port',
+            'sample': '%d units by %d processes x %d threads in %.1f s (host has %d hardware threads)' % (units, P, threads, dt, ncpu)}
+
+
 def pmc_traffic(root, tag):
     """HBM bytes per GEMM launch from the committed PMC passes of this same command (profiles/rNN/pmc_FETCH_SIZE<tag>.txt,
     pmc_WRITE_SIZE<tag>.txt: separate rocprofv3 --pmc runs, KB summed over the dispatches).  FETCH_SIZE is doubled: on gfx950 it
@@ -127,91 +188,97 @@ class Workload(object):
     pass
 
 
-def make_workload(args, dev, rank):
+def make_workload(args, dev, rank, cpu_only=False):
+    """cpu_only: no engine, no device -- just the inputs and the CPU port's unit of work (the whole-host baseline's workers)."""
     import torch
     from xfr_amd import shard, synth
-    from xfr_amd.engine import Engine
     W = Workload()
     W.model = args.model
     sd_holder = {}
+    if not cpu_only:
+        from xfr_amd.engine import Engine
     if args.model == 'resnet101':
         from xfr_amd.models import resnet
         W.mode = args.mode or 'affineonly_with_prior'
         B = W.B = args.batch or 32
         bb = resnet.ResNet([3, 4, 23, 3], num_classes=2)   # fc2 is replaced by the per-triplet classifier anyway
-        prog = bb.build_program()
-        eng = Engine(prog, 2 * B, dev)                     # the two encode batches of a step run as one 2B-image forward
         make_sd = lambda: sd_holder.setdefault('sd', synth.synth_state_dict(bb, seed=0, recipe='mild'))   # noqa: E731
         imgs = synth.bench_images(B, (3, 224, 224), seed=1234 + rank, mean=resnet.MEAN_RGB)
-        mates, nonmates, probes = imgs[0:B].to(dev), imgs[B:2 * B].to(dev), imgs[2 * B:3 * B].to(dev)
-        gallery = torch.cat((mates, nonmates), dim=0)      # [2B,3,224,224] resident in HBM
-        enc_t = prog.marks['encode']
-        W.pipeline = 1
-        W.step = lambda ready=True: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, None, inputs_ready=ready)   # noqa: E731
+        if not cpu_only:
+            prog = bb.build_program()
+            eng = Engine(prog, 2 * B, dev)                 # the two encode batches of a step run as one 2B-image forward
+            mates, nonmates, probes = imgs[0:B].to(dev), imgs[B:2 * B].to(dev), imgs[2 * B:3 * B].to(dev)
+            gallery = torch.cat((mates, nonmates), dim=0)  # [2B,3,224,224] resident in HBM
+            enc_t = prog.marks['encode']
+            W.pipeline = 1
+            W.step = lambda ready=True: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, None, inputs_ready=ready)   # noqa: E731
         W.flop_per_unit = 6 * F_FWD['resnet101']           # 2 encodes + true fwd + relu(W) fwd + 2 backward-data sweeps = 86.51 GFLOP
         W.metric = 'triplet-contrastive-EBP saliency maps/sec, ResNet-101 224x224'
         W.work = ('ResNet-101 triplet contrastive EBP, batch=%d synthetic 224x224 triplets per GPU (2 encodes + contrastive_ebp per '
                   'triplet), mode %s, eps 1e-16' % (B, W.mode))
         W.fixture = 'bench/r101' if (B == 32 and W.mode == 'affineonly_with_prior') else None
         W.pmc_tag = '' if (B == 32 and W.mode == 'affineonly_with_prior') else None
+        W.cpu_what = 'ResNet-101 triplet(s) (2 encodes + contrastive_ebp each)'
 
-        def cpu(budget):
+        def cpu_unit():
             from oracle import ebp_oracle as O
-            ow = O.OracleWhitebox('stresnet101', sd_holder['sd'], ('hooked', None), W.mode)
-            pm, pn, pp = mates.cpu(), nonmates.cpu(), probes.cpu()
+            ow = O.OracleWhitebox('stresnet101', make_sd(), ('hooked', None), W.mode)
+            pm, pn, pp = imgs[0:B], imgs[B:2 * B], imgs[2 * B:3 * B]
 
             def unit(i):
                 ow.set_triplet_classifier(ow.encode(pm[i:i + 1]) / 2500.0, ow.encode(pn[i:i + 1]) / 2500.0)
                 ow.contrastive_ebp(pp[i:i + 1], 0, 1)
-            out = time_port(unit, 'ResNet-101 triplet(s) (2 encodes + contrastive_ebp each)', B, budget)
-            out.update(port_vs_reference(ROOT))
-            return out
+            return unit, B
     elif args.model == 'resnet50_128':
         from xfr_amd.models import resnet50_128
         W.mode = args.mode or 'norelu'
         B = W.B = args.batch or 64
         bb = resnet50_128.Resnet50_128()
-        prog = bb.build_program()
-        eng = Engine(prog, 2 * B, dev)
         make_sd = lambda: sd_holder.setdefault('sd', synth.synth_state_dict(bb, seed=0))   # noqa: E731
         imgs = synth.bench_images(B, (3, 224, 224), seed=1234 + rank, mean=(131.0912, 103.8827, 91.4953))
-        gallery, probes = imgs[:2 * B].to(dev).contiguous(), imgs[2 * B:].to(dev).contiguous()
-        enc_t = prog.marks['encode']
-        W.pipeline = 1
-        W.step = lambda ready=True: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, 20.0, inputs_ready=ready)   # noqa: E731
+        if not cpu_only:
+            prog = bb.build_program()
+            eng = Engine(prog, 2 * B, dev)
+            gallery, probes = imgs[:2 * B].to(dev).contiguous(), imgs[2 * B:].to(dev).contiguous()
+            enc_t = prog.marks['encode']
+            W.pipeline = 1
+            W.step = lambda ready=True: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, 20.0, inputs_ready=ready)   # noqa: E731
         W.flop_per_unit = 6 * F_FWD['resnet50_128']
         W.metric = 'triplet truncated-contrastive-EBP (20 %) saliency maps/sec, VGGFace2 ResNet-50-128d 224x224'
         W.work = 'ResNet-50-128d truncated contrastive EBP, batch=%d synthetic triplets per GPU, mode %s' % (B, W.mode)
         W.fixture = 'bench/r50' if (B == 64 and W.mode == 'norelu') else None
         W.pmc_tag = '_r50' if (B == 64 and W.mode == 'norelu') else None
+        W.cpu_what = 'ResNet-50-128d triplet(s) (2 encodes + truncated_contrastive_ebp each)'
 
-        def cpu(budget):
+        def cpu_unit():
             from oracle import ebp_oracle as O
-            ow = O.OracleWhitebox('resnet50_128', sd_holder['sd'], ('hooked', None), W.mode)
-            g, pp = gallery.cpu(), probes.cpu()
+            ow = O.OracleWhitebox('resnet50_128', make_sd(), ('hooked', None), W.mode)
+            g, pp = imgs[:2 * B], imgs[2 * B:]
 
             def unit(i):
                 ow.set_triplet_classifier(ow.encode(g[i:i + 1]) / 2500.0, ow.encode(g[B + i:B + i + 1]) / 2500.0)
                 ow.truncated_contrastive_ebp(pp[i:i + 1], 0, 1, percentile=20)
-            return time_port(unit, 'ResNet-50-128d triplet(s) (2 encodes + truncated_contrastive_ebp each)', B, budget)
+            return unit, B
     else:
         from xfr_amd.models import lightcnn
         W.mode = args.mode or 'affineonly'
         B = W.B = args.batch or 128
         bb = lightcnn.LightCNN_29Layers_v2(num_classes=80013)
-        prog = bb.build_program()
-        eng = Engine(prog, B, dev)
         make_sd = lambda: sd_holder.setdefault('sd', synth.synth_state_dict(bb, seed=0))   # noqa: E731
-        x = synth.synth_images(B, (1, 128, 128), seed=1234 + rank, scale255=False).to(dev)
-        seed = torch.zeros((1, B, 80013), device=dev)
-        seed[0, :, 0] = 1.0
-        cls_t = prog.marks['classify']
-        W.pipeline = 2          # forward of step i+1 under the backward of step i; x is resident (inputs_ready below)
+        xs = synth.synth_images(B, (1, 128, 128), seed=1234 + rank, scale255=False)
+        if not cpu_only:
+            prog = bb.build_program()
+            eng = Engine(prog, B, dev)
+            x = xs.to(dev)
+            seed = torch.zeros((1, B, 80013), device=dev)
+            seed[0, :, 0] = 1.0
+            cls_t = prog.marks['classify']
+            W.pipeline = 2          # forward of step i+1 under the backward of step i; x is resident (inputs_ready below)
 
-        def step(ready=True):
-            _, pooled = eng.ebp(x, cls_t, seed, want_mwp=False, want_pooled=True, inputs_ready=ready)
-            return eng.mwp_to_saliency(pooled[0])
-        W.step = step
+            def step(ready=True):
+                _, pooled = eng.ebp(x, cls_t, seed, want_mwp=False, want_pooled=True, inputs_ready=ready)
+                return eng.mwp_to_saliency(pooled[0])
+            W.step = step
         # the engine only runs the relu(W) forward where a hook divides by X ('affineonly' needs none): 2 F_fwd executed, 3 F_fwd in
         # the modes that divide by a Split's X -- the roofline uses the executed GEMM FLOPs, capped by SURVEY's 3 F_fwd
         W.flop_per_unit = 3 * F_FWD['lightcnn']
@@ -219,23 +286,36 @@ def make_workload(args, dev, rank):
         W.work = 'Light-CNN-29v2 excitation backprop, batch=%d synthetic images per GPU, mode %s' % (B, W.mode)
         W.fixture = None
         W.pmc_tag = '_lcnn' if (B == 128 and W.mode == 'affineonly') else None
+        W.cpu_what = 'Light-CNN-29v2 ebp call(s) over the 80013-way classifier'
 
-        def cpu(budget):
+        def cpu_unit():
             from oracle import ebp_oracle as O
-            ow = O.OracleWhitebox('lightcnn29v2', sd_holder['sd'], ('hooked', None), W.mode)
-            xs = x.cpu()
+            ow = O.OracleWhitebox('lightcnn29v2', make_sd(), ('hooked', None), W.mode)
             P = torch.zeros((1, 80013))
             P[0, 0] = 1.0
-            return time_port(lambda i: ow.ebp(xs[i:i + 1], P), 'Light-CNN-29v2 ebp call(s) over the 80013-way classifier', B, budget)
-    W.eng = eng
+            return (lambda i: ow.ebp(xs[i:i + 1], P)), B
+    W.cpu_unit = cpu_unit
+    W.batch_arg = args.batch
+
+    def cpu(budget, with_whole_host=True):
+        unit, n_units = cpu_unit()
+        out = time_port(unit, W.cpu_what, n_units, budget)
+        if W.model == 'resnet101':
+            out.update(port_vs_reference(ROOT))
+        if with_whole_host:
+            out['whole_host'] = whole_host(W.model, W.batch_arg, W.mode, out['cores'], budget)
+        return out
     W.cpu_baseline = cpu
+    W.sd_holder = sd_holder
+    if cpu_only:
+        return W
+    W.eng = eng
     shard.load_and_broadcast(eng, make_sd, src=0)      # rank 0 packs, everybody receives the arena over RCCL
     eng.set_mode(W.mode)
-    W.sd_holder = sd_holder
     return W
 
 
-def rank_report(eng, rank, local, world):
+def rank_report(eng, rank, local, world, binding=None):
     """What proves N ranks and one broadcast in the driver's log: per rank the device, the checksum of the packed parameter arena it
     ended up with (equal on all ranks) and the RCCL version; gathered on rank 0 for the JSON line, echoed on stderr by every rank."""
     import torch
@@ -247,14 +327,86 @@ def rank_report(eng, rank, local, world):
         rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
     except Exception:
         rccl = None
-    me = {'rank': rank, 'device': local, 'device_name': torch.cuda.get_device_name(local), 'arena_bytes': int(arena.numel()),
-          'arena_checksum48': '%012x' % crc, 'rccl': rccl, 'backend': dist.get_backend() if dist.is_initialized() else None}
+    from xfr_amd import shard
+    me = {'rank': rank, 'device': local, 'visible_device': shard.normalize_gpus([local])[0], 'device_name': torch.cuda.get_device_name(local),
+          'arena_bytes': int(arena.numel()), 'arena_checksum48': '%012x' % crc, 'rccl': rccl,
+          'backend': dist.get_backend() if dist.is_initialized() else None}
+    if binding is not None:
+        me['cpu_binding'] = binding
     sys.stderr.write('bench.py rank %d/%d: %s\n' % (rank, world, json.dumps(me)))
     allr = [me]
     if world > 1:
         allr = [None] * world
         dist.all_gather_object(allr, me)
     return allr
+
+
+def timed_loop(W, steps, warmup, barrier, world, dev):
+    """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; the checks on the last step's maps."""
+    import torch
+    import torch.distributed as dist
+    step = W.step
+    for _ in range(warmup):
+        sal = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sal = step()
+    t_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (launch-bound if close to dt)
+    barrier()
+    dt = dt_rank = time.perf_counter() - t0
+    cs = chain_stats()                        # process-wide counters right after the timed loop: nothing but product-path steps so far
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # every map of the last step: finite, non-negative, unit sum
+    ok = bool(torch.isfinite(sal).all().item()) and float(sal.min().item()) >= 0.0 and \
+        float((sal.sum(dim=(1, 2)) - 1.0).abs().max().item()) < 1e-3
+    return {'dt': dt, 'dt_rank': dt_rank, 't_enqueue': t_enqueue, 'sal': sal, 'ok': ok, 'chain': cs}
+
+
+def executed_flops(W, reps=2):
+    """(GEMM ms, launches, executed GEMM FLOPs) per step of the one-stream schedule: HIP events around every launch."""
+    eng = W.eng
+    eng.set_profile(True)
+    s_ms, s_n, s_fl = 0.0, 0, 0.0
+    for _ in range(reps):
+        W.step(False)
+        ms, n, fl = eng.get_profile(); s_ms += ms; s_n += n; s_fl += fl
+    eng.set_profile(False)
+    return s_ms / reps, s_n / reps, s_fl / reps
+
+
+def run_secondary(model, dev, steps, warmup, chain_before):
+    """One secondary BASELINE.json configuration at N = 1 under the main line's rules: resident inputs, W untimed + K timed steps between
+    synchronisations, every map checked, row 0 against the reference's map where a fixture exists."""
+    import torch
+
+    class A(object):
+        pass
+    a = A()
+    a.model, a.batch, a.mode = model, None, None
+    W = make_workload(a, dev, 0)
+    W.eng.set_pipeline(W.pipeline)
+    r = timed_loop(W, steps, warmup, torch.cuda.synchronize, 1, dev)
+    ms_step = 1e3 * r['dt'] / steps
+    ok, row0 = r['ok'], None
+    if W.fixture:
+        row0 = fixture_cosine(r['sal'][0], W.fixture)
+        ok = ok and row0 is not None and row0 >= ROW0_COS
+    interp = r['chain'][1] - chain_before[1]
+    ok = ok and interp == 0
+    _, n_launch, fl = executed_flops(W, 1)
+    alg_step = min(W.flop_per_unit * W.B, fl)
+    out = {'model': model, 'metric': W.metric, 'workload': W.work, 'value': W.B * steps / r['dt'], 'unit': 'maps/s', 'ms_per_step': ms_step,
+           'steps': steps, 'warmup': warmup, 'frac_timed': alg_step / (ms_step * 1e-3) / PEAK_F32_MFMA,
+           'algorithmic_flop_per_step': alg_step, 'gemm_launches_per_step': n_launch,
+           'outputs_ok': ok, 'row0_cosine_vs_reference': row0, 'interpreted_chain_launches': interp}
+    W.eng.close()
+    del W
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -267,6 +419,9 @@ def main():
     ap.add_argument('--model', default='resnet101', choices=['resnet101', 'resnet50_128', 'lightcnn'],
                     help='resnet101 = the BASELINE.json headline; the other two are its secondary configurations')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-whole-host', action='store_true', help='cpu_baseline without the P-process whole-host figure')
+    ap.add_argument('--no-secondary', action='store_true', help='N = 1, --model resnet101: do not append the ResNet-50-128d / Light-CNN lines')
+    ap.add_argument('--secondary-steps', type=int, default=15)
     ap.add_argument('--no-unfused-ref', action='store_true', help='skip the extra un-fused reference steps of the roofline object')
     ap.add_argument('--no-profile', action='store_true', help='no roofline object (no extra steps after the timed region)')
     ap.add_argument('--serial', action='store_true', help='run every step on ONE stream with per-GEMM HIP events; use under rocprofv3 so that kernel durations are not inflated by concurrent streams')
@@ -277,7 +432,13 @@ def main():
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
+    ap.add_argument('--bind', action='store_true', help='pin every rank to its own CPU set (the GPU\'s NUMA node split among the ranks that share it): 8 launch threads of ~500 launches per step each do not migrate or share cores')
+    ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-worker-seconds', type=float, default=20.0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-worker-threads', type=int, default=16, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker_main(args.model, args.cpu_worker_seconds, args.cpu_worker_threads, args.batch, args.mode)
 
     import torch
     import torch.distributed as dist
@@ -291,9 +452,10 @@ def main():
             sys.exit(2)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    binding = shard.bind_rank_cpus(local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))) if args.bind else None
     W = make_workload(args, dev, rank)
     eng, B = W.eng, W.B
-    ranks = rank_report(eng, rank, local, world)
+    ranks = rank_report(eng, rank, local, world, binding)
     if rank == 0 and len({r['arena_checksum48'] for r in ranks}) != 1:
         sys.stderr.write('bench.py: the ranks hold different parameter arenas after the broadcast\n')
         sys.exit(3)
@@ -321,22 +483,13 @@ def main():
         eng.set_profile(True)
         if args.profile_csv:
             eng.profile_csv(args.profile_csv)
-    for _ in range(args.warmup):
-        sal = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sal = step()
-    t_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (launch-bound if close to dt)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # every map of the last step: finite, non-negative, unit sum; sample 0 (rank 0) against the reference's map of that triplet
-    ok = bool(torch.isfinite(sal).all().item()) and float(sal.min().item()) >= 0.0 and \
-        float((sal.sum(dim=(1, 2)) - 1.0).abs().max().item()) < 1e-3
+    r = timed_loop(W, args.steps, args.warmup, barrier, world, dev)
+    dt, t_enqueue, sal, ok = r['dt'], r['t_enqueue'], r['sal'], r['ok']
+    chain_timed = r['chain']              # (compiled, interpreted, signatures) through the end of the timed loop
+    # the product path runs compiled epilogues only: an interpreted launch inside the timed region fails the line
+    ok = ok and (chain_timed[1] == 0 or args.fusion is not None)
+    # per-rank rates: a straggler shows up as `spread` (the whole-job value below uses the MAX-over-ranks time)
+    rank_rates = shard.gather_rank_rates(B * args.steps / r['dt_rank'], dev)
     row0 = None
     if rank == 0 and W.fixture:
         row0 = fixture_cosine(sal[0], W.fixture)
@@ -367,18 +520,17 @@ def main():
         sustained = {'maps_s': n_sus * B / (time.perf_counter() - t1), 'seconds': time.perf_counter() - t1, 'steps': n_sus}
 
     roof = None
+    unfused_leg = None
     ms_step = 1e3 * dt / args.steps
     if not args.no_profile and rank == 0:
         peak = PEAK_F32_MFMA / 1e12
         # (1) one stream, HIP events around every GEMM launch on the launch stream: what rocprofv3 --kernel-trace can reproduce
         #     (profiles/rNN/kernel_stats_serial*.csv); the executed FLOPs tell how much of the algorithmic count the mode needs
-        eng.set_profile(True)
-        s_ms, s_n, s_fl, reps = 0.0, 0, 0.0, 2
-        for _ in range(reps):
-            W.step(False)
-            ms, n, fl = eng.get_profile(); s_ms += ms; s_n += n; s_fl += fl
-        eng.set_profile(False)
-        alg_step = min(W.flop_per_unit * B, s_fl / reps) if W.model == 'lightcnn' else W.flop_per_unit * B
+        reps = 2
+        s_ms, s_n, s_fl = executed_flops(W, reps)
+        # the numerator of every fraction: never more than what the launches executed (ResNets: the stem's backward-data GEMM is --
+        # correctly -- never run, so executed < 6 F_fwd; Light-CNN 'affineonly' needs no relu(W) forward)
+        alg_step = min(W.flop_per_unit * B, s_fl)
         # (2) the timed schedule itself: launch log written by the kernels, streams overlapped as timed
         for _ in range(3):
             step()
@@ -389,17 +541,17 @@ def main():
         clk = tuning.shader_clock(step, 6, dev)
         achieved = tl['achieved_over_union_TFLOPs']
         roof = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
-                'kernel': 'conv_gemm_kernel + conv_gemm_ks_kernel (all GEMM launches of one step), timed three-stream schedule',
-                'how': 'algorithmic FLOPs / union of the GEMM launches\' busy intervals (in-kernel s_memrealtime stamps, xfr_amd/tuning.py)',
+                'kernel': 'conv_gemm kernels (all GEMM launches of one step), timed three-stream schedule',
+                'how': 'min(algorithmic, executed) FLOPs / union of the GEMM launches\' busy intervals (in-kernel s_memrealtime stamps, xfr_amd/tuning.py)',
                 'launches_per_step': tl['launches_per_step'], 'gemm_busy_ms_per_step': tl['gemm_union_busy_ms_per_step'],
                 'avg_launch_ms': tl['avg_launch_ms_in_union'], 'step_ms_while_logging': tl['ms_per_step'],
                 'concurrent_launches_ms_per_step': tl['concurrent_launches_ms_per_step'],
-                # the same algorithmic FLOPs over the TIMED step (every non-GEMM kernel included)
+                # the same FLOPs over the TIMED step (every non-GEMM kernel included)
                 'frac_timed': alg_step / (ms_step * 1e-3) / PEAK_F32_MFMA, 'achieved_timed': alg_step / (ms_step * 1e-3) / 1e12,
                 # one stream (the schedule rocprofv3 --kernel-trace sees): sum of the launch durations, HIP events
-                'frac_serial': alg_step * reps / (s_ms * 1e-3) / PEAK_F32_MFMA, 'achieved_serial': alg_step * reps / (s_ms * 1e-3) / 1e12,
-                'gemm_ms_per_step_serial': s_ms / reps, 'avg_launch_ms_serial': s_ms / max(s_n, 1),
-                'executed_flop_per_step': s_fl / reps, 'algorithmic_flop_per_step': alg_step}
+                'frac_serial': alg_step / (s_ms * 1e-3) / PEAK_F32_MFMA, 'achieved_serial': alg_step / (s_ms * 1e-3) / 1e12,
+                'gemm_ms_per_step_serial': s_ms, 'avg_launch_ms_serial': s_ms / max(s_n, 1),
+                'executed_flop_per_step': s_fl, 'algorithmic_flop_per_step': W.flop_per_unit * B, 'flop_per_step_used': alg_step}
         if clk:
             # 157.3 TFLOP/s is the peak at the nominal 2.4 GHz; what the chip can do at the clock it actually held
             roof['shader_clock_GHz'] = clk
@@ -410,8 +562,10 @@ def main():
         if args.timeline_json:
             json.dump(tl, open(args.timeline_json, 'w'), indent=1)
         # the same launches with the elementwise epilogues un-fused (convolution work only): reference figure for the MFMA
-        # kernel by itself; the product path above is the fused one
+        # kernel by itself; the product path above is the fused one.  Its merged copy / flush chains accumulate into their
+        # destination and therefore run INTERPRETED epilogues: counted separately below, never part of the product path's count.
         if not args.no_unfused_ref and W.model == 'resnet101':
+            before = chain_stats()
             eng.set_epilogue_fusion(False)
             eng.set_profile(True)
             u_ms, u_n = 0.0, 0
@@ -420,8 +574,26 @@ def main():
                 ms, n, fl = eng.get_profile(); u_ms += ms; u_n += n
             eng.set_profile(False)
             eng.set_epilogue_fusion(True)
+            after = chain_stats()
+            unfused_leg = {'compiled_launches': after[0] - before[0], 'interpreted_launches': after[1] - before[1]}
             roof['unfused_epilogues_serial'] = {'achieved': alg_step * reps / (u_ms * 1e-3) / 1e12, 'frac': alg_step * reps / (u_ms * 1e-3) / PEAK_F32_MFMA,
                                                 'gemm_ms_per_step': u_ms / reps, 'avg_launch_ms': u_ms / max(u_n, 1)}
+
+    secondary = None
+    if rank == 0 and world == 1 and args.model == 'resnet101' and not args.no_secondary and not args.serial and args.batch is None and args.mode is None:
+        # BASELINE.json configs[2] and configs[3] on the same line (the driver only runs the default command)
+        chain_main = chain_stats()
+        eng.close()
+        del eng
+        W.eng = None
+        torch.cuda.empty_cache()
+        secondary = []
+        for m in ('resnet50_128', 'lightcnn'):
+            try:
+                secondary.append(run_secondary(m, dev, args.secondary_steps, 3, chain_stats()))
+            except Exception as ex:      # the headline must still be printed
+                secondary.append({'model': m, 'error': repr(ex), 'outputs_ok': False})
+        del chain_main
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -434,17 +606,21 @@ def main():
             'outputs_ok': ok, 'row0_cosine_vs_reference': row0,
             # host time per step while the queue is full (back-pressure included) and on an empty queue (the true launch cost)
             'host_enqueue_ms_per_step': 1e3 * t_enqueue / args.steps, 'host_enqueue_idle_ms': host_idle_ms,
+            'rank_maps_s': rank_rates,
             'ranks': ranks,
         }
         if sustained is not None:
             line['sustained_maps_s'] = world * sustained['maps_s']
             line['sustained'] = sustained
-        cs = chain_stats()
-        line['chain_epilogues'] = {'compiled_launches': cs[0], 'interpreted_launches': cs[1], 'signatures': cs[2]}
+        # counters as they stood right after the timed loop (warm-up + timed steps: the product path); the un-fused reference leg apart
+        line['chain_epilogues'] = {'compiled_launches': chain_timed[0], 'interpreted_launches': chain_timed[1], 'signatures': chain_timed[2],
+                                   'when': 'through the end of the timed loop', 'unfused_reference_leg': unfused_leg}
         if roof is not None:
             line['roofline'] = roof
+        if secondary is not None:
+            line['secondary'] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = W.cpu_baseline(20.0)
+            line['cpu_baseline'] = W.cpu_baseline(20.0, not args.no_whole_host)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

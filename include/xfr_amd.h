@@ -323,7 +323,10 @@ xfr_status xfr_debug_conv_stamps(void* stamps_dev, int32_t capacity_workgroups);
  * device memory, 64 bytes per launch, `capacity` launches), every GEMM launch of this process records when its first workgroup
  * started and its last one ended (s_memrealtime, 10 ns ticks) and the library notes its shape, stream and tile configuration.  A
  * call with dump_path != NULL first writes what has been recorded so far as CSV (synchronise the device before); log_dev = NULL
- * stops recording.  tools/gemm_timeline.py reads the file. */
+ * stops recording.  tools/gemm_timeline.py reads the file.
+ * xfr_debug_conv_stamps and xfr_debug_conv_log are PROCESS-GLOBAL and NOT thread-safe: set, dump and clear them from the one host thread
+ * that also issues the engine calls being measured; no engine may be launching from another thread meanwhile.  A dump after
+ * log_dev = NULL writes nothing and returns XFR_OK. */
 xfr_status xfr_debug_conv_log(void* log_dev, int32_t capacity, const char* dump_path);
 
 /* Bytes of device memory held by the engine (weights + workspace). */
@@ -340,7 +343,8 @@ xfr_status xfr_engine_profile_csv(xfr_engine* e, const char* path);
 
 /* Process-wide counts of GEMM launches that carried a fused elementwise chain: those whose epilogue was one of the
  * compile-time specialised ones (xfr_amd/csrc/chain_sigs.inc) and those that fell back to the interpreter; n_signatures =
- * size of the compiled table.  bench.py and the tests assert interpreted == 0 on the three BASELINE backbones. */
+ * size of the compiled table.  bench.py snapshots the counters right after its timed loop and fails `outputs_ok` if an interpreted
+ * launch ran there; tests/test_gpu_entry.py asserts interpreted == 0 for the benchmarked entry point on the BASELINE backbones. */
 xfr_status xfr_chain_epilogue_stats(int64_t* compiled_launches, int64_t* interpreted_launches, int32_t* n_signatures);
 
 /* The planner without a device: the fused forward-only and backward schedules of a layer program for one subtree mode and

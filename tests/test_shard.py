@@ -34,7 +34,10 @@ def _worker(rank, world, port, q):
     local = torch.stack([torch.full((4, 4), float(i)) for i in range(lo, hi)]) if hi > lo else torch.zeros((0, 4, 4))
     allm = shard.gather_maps(local, n_total)
     ok_g = bool((allm[:, 0, 0] == torch.arange(n_total, dtype=torch.float32)).all())
-    q.put((rank, ok_b, ok_g))
+    # per-rank rates: rank 1 plays the straggler (half the rate); every rank sees it in `spread`
+    rr = shard.gather_rank_rates(100.0 if rank == 0 else 50.0)
+    ok_r = rr['per_rank'] == [100.0, 50.0] and rr['min'] == 50.0 and rr['max'] == 100.0 and abs(rr['spread'] - 0.5) < 1e-12
+    q.put((rank, ok_b, ok_g and ok_r))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,3 +54,46 @@ def test_gloo_world_size_2_broadcast_and_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] and r[2] for r in res)
+
+
+def test_rank_rates_single_process():
+    rr = shard.gather_rank_rates(1234.5)
+    assert rr == {'per_rank': [1234.5], 'min': 1234.5, 'max': 1234.5, 'spread': 0.0}
+
+
+def test_normalize_gpus_like_the_reference():
+    # no mask: unchanged (utils.py:521-525)
+    assert shard.normalize_gpus([0, 1], env={}) == [0, 1]
+    assert shard.normalize_gpus([0, 1], env={'HIP_VISIBLE_DEVICES': ''}) == [0, 1]
+    # logical index -> entry of the mask (utils.py:531-536); HIP's mask wins over CUDA's
+    assert shard.normalize_gpus([0, 2], env={'HIP_VISIBLE_DEVICES': '4,5,7'}) == [4, 7]
+    assert shard.normalize_gpus([1], env={'CUDA_VISIBLE_DEVICES': '3,2'}) == [2]
+    assert shard.normalize_gpus([1], env={'HIP_VISIBLE_DEVICES': '6,1', 'CUDA_VISIBLE_DEVICES': '3,2'}) == [1]
+    assert shard.normalize_gpus([0], env={'ROCR_VISIBLE_DEVICES': 'GPU-abcdef'}) == ['GPU-abcdef']
+    # more GPUs than visible / index outside the range: ValueError (utils.py:528-529, 535-536)
+    with pytest.raises(ValueError):
+        shard.normalize_gpus([0, 1, 2], env={'HIP_VISIBLE_DEVICES': '0,1'})
+    with pytest.raises(ValueError):
+        shard.normalize_gpus([5], env={'HIP_VISIBLE_DEVICES': '0,1'})
+
+
+def test_cpu_binding_slices():
+    assert shard.parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    sl = shard.cpu_slices(range(16), 3)
+    assert sum(sl, []) == list(range(16)) and max(map(len, sl)) - min(map(len, sl)) <= 1
+    with pytest.raises(ValueError):
+        shard.cpu_slices([0, 1], 3)
+    # no NUMA information (nodes unknown): an even split of the allowed CPUs; the calling process really is pinned, then restored
+    before = os.sched_getaffinity(0)
+    allowed = sorted(before)
+    if len(allowed) >= 2:
+        try:
+            b0 = shard.bind_rank_cpus(0, 2, nodes=[None, None], allowed=allowed)
+            got0 = sorted(os.sched_getaffinity(0))
+            os.sched_setaffinity(0, before)
+            b1 = shard.bind_rank_cpus(1, 2, nodes=[None, None], allowed=allowed)
+            got1 = sorted(os.sched_getaffinity(0))
+        finally:
+            os.sched_setaffinity(0, before)
+        assert got0 + got1 == allowed and not set(got0) & set(got1)
+        assert b0['n_cpus'] == len(got0) and b1['n_cpus'] == len(got1) and 'even split' in b0['how']

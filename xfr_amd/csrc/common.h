@@ -249,7 +249,16 @@ constexpr int XFR_TAIL_MAX_TILES = 256;
 constexpr size_t XFR_TAIL_WS_BYTES = (size_t)16 << 20;
 // false: nothing was launched -- a dual (W / relu(W)) launch carries a chain for which no compiled epilogue exists
 bool launch_conv_gemm(const ConvParams& p, hipStream_t s);
+// 0 if launch_conv_gemm will accept p's fused chain, else why not (text: conv_gemm_refusal): 1 = dual launch without a compiled epilogue,
+// 2 = MaxFeatureMap step (EW_MAXPAIR / EW_MAXHALF_OUT) without a compiled epilogue.  No device work.
+int conv_gemm_cannot_launch(const ConvParams& p);
+const char* conv_gemm_refusal(int why);
 int conv_gemm_pick_cfg(const ConvParams& p);
+// conv_ws.hip: the persistent wave-specialised kernel for 1x1 stride-1 layers.  conv_ws_ok: the launch fits its scope (its chain, if any,
+// must also have a compiled epilogue); launch_conv_ws: q with the chain already planned (chain_sig, chain_ld), cfg 8 = (BK 16, 3 stages),
+// 9 = (16, 4)
+bool conv_ws_ok(const ConvParams& p);
+void launch_conv_ws(const ConvParams& q, int cfg, hipStream_t s);
 
 // g = src[idx]; run chain; dst[idx] = (accumulate ? dst[idx] : 0) + g.   Tensors are [C][SB][HW] for the gradient
 // and [C][B][HW] for the forward-side sources (sample b = sb % B).

@@ -32,259 +32,17 @@
 #include <atomic>
 #include <vector>
 #include "common.h"
-#include "ew_interp.h"
 #include <cstdio>
 #include <cstdlib>
 
-typedef float v16f __attribute__((ext_vector_type(16)));
+#include "conv_epilogue.h"
 
 namespace {
 
 constexpr int NT = 256;
 std::atomic<long> g_chain_launches[2];   // GEMM launches with a fused chain: [0] compiled epilogue, [1] interpreted (engines may run on several host threads)
 
-// XCD-aware block -> tile mapping.  The dispatcher places block b on XCD b % 8; remap so that each XCD walks a
-// contiguous range of logical tiles, ordered co-fastest: the blocks that share one activation (m) tile run
-// back-to-back on the same XCD and hit its private L2.  Bijective for any grid size.
-__device__ inline int xcd_remap(int bid, int nblk)
-{
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + loc;
-}
-
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// Buffer-addressed global -> LDS loads.  address = rsrc.base + voffset (per lane) + soffset (wave-uniform); a lane
-// whose voffset is >= rsrc.num_records (we use 0x80000000 for masked im2col elements) is out of range and the
-// hardware writes 0.0 into its LDS slot -- padding, M tails and K tails cost no branch and no zero page.
-__device__ inline void bload16(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)l, 16, (int)voff, (int)soff, 0, 0);
-}
-__device__ inline void bload4(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)l, 4, (int)voff, (int)soff, 0, 0);
-}
-
-constexpr unsigned OOB = 0x80000000u;
-
 enum { MODE_VEC = 0, MODE_TAP = 1, MODE_GEN = 2, MODE_TAP4 = 3 };
-
-// tuning hook: phase stamps of a wave (ConvParams::stamps)
-__device__ __forceinline__ void stamp(const ConvParams& p, int wave, int lane, int slot, int kind = 0)
-{
-    bool rec = p.stamps && lane == 0;
-    int idx = blockIdx.x;
-    if (rec) {
-        if (p.stamp_regions > 0) {
-            const int stride = (gridDim.x + 255) >> 8;
-            rec = (blockIdx.x % stride) == 0;
-            idx = (p.stamp_seq % p.stamp_regions) * 256 + blockIdx.x / stride;
-        } else rec = (int)blockIdx.x < p.stamps_cap;
-    }
-    if (rec) {
-        unsigned long long* q = p.stamps + ((size_t)idx * 4 + wave) * 8;
-        q[slot] = __builtin_amdgcn_s_memrealtime();      // the 100 MHz reference clock: one time base for all XCDs
-        if (slot == 0) {
-            q[5] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);       // HW_REG_HW_ID
-            q[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20)       // HW_REG_XCC_ID
-                   | (unsigned long long)(p.K & 0xffff) << 8 | (unsigned long long)(p.M & 0x3fffff) << 24 | (unsigned long long)(p.CoutTot & 0x1fff) << 46
-                   | (unsigned long long)kind << 60;   // which launch shape (and which of the two kernels) wrote the record
-            q[7] = __builtin_amdgcn_s_memtime();                        // shader-clock counter (per XCD): entry ...
-        }
-        if (slot == 4) q[7] = __builtin_amdgcn_s_memtime() - q[7];      // ... to exit: shader cycles of this wave's life
-    }
-    // launch log: block 0 notes the start, a sample of the workgroups their end -- plain stores into the launch's 8-word record (slot
-    // 1 + (block / 16) % 7: the last writer of a slot is one of the late workgroups; the host takes the maximum over the slots)
-    if (p.span && lane == 0 && wave == 0) {
-        if (slot == 0 && blockIdx.x == 0) p.span[0] = __builtin_amdgcn_s_memrealtime();
-        if (slot == 4 && ((blockIdx.x & 15) == 0 || blockIdx.x == gridDim.x - 1)) p.span[1 + (blockIdx.x >> 4) % 7] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
-template <int N>
-__device__ inline void wait_vmcnt()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ float pick4(float a0, float a1, float a2, float a3, int slot)
-{   // slot is wave-uniform
-    float r = a0;
-    r = slot == 1 ? a1 : r;
-    r = slot == 2 ? a2 : r;
-    r = slot == 3 ? a3 : r;
-    return r;
-}
-
-// channel of GEMM row `co`: the identity, except for MaxFeatureMap convolutions packed interleaved (ConvParams::co_pair)
-__device__ __forceinline__ int out_row(const ConvParams& p, int co) { return p.co_pair ? (co & 1) * p.co_pair + (co >> 1) : co; }
-
-// ---- compiled chain epilogues -------------------------------------------------------------------------------------------
-// chain_sigs.inc (generated by tools/gen_chain_sigs.py from the layer programs of the three backbones in all four subtree
-// modes) lists the signatures of the chains the planner fuses behind GEMMs.  For a listed chain the epilogue below is
-// specialised at compile time: the step types, which prefetch slot feeds which step and which slots exist are constants, so
-// the micro-program is straight-line code, its operand loads are independent of each other and can all be issued before the
-// accumulator tile has even been turned through LDS, and the per-step descriptor fields are scalar loads at fixed offsets.
-#include "chain_sigs.inc"
-
-// host side: does compiled signature `sig` belong to the MaxFeatureMap kernel family (chain_epilogue_dispatch)
-inline bool chain_sig_is_mfm(int sig)
-{
-    for (int i = 0; i < XFR_MAX_EW_STEPS; ++i) {
-        const int op = sig_op(kChainSigs[sig][i]);
-        if (op == SIG_MAXPAIR || op == SIG_MAXHALF_OUT) return true;
-    }
-    return false;
-}
-
-template <int SIG>
-constexpr unsigned sig_live_slots()
-{
-    unsigned m = 0;
-    for (int i = 0; i < XFR_MAX_EW_STEPS; ++i) {
-        const unsigned c = kChainSigs[SIG][i];
-        if (sig_op(c) == SIG_END) break;
-        if (sig_is_slot(sig_s0(c))) m |= 1u << sig_s0(c);
-        if (sig_is_slot(sig_s1(c))) m |= 1u << sig_s1(c);
-    }
-    return m;
-}
-
-template <int SIG>
-constexpr bool sig_has_maxpair()
-{
-    for (int i = 0; i < XFR_MAX_EW_STEPS; ++i)
-        if (sig_op(kChainSigs[SIG][i]) == SIG_MAXPAIR) return true;
-    return false;
-}
-
-template <int SIG>
-constexpr bool sig_has_fanout()
-{
-    for (int i = 0; i < XFR_MAX_EW_STEPS; ++i)
-        if (sig_op(kChainSigs[SIG][i]) == SIG_MAXHALF_OUT) return true;
-    return false;
-}
-
-struct EpiOps {          // operands of one float4 piece; indexed by compile-time constants only (stays in registers)
-    float4 partner;      // SIG_MAXPAIR: the same positions of row c ^ 1 (bias included)
-    float4* out4;        // SIG_MAXHALF_OUT: the fan-out stores its two halves itself
-    unsigned row4, arow4;
-    float4 v[EW_NLOADS];
-    float pc0[XFR_MAX_EW_STEPS], pc1[XFR_MAX_EW_STEPS];
-};
-
-template <int SIG, int I>
-__device__ __forceinline__ void epi_load_pc(EpiOps& o, const EwChain& ch, int c)
-{
-    constexpr unsigned code = kChainSigs[SIG][I];
-    constexpr int op = sig_op(code);
-    if constexpr (op != SIG_END) {
-        constexpr int st = sig_step(code);
-        if constexpr (op == SIG_SCALE_C) o.pc0[I] = ch.s[st].p0[c];
-        if constexpr (op == SIG_AFFINE_C || op == SIG_FORK_POSBN) { o.pc0[I] = ch.s[st].p0[c]; o.pc1[I] = ch.s[st].p1[c]; }
-        if constexpr (I + 1 < XFR_MAX_EW_STEPS) epi_load_pc<SIG, I + 1>(o, ch, c);
-    }
-}
-
-template <int SIG>
-__device__ __forceinline__ void epi_load(EpiOps& o, const ConvParams& p, unsigned idx4, unsigned aidx4, int c)
-{
-    constexpr unsigned live = sig_live_slots<SIG>();
-    if constexpr ((live & 1u) != 0) o.v[0] = reinterpret_cast<const float4*>(p.chain_ld.lp[0])[aidx4];
-    if constexpr ((live & 2u) != 0) o.v[1] = reinterpret_cast<const float4*>(p.chain_ld.lp[1])[aidx4];
-    if constexpr ((live & 4u) != 0) o.v[2] = reinterpret_cast<const float4*>(p.chain_ld.lp[2])[aidx4];
-    if constexpr ((live & 8u) != 0) o.v[3] = reinterpret_cast<const float4*>(p.chain_ld.lp[3])[idx4];
-    if constexpr ((live & 32u) != 0) o.v[5] = reinterpret_cast<const float4*>(p.chain_ld.lp[5])[aidx4];
-    if constexpr ((live & 64u) != 0) o.v[6] = reinterpret_cast<const float4*>(p.chain_ld.lp[6])[aidx4];
-    epi_load_pc<SIG, 0>(o, p.chain, c);
-}
-
-// the steps of signature SIG from code I on, on one float4 piece: same operations in the same order as ew_interpret
-template <int SIG, int I>
-__device__ __forceinline__ void epi_steps(float (&g)[4], const EpiOps& o, const EwChain& ch, unsigned idx4, unsigned aidx4, float eps)
-{
-    constexpr unsigned code = kChainSigs[SIG][I];
-    constexpr int op = sig_op(code);
-    if constexpr (op != SIG_END) {
-        constexpr int st = sig_step(code), s0 = sig_s0(code), s1 = sig_s1(code);
-        if constexpr (op == SIG_HOOK_DIV || op == SIG_HOOK_RELU || op == SIG_HOOK_PASS) {
-            float4 av;
-            if constexpr (sig_is_slot(s0)) av = o.v[s0]; else av = reinterpret_cast<const float4*>(ch.s[st].p0)[aidx4];
-            const float a[4] = {fmaxf(av.x, 0.f), fmaxf(av.y, 0.f), fmaxf(av.z, 0.f), fmaxf(av.w, 0.f)};
-            float pp[4], zh[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { zh[q] = fmaxf(g[q], 0.f); pp[q] = a[q] * zh[q]; }
-            if constexpr (sig_store(code)) reinterpret_cast<float4*>(ch.s[st].pstore)[idx4] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-            if constexpr (op == SIG_HOOK_DIV) {
-                float x[4] = {a[0], a[1], a[2], a[3]};
-                if constexpr (s1 != 7) {
-                    float4 xv;
-                    if constexpr (sig_is_slot(s1)) xv = o.v[s1]; else xv = reinterpret_cast<const float4*>(ch.s[st].p1)[aidx4];
-                    x[0] = fmaxf(xv.x, 0.f); x[1] = fmaxf(xv.y, 0.f); x[2] = fmaxf(xv.z, 0.f); x[3] = fmaxf(xv.w, 0.f);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = __fdiv_rn(pp[q], x[q] + eps);
-            } else if constexpr (op == SIG_HOOK_RELU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = zh[q];
-            }
-        } else if constexpr (op == SIG_RELU) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
-        } else if constexpr (op == SIG_MASK) {
-            float4 tv;
-            if constexpr (sig_is_slot(s0)) tv = o.v[s0]; else tv = reinterpret_cast<const float4*>(ch.s[st].p0)[aidx4];
-            g[0] = tv.x > 0.f ? g[0] : 0.f; g[1] = tv.y > 0.f ? g[1] : 0.f;
-            g[2] = tv.z > 0.f ? g[2] : 0.f; g[3] = tv.w > 0.f ? g[3] : 0.f;
-        } else if constexpr (op == SIG_SCALE_C) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] *= o.pc0[I];
-        } else if constexpr (op == SIG_SCALE) {
-            const float f = ch.s[st].f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] *= f;
-        } else if constexpr (op == SIG_STORE) {
-            reinterpret_cast<float4*>(ch.s[st].pstore)[idx4] = make_float4(g[0], g[1], g[2], g[3]);
-        } else if constexpr (op == SIG_ADDP) {
-            float4 d;
-            if constexpr (sig_is_slot(s0)) d = o.v[s0]; else d = reinterpret_cast<const float4*>(ch.s[st].p0)[idx4];
-            g[0] += d.x; g[1] += d.y; g[2] += d.z; g[3] += d.w;
-        } else if constexpr (op == SIG_AFFINE_C) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] = __fadd_rn(__fmul_rn(g[q], o.pc0[I]), o.pc1[I]);
-        } else if constexpr (op == SIG_MAXHALF_OUT) {
-            // VJP of torch.max(split[0], split[1]) as a fan-out: both halves run the rest of the chain at their own channel and store
-            const int Co = ch.s[st].action;
-            const float4* tin = reinterpret_cast<const float4*>(ch.s[st].p0);
-            const float4 ta = tin[aidx4], tb = tin[aidx4 + (unsigned)Co * o.arow4];
-            const float av[4] = {ta.x, ta.y, ta.z, ta.w}, bv[4] = {tb.x, tb.y, tb.z, tb.w};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float gh[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) gh[q] = ew_maxhalf_route(g[q], h ? bv[q] : av[q], h ? av[q] : bv[q]);
-                const unsigned i4 = idx4 + (unsigned)(h * Co) * o.row4, a4 = aidx4 + (unsigned)(h * Co) * o.arow4;
-                if constexpr (I + 1 < XFR_MAX_EW_STEPS) epi_steps<SIG, I + 1>(gh, o, ch, i4, a4, eps);
-                o.out4[i4] = make_float4(gh[0], gh[1], gh[2], gh[3]);
-            }
-            return;
-        } else if constexpr (op == SIG_MAXPAIR) {
-            // torch.max(a, b): NaN propagates (lightcnn.py:62 through at::maximum)
-            const float w[4] = {o.partner.x, o.partner.y, o.partner.z, o.partner.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] = (g[q] != g[q]) ? g[q] : ((w[q] != w[q]) ? w[q] : fmaxf(g[q], w[q]));
-        } else {   // SIG_FORK_POSBN
-            reinterpret_cast<float4*>(ch.s[st].pstore)[idx4] =
-                make_float4(__fadd_rn(__fmul_rn(fmaxf(g[0], 0.f), o.pc0[I]), o.pc1[I]), __fadd_rn(__fmul_rn(fmaxf(g[1], 0.f), o.pc0[I]), o.pc1[I]),
-                            __fadd_rn(__fmul_rn(fmaxf(g[2], 0.f), o.pc0[I]), o.pc1[I]), __fadd_rn(__fmul_rn(fmaxf(g[3], 0.f), o.pc0[I]), o.pc1[I]));
-        }
-        if constexpr (I + 1 < XFR_MAX_EW_STEPS) epi_steps<SIG, I + 1>(g, o, ch, idx4, aidx4, eps);
-    }
-}
 
 // Epilogue of one wave's 32x32 accumulator tile for a chain with signature SIG.  A lane owns, for each of the four 8-channel
 // groups hf, one float4 piece (channel hf*8 + lane/8, positions 4*(lane%8)..+3).  The operand loads of groups 0 and 1 are
@@ -385,8 +143,6 @@ __device__ __forceinline__ void dense_epilogue(const ConvParams& p, const v16f& 
 // The compiled epilogues live in two kernel families: the MaxFeatureMap signatures (pair maximum, fan-out VJP: two more operand
 // loads and a chain tail that runs twice) need ~10 registers more than the rest, and a kernel's register count -- hence how many
 // workgroups share a CU -- is the maximum over everything it contains.  MFM = false: every other signature (all ResNet chains).
-template <int SIG>
-constexpr bool sig_is_mfm() { return sig_has_maxpair<SIG>() || sig_has_fanout<SIG>(); }
 
 template <int SIG, bool MFM>
 __device__ __forceinline__ void chain_epilogue_dispatch(int sig, const ConvParams& p, const v16f& acc, float* tile, int lane, int l31,
@@ -1285,6 +1041,23 @@ int pick_tail_split(const ConvParams& p, int tiles, int nk, size_t tile_bytes)
     return bestS;
 }
 
+// Chain of a launch: operand prefetch plan, compiled signature.  Returns 0, or why the launch cannot carry its chain (conv_gemm_refusal).
+int plan_chain(ConvParams& q)
+{
+    EwChain wide = q.chain;                  // compiled epilogues may use the two extra forward slots
+    EwLoads wide_ld;
+    ew_plan_loads(wide, q.out0, wide_ld, EW_FWD_SLOTS_WIDE);
+    ew_plan_loads(q.chain, q.out0, q.chain_ld);
+    const int ohw = q.OH * q.OW;
+    const bool vec_ok = (q.M & 3) == 0 && ((q.chain_B * ohw) & 3) == 0 && ((q.out_nb * ohw) & 3) == 0;
+    q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
+    if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
+    if (q.nhalves == 2 && q.chain_sig < 0) return 1;      // a dual launch can only carry a compiled chain: the caller un-fuses
+    for (int i = 0; i < q.chain.n && q.chain_sig < 0; ++i)
+        if (q.chain.s[i].type == EW_MAXPAIR || q.chain.s[i].type == EW_MAXHALF_OUT) return 2;   // steps the interpreter does not have
+    return 0;
+}
+
 template <int TCO, int TM, int BK, int NST, int MODE>
 bool launch_one(const ConvParams& p, hipStream_t s)
 {
@@ -1305,19 +1078,8 @@ bool launch_one(const ConvParams& p, hipStream_t s)
         }
     }
     if constexpr (TCO == 64 && TM == 64) {
-        if (q.chain.n > 0) {      // fused micro-program: backward launches only (no relu_in, one half)
-            EwChain wide = q.chain;                  // compiled epilogues may use the two extra forward slots
-            EwLoads wide_ld;
-            ew_plan_loads(wide, q.out0, wide_ld, EW_FWD_SLOTS_WIDE);
-            ew_plan_loads(q.chain, q.out0, q.chain_ld);
-            const int ohw = q.OH * q.OW;
-            const bool vec_ok = (q.M & 3) == 0 && ((q.chain_B * ohw) & 3) == 0 &&
-                                ((q.out_nb * ohw) & 3) == 0;
-            q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
-            if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
-            if (q.nhalves == 2 && q.chain_sig < 0) return false;      // a dual launch can only carry a compiled chain: the caller un-fuses
-            for (int i = 0; i < q.chain.n && q.chain_sig < 0; ++i)
-                if (q.chain.s[i].type == EW_MAXPAIR || q.chain.s[i].type == EW_MAXHALF_OUT) return false;   // steps the interpreter does not have
+        if (q.chain.n > 0) {      // fused micro-program (no relu_in)
+            if (plan_chain(q)) return false;
             g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
             if (q.chain_sig >= 0 && chain_sig_is_mfm(q.chain_sig))
                 hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 3>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
@@ -1358,17 +1120,7 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
         }
     }
     if (q.chain.n > 0) {
-        EwChain wide = q.chain;
-        EwLoads wide_ld;
-        ew_plan_loads(wide, q.out0, wide_ld, EW_FWD_SLOTS_WIDE);
-        ew_plan_loads(q.chain, q.out0, q.chain_ld);
-        const int ohw = q.OH * q.OW;
-        const bool vec_ok = (q.M & 3) == 0 && ((q.chain_B * ohw) & 3) == 0 && ((q.out_nb * ohw) & 3) == 0;
-        q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
-        if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
-        if (q.nhalves == 2 && q.chain_sig < 0) return false;      // a dual launch can only carry a compiled chain: the caller un-fuses
-        for (int i = 0; i < q.chain.n && q.chain_sig < 0; ++i)
-            if (q.chain.s[i].type == EW_MAXPAIR || q.chain.s[i].type == EW_MAXHALF_OUT) return false;   // steps the interpreter does not have
+        if (plan_chain(q)) return false;
         g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
         if (q.chain_sig >= 0 && chain_sig_is_mfm(q.chain_sig))
             hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 3>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
@@ -1433,6 +1185,22 @@ int conv_gemm_chain_sig(const EwChain& ch)
 }
 int conv_gemm_num_chain_sigs() { return kNumChainSigs; }
 
+int conv_gemm_cannot_launch(const ConvParams& p)
+{
+    if (p.chain.n <= 0) return 0;
+    ConvParams q = p;
+    return plan_chain(q);
+}
+const char* conv_gemm_refusal(int why)
+{
+    switch (why) {
+        case 0: return "the convolution launch was refused without a reason";
+        case 1: return "a dual (W / relu(W)) convolution launch carries a fused chain without a compiled epilogue";
+        case 2: return "a fused chain with a MaxFeatureMap step (pair maximum / fan-out VJP) has no compiled epilogue and the interpreter does not run those steps";
+        default: return "unknown convolution launch refusal";
+    }
+}
+
 void conv_gemm_chain_launch_counts(long* compiled, long* interpreted)
 {
     if (compiled) *compiled = g_chain_launches[0].load();
@@ -1481,6 +1249,8 @@ unsigned long long* g_log = nullptr;
 int g_log_cap = 0;
 std::vector<LogRec> g_log_recs;
 }
+// The tuning hooks below (stamps, launch log) are process-global and NOT thread-safe: one host thread, no engine launching on another
+// thread while they are being set, dumped or cleared (include/xfr_amd.h says so for xfr_debug_conv_log / xfr_debug_conv_stamps).
 void conv_gemm_set_log(unsigned long long* log_dev, int capacity)
 {
     g_log = log_dev;
@@ -1489,6 +1259,7 @@ void conv_gemm_set_log(unsigned long long* log_dev, int capacity)
 }
 int conv_gemm_dump_log(const char* path)
 {
+    if (!g_log) return 0;                       // logging was stopped: the host records are stale, the device buffer may be gone
     const size_t n = g_log_recs.size();
     std::vector<unsigned long long> h(8 * n + 8);
     if (n && hipMemcpy(h.data(), g_log, 8 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -1516,6 +1287,19 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
         g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
     }
     const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
+    // cfg 8 / 9: the persistent wave-specialised kernel (conv_ws.hip) for 1x1 stride-1 layers whose chain, if any, is compiled
+    if ((cfg == 8 || cfg == 9) && conv_ws_ok(p)) {
+        ConvParams q = p;
+        q.tail_q = 0;
+        q.tail_s = 1;
+        bool ws = true;
+        if (q.chain.n > 0) {
+            if (plan_chain(q)) return false;
+            ws = q.chain_sig >= 0;               // an interpreted chain stays on conv_gemm_kernel
+            if (ws) g_chain_launches[0]++;
+        }
+        if (ws) { launch_conv_ws(q, cfg, s); return true; }
+    }
     // cfg 6 / 7: the intra-workgroup split-K kernel, (BK, ring stages) = (8, 3): 48 KB of LDS, three workgroups per CU; (4, 4): 32 KB, five.
     // Round 3 sweep (tools/conv_sweep.py): (4, 5) and (4, 6) tie with (4, 4), (16, 3) -- one workgroup per CU -- loses 15 %.
     if (cfg == 6 && ks_ok<8>(p)) return launch_cfg_ks<8, 3>(p, s);

@@ -116,6 +116,7 @@ struct BwdPlan {
     std::vector<BwdStep> fused_gemm_nofan; // the same without the MaxFeatureMap fan-out (a compiled-only epilogue step): what the interpreted epilogues run
     std::vector<int> firing_kinds;   // xfr_op_kind per firing, reference order
     int n_firings = 0;
+    int fan_ok = -1;                 // does every fan-out epilogue of fused_gemm have a compiled signature (-1: not checked yet; fanout_compiled)
 };
 
 }  // namespace
@@ -583,15 +584,20 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
             e->ev_pool.emplace_back(a, b);
         }
         if (e->ev_params.size() < e->ev_pool.size()) e->ev_params.resize(e->ev_pool.size());
+        const int why = conv_gemm_cannot_launch(p);
+        if (why) return fail(XFR_STATE_ERROR, "%s", conv_gemm_refusal(why));          // nothing launched: no event pair, no record
+        // The first GEMM of a profiled run: everything enqueued before it (layout conversion, cross-stream waits of the step before)
+        // must have retired, or its start event -- recorded on a stream that is idle at enqueue time -- is stamped early and the launch
+        // is charged its predecessors (round 3: the stems read 0.87 ms in the per-shape table where rocprofv3 saw 0.37).
+        if (e->ev_used == 0) HIP_TRY(hipStreamSynchronize(s));
         e->ev_params[e->ev_used] = p;
         auto& ev = e->ev_pool[e->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, s));
-        const bool launched = launch_conv_gemm(p, s);
+        launch_conv_gemm(p, s);
         HIP_TRY(hipEventRecord(ev.second, s));
-        if (!launched) return fail(XFR_STATE_ERROR, "a dual convolution launch carries a fused chain without a compiled epilogue");
         e->prof_flops += 2.0 * (double)(p.K_logical ? p.K_logical : p.K) * (double)p.M * (double)p.CoutTot * (double)p.nhalves;
     } else if (!launch_conv_gemm(p, s)) {
-        return fail(XFR_STATE_ERROR, "a dual convolution launch carries a fused chain without a compiled epilogue");
+        return fail(XFR_STATE_ERROR, "%s", conv_gemm_refusal(conv_gemm_cannot_launch(p)));
     }
     return XFR_OK;
 }
@@ -1224,6 +1230,14 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
                     if (c.chain[q].type == EW_SCALE_C || c.chain[q].type == EW_AFFINE_C || c.chain[q].type == EW_FORK_POSBN) fan = false;   // per-channel
             }                                                                                                                        // parameters of row c
             if (!fan && (e->tens[c.ew_t].C != e->tens[b_t].C || e->tens[c.ew_t].HW() != e->tens[b_t].HW())) continue;
+            // behind a fan-out the chain runs per half at channel c + h * Co, but the epilogue loads per-channel parameters at GEMM row
+            // c: a chain with per-channel steps must not follow EW_MAXHALF_OUT (at the merge that creates the fan-out, above, or later)
+            {
+                bool a_fanned = false, c_perchan = false;
+                for (const Sym& y : a.chain) if (y.type == EW_MAXHALF_OUT) a_fanned = true;
+                for (const Sym& y : c.chain) if (y.type == EW_SCALE_C || y.type == EW_AFFINE_C || y.type == EW_FORK_POSBN) c_perchan = true;
+                if (a_fanned && c_perchan) continue;
+            }
             // does anything after j still read b_t?
             bool other_readers = false;
             for (size_t k = j + 1; k < st.size() && !inplace; ++k) {      // (in place: later readers want the chain's result, which is what stays)
@@ -1336,6 +1350,66 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
     }
 }
 
+// launch parameters of a backward-data GEMM step (with its fused chain resolved against the workspace)
+void bwd_conv_params(xfr_engine* e, const BwdPlan& plan, const BwdStep& st, int B, int SB, int SBa, ConvParams& p)
+{
+    const OpRec& o = e->ops[st.op];
+    const xfr_op_desc& d = o.d;
+    const Tensor& a = e->tens[d.in0];
+    const Tensor& t = e->tens[d.out];
+    memset(&p, 0, sizeof(p));
+    p.in = e->G(st.src_t);
+    p.w = e->arena + (plan.plain ? o.w_bwd_true : o.w_bwd);
+    p.out0 = e->G(st.dst_t);
+    p.Cin = t.C; p.H = t.H; p.W = t.W; p.NB = SBa; p.in_nb = SB; p.out_nb = SB;
+    p.tap_major = (d.stride == 1 && o.tap_bwd) ? 1 : 0;
+    p.in_bytes = (unsigned)((size_t)SB * t.per_n() * sizeof(float));
+    p.CoutTot = a.C; p.nhalves = 1; p.ldw = o.ldb;
+    p.K = o.Kb;
+    p.accumulate = st.accumulate;
+    if (d.stride == 1) {
+        // backward-data of a stride-1 convolution == convolution with the flipped, transposed kernel and padding k-1-p
+        p.kh = d.kh; p.kw = d.kw; p.stride = 1; p.pad = d.kh - 1 - d.pad;
+        p.OH = a.H; p.OW = a.W;
+        p.out_H = a.H; p.out_W = a.W; p.out_stride = 1;
+    } else {
+        // 1x1 stride-s: the gradient lands on the sampled grid only
+        p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0;
+        p.OH = t.H; p.OW = t.W;
+        p.out_H = a.H; p.out_W = a.W; p.out_stride = d.stride;
+        p.accumulate = 1;   // the target was zero-filled or already holds other contributions
+    }
+    p.M = SBa * p.OH * p.OW;
+    if (!st.chain.empty()) {
+        resolve_chain(e, st.chain, p.chain, nullptr, SB);
+        p.chain_B = B;
+        p.chain_eps = e->eps;
+        p.accumulate = 0;
+    }
+    p.chain_interpret = e->interpret_chains ? 1 : 0;
+}
+
+// The fan-out schedule (plan.fused_gemm: MaxFeatureMap VJPs inside GEMM epilogues) only runs where every such epilogue is COMPILED --
+// the interpreter has no fan-out step.  Every other fusion falls back to the interpreted epilogue; a network whose merged fan-out
+// chain is not in chain_sigs.inc falls back to the schedule without fan-outs (plan.fused_gemm_nofan).  Decided once per plan: whether
+// a chain has a compiled signature depends on the layer program and the mode, not on the batch (the fan-out requires HW % 4 == 0).
+bool fanout_compiled(xfr_engine* e, BwdPlan& plan, int B, int SB)
+{
+    if (plan.fan_ok >= 0) return plan.fan_ok != 0;
+    plan.fan_ok = 1;
+    for (const BwdStep& st : plan.fused_gemm) {
+        if (st.kind != ST_CONV_BWD) continue;
+        bool fan = false;
+        for (const auto& sy : st.chain) if (sy.type == EW_MAXHALF_OUT) fan = true;
+        if (!fan) continue;
+        ConvParams p;
+        bwd_conv_params(e, plan, st, B, SB, SB, p);
+        p.chain_interpret = 0;
+        if (conv_gemm_cannot_launch(p)) { plan.fan_ok = 0; break; }
+    }
+    return plan.fan_ok != 0;
+}
+
 xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t s)
 {
     const int SB = S * B;
@@ -1354,7 +1428,8 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
     const bool prefix = !e->rc_active.empty() && (int)e->rc_active.size() * e->rc_n == SB;
     int run_max = -1;
     const bool use_gemm_fusion = use_fused && e->fuse_gemm_epilogue && !special && !plan.fused_gemm.empty();
-    for (const BwdStep& st : (use_gemm_fusion ? (e->interpret_chains ? plan.fused_gemm_nofan : plan.fused_gemm) : use_fused ? plan.fused : plan.steps)) {
+    const bool fanout = use_gemm_fusion && !e->interpret_chains && fanout_compiled(e, plan, B, SB);
+    for (const BwdStep& st : (use_gemm_fusion ? (fanout ? plan.fused_gemm : plan.fused_gemm_nofan) : use_fused ? plan.fused : plan.steps)) {
         int SBa = SB;
         if (prefix) {
             for (const auto& sy : st.chain)
@@ -1374,41 +1449,8 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                 launch_fill(e->G(st.dst_t), (long)SB * e->tens[st.dst_t].per_n(), 0.f, s);
                 break;
             case ST_CONV_BWD: {
-                const OpRec& o = e->ops[st.op];
-                const xfr_op_desc& d = o.d;
-                const Tensor& a = e->tens[d.in0];
-                const Tensor& t = e->tens[d.out];
                 ConvParams p;
-                memset(&p, 0, sizeof(p));
-                p.in = e->G(st.src_t);
-                p.w = e->arena + (plan.plain ? o.w_bwd_true : o.w_bwd);
-                p.out0 = e->G(st.dst_t);
-                p.Cin = t.C; p.H = t.H; p.W = t.W; p.NB = SBa; p.in_nb = SB; p.out_nb = SB;
-                p.tap_major = (d.stride == 1 && o.tap_bwd) ? 1 : 0;
-                p.in_bytes = (unsigned)((size_t)SB * t.per_n() * sizeof(float));
-                p.CoutTot = a.C; p.nhalves = 1; p.ldw = o.ldb;
-                p.K = o.Kb;
-                p.accumulate = st.accumulate;
-                if (d.stride == 1) {
-                    // backward-data of a stride-1 convolution == convolution with the flipped, transposed kernel and
-                    // padding k-1-p
-                    p.kh = d.kh; p.kw = d.kw; p.stride = 1; p.pad = d.kh - 1 - d.pad;
-                    p.OH = a.H; p.OW = a.W;
-                    p.out_H = a.H; p.out_W = a.W; p.out_stride = 1;
-                } else {
-                    // 1x1 stride-s: the gradient lands on the sampled grid only
-                    p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0;
-                    p.OH = t.H; p.OW = t.W;
-                    p.out_H = a.H; p.out_W = a.W; p.out_stride = d.stride;
-                    p.accumulate = 1;   // the target was zero-filled or already holds other contributions
-                }
-                p.M = SBa * p.OH * p.OW;
-                if (!st.chain.empty()) {
-                    resolve_chain(e, st.chain, p.chain, nullptr, SB);
-                    p.chain_B = B;
-                    p.chain_eps = e->eps;
-                    p.accumulate = 0;
-                }
+                bwd_conv_params(e, plan, st, B, SB, SBa, p);
                 xfr_status rs = run_conv(e, p, s);
                 if (rs != XFR_OK) return rs;
                 break;
@@ -1504,6 +1546,10 @@ xfr_status fence_slot0(xfr_engine* e, hipStream_t s)
 
 xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_tensor, const float* seed_dev, hipStream_t s)
 {
+    // the one-shot promise of xfr_engine_set_inputs_ready covers THIS call, whatever becomes of it: consumed before the first check that
+    // can fail, so an early error never leaves it standing for a later call that declared nothing
+    const bool ready = e->inputs_ready;
+    e->inputs_ready = false;
     if (seed_tensor < 2 || seed_tensor >= (int)e->tens.size()) return fail(XFR_INVALID_ARG, "bad seed tensor %d", seed_tensor);
     if (!seed_dev) return fail(XFR_INVALID_ARG, "null seed");
     BwdPlan* plan = nullptr;
@@ -1516,9 +1562,7 @@ xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_te
     e->cur_slot = pipe ? (int)(e->seq++ & 1) : 0;
     const int slot = e->cur_slot;
     if (pipe && e->slot_pending[slot]) HIP_TRY(hipStreamWaitEvent(sf, e->ev_slot_done[slot], 0));
-    // the promise covers ONE call: a caller that forgets to renew it falls back to the safe ordering, never to a stale promise
-    const bool ready = e->inputs_ready;
-    e->inputs_ready = false;
+    // (the promise covers ONE call: a caller that forgets to renew it falls back to the safe ordering, never to a stale promise)
     if (pipe && !ready) {
         // x_dev may still be pending on the caller's stream (a cast, a copy): order the internal forward after it.  Callers
         // whose inputs are resident declare it with xfr_engine_set_inputs_ready and keep the cross-call overlap.

@@ -75,3 +75,101 @@ def gather_maps(local_maps, n_total):
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
     return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(outs, sizes)], dim=0)
+
+
+def normalize_gpus(gpus, env=None):
+    """Logical GPU indices (command line, LOCAL_RANK) -> the ids the runtime was told to expose, like the reference's
+    `normalize_gpus` does with CUDA_VISIBLE_DEVICES (python/xfr/utils.py:515-540) -- here through HIP_VISIBLE_DEVICES, then
+    ROCR_VISIBLE_DEVICES, then CUDA_VISIBLE_DEVICES (ROCm honours all three).  No mask set: the list is returned unchanged.
+    Raises ValueError like the reference when an index lies outside the visible range."""
+    env = os.environ if env is None else env
+    mask = None
+    for name in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if env.get(name):
+            mask = env[name]
+            break
+    if not mask:
+        return list(gpus)
+    visible = [v.strip() for v in mask.split(',')]
+    if len(visible) < len(gpus):
+        raise ValueError('more GPUs requested than are visible through the *_VISIBLE_DEVICES mask')
+    out = []
+    for g in gpus:
+        if not 0 <= int(g) < len(visible):
+            raise ValueError('GPU %s is outside the visible range' % (g,))
+        v = visible[int(g)]
+        out.append(int(v) if v.lstrip('-').isdigit() else v)
+    return out
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (sysfs cpulist format)."""
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def cpu_slices(cpus, n_ranks):
+    """Split a CPU list into n_ranks contiguous, disjoint, non-empty slices (sizes differ by at most one)."""
+    cpus = sorted(cpus)
+    if n_ranks < 1 or len(cpus) < n_ranks:
+        raise ValueError('%d CPUs cannot be split among %d ranks' % (len(cpus), n_ranks))
+    return [cpus[slice(*shard_range(len(cpus), r, n_ranks))] for r in range(n_ranks)]
+
+
+def gpu_numa_node(local):
+    """NUMA node of logical device `local` from sysfs (PCI address from the device properties), or None."""
+    try:
+        p = torch.cuda.get_device_properties(local)
+        bdf = '%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def bind_rank_cpus(local, local_world, nodes=None, allowed=None):
+    """One CPU set per rank: the CPUs of the GPU's NUMA node, split among the ranks whose GPUs sit on that node (the reference's
+    workers are unpinned, generate_inpaintinggame_wb_saliency_maps_multigpu.py:193-216; eight launch threads of ~500 launches per
+    step each should neither migrate nor share cores).  Falls back to an even split of the allowed CPUs when sysfs says nothing.
+    `nodes` (test hook): NUMA node per local rank; `allowed`: the CPU list to carve from.  Returns what was done (for the rank report)."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    if nodes is None:
+        nodes = [gpu_numa_node(i) for i in range(local_world)]
+    how, mine = 'even split of the allowed CPUs', None
+    node = nodes[local] if local < len(nodes) else None
+    if node is not None:
+        try:
+            node_cpus = [c for c in parse_cpulist(open('/sys/devices/system/node/node%d/cpulist' % node).read()) if c in set(allowed)]
+            peers = [i for i in range(local_world) if nodes[i] == node]
+            if len(node_cpus) >= len(peers):
+                mine = cpu_slices(node_cpus, len(peers))[peers.index(local)]
+                how = 'NUMA node %d split among %d rank(s)' % (node, len(peers))
+        except Exception:
+            mine = None
+    if mine is None:
+        mine = cpu_slices(allowed, local_world)[local]
+    try:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), torch.get_num_threads())))
+    except Exception as ex:
+        how += ' (sched_setaffinity failed: %r)' % (ex,)
+    return {'cpus': '%d-%d' % (mine[0], mine[-1]) if mine == list(range(mine[0], mine[-1] + 1)) else ','.join(map(str, mine)),
+            'n_cpus': len(mine), 'numa_node': node, 'how': how}
+
+
+def gather_rank_rates(rate, device=None):
+    """Every rank's own rate (units/s over ITS time for the timed steps) -> {'per_rank', 'min', 'max', 'spread'} on every rank;
+    spread = (max - min) / max: a straggler that the whole-job figure (max-over-ranks time) hides shows up here."""
+    rates = [float(rate)]
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([float(rate)], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+        outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, t)
+        rates = [float(o.item()) for o in outs]
+    mx, mn = max(rates), min(rates)
+    return {'per_rank': rates, 'min': mn, 'max': mx, 'spread': (mx - mn) / mx if mx > 0 else 0.0}
