@@ -68,8 +68,9 @@ def time_port(unit, what, n_units, budget_s):
     is chosen by a short probe and reported as `cores`."""
     import torch
     ncpu = os.cpu_count() or 1
+    usable = host_cpu_budget()['usable']
     best_t, best_dt = None, None
-    for th in sorted({min(ncpu, c) for c in (8, 16, 32)}):
+    for th in sorted({max(1, min(ncpu, c)) for c in (8, 16, 32, usable)}):
         torch.set_num_threads(th)
         t0 = time.time()
         unit(0)
@@ -86,7 +87,7 @@ def time_port(unit, what, n_units, budget_s):
             break
     dt = time.time() - t0
     return {'value': n / dt, 'unit': 'maps/s', 'cores': int(best_t), 'kind': 'port',
-            'sample': '%d %s, batch 1, %.1f s, %d threads (best of 8/16/32; host has %d)' % (n, what, dt, best_t, ncpu)}
+            'sample': '%d %s, batch 1, %.1f s, %d threads (best of 8/16/32/%d; host shows %d logical CPUs, grants %d)' % (n, what, dt, best_t, usable, ncpu, usable)}
 
 
 def cpu_worker_main(model, seconds, threads, batch, mode):
@@ -111,13 +112,39 @@ def cpu_worker_main(model, seconds, threads, batch, mode):
     print(json.dumps({'units': n, 'seconds': time.time() - t0}))
 
 
+def host_cpu_budget():
+    """CPUs this process may really use: the smaller of the affinity mask and the cgroup CPU quota (cpu.max / cfs_quota_us).  The GPU
+    boxes of this pool show 256 hardware threads to os.cpu_count() under a quota of 16 CPUs: threads beyond the quota only get throttled
+    (round 4: 16 processes x 16 threads finished 16 units in 28.7 s where ONE such process finishes 49 in 20 s)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return {'logical': os.cpu_count() or 1, 'affinity': n, 'cgroup_quota': quota, 'usable': int(max(1, min(n, quota if quota else n)))}
+
+
 def whole_host(model, batch, mode, threads, budget_s):
     """north_star: "next to the reference's CPU-only path timed on the same box's host cores".  One worker cannot use the host (the
     batch-1 convolutions stop scaling at ~16 threads), so P = cpu_count // threads worker PROCESSES of `threads` threads each run the
     port side by side for `budget_s` seconds; value = all units finished / the common window."""
     import subprocess
-    ncpu = os.cpu_count() or 1
+    budget = host_cpu_budget()
+    ncpu = budget['usable']
     P = max(1, ncpu // max(threads, 1))
+    if P == 1:
+        return {'processes': 1, 'host_cpus': budget,
+                'note': 'the host grants this process %d CPUs (cgroup quota / affinity; %d logical): the %d-thread figure above IS the whole-host figure' % (
+                    ncpu, budget['logical'], threads)}
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', '--model', model, '--cpu-worker-seconds', str(budget_s),
            '--cpu-worker-threads', str(threads)] + (['--batch', str(batch)] if batch else []) + (['--mode', mode] if mode else [])
@@ -142,7 +169,7 @@ def whole_host(model, batch, mode, threads, budget_s):
             except Exception:
                 q.kill()
     units = sum(o['units'] for o in outs)
-    return {'value': units / dt, 'unit': 'maps/s', 'cores': P * threads, 'processes': P, 'threads_per_process': threads, 'kind': 'port',
+    return {'value': units / dt, 'unit': 'maps/s', 'cores': P * threads, 'processes': P, 'threads_per_process': threads, 'kind': 'port', 'host_cpus': budget,
             'sample': '%d units by %d processes x %d threads in %.1f s (host has %d hardware threads)' % (units, P, threads, dt, ncpu)}
 
 
@@ -431,6 +458,7 @@ def main():
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 10 s sustained loop after the timed region')
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
+    ap.add_argument('--persistent-gemm', action='store_true', help='xfr_engine_set_persistent_gemm(1): the short-K 1x1 layers on the persistent wave-specialised kernel (A/B on one box; off by default)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
     ap.add_argument('--bind', action='store_true', help='pin every rank to its own CPU set (the GPU\'s NUMA node split among the ranks that share it): 8 launch threads of ~500 launches per step each do not migrate or share cores')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
@@ -476,6 +504,8 @@ def main():
 
     if args.fusion is not None:
         eng.set_epilogue_fusion(args.fusion)
+    if args.persistent_gemm:
+        eng.set_persistent_gemm(True)
     if not args.no_pipeline and not args.serial:
         eng.set_pipeline(W.pipeline)      # inputs are resident and never modified: the pipelining contract holds
     step = W.step

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define XFR_AMD_ABI_VERSION 2
+#define XFR_AMD_ABI_VERSION 3
 
 typedef enum {
     XFR_OK = 0,
@@ -248,6 +248,12 @@ xfr_status xfr_engine_hold_forward(xfr_engine* e, int32_t hold);
  * bits between batch sizes / positions.  enable = 0 restores batch-invariant arithmetic (every output element is
  * accumulated in one K order regardless of the batch). */
 xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable);
+
+/* The persistent wave-specialised GEMM kernel (xfr_amd/csrc/conv_ws.hip) for the short-K 1x1 stride-1 layers: enable = 1 lets the
+ * launcher's rule select it (K <= 256, >= 1536 tiles); OFF by default -- round 4 measured it +5..8 % on those layers in isolation,
+ * level in the engine's serial schedule and -1.7 % in the timed three-stream step.  It sums K in the order of the
+ * one-tile-per-workgroup kernel it replaces: switching changes no bit (tests/test_gpu_parity.py).  ABI version 3. */
+xfr_status xfr_engine_set_persistent_gemm(xfr_engine* e, int32_t enable);
 
 /* _mwp_to_saliency (whitebox.py:448-460, ebp_ver 6) on N pooled maps: in N x H x W -> out N x H x W. */
 xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w,

@@ -1214,6 +1214,12 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.
     // K >= 512: the intra-workgroup split-K kernel (tools/conv_sweep.py, round 3: +6..13 % on the 3x3 layers and the K = 512 /
     // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
+    // Short-K 1x1 layers on grids of at least two tiles per resident workgroup: the persistent wave-specialised kernel (conv_ws.hip).  It sums K
+    // in conv_gemm_kernel's order, so choosing by the grid size (a property of the batch) changes no bit.
+    if (!p.no_ws && p.K <= 256 && conv_ws_ok(p)) {
+        const long t = (long)((p.CoutTot + 63) / 64) * p.nhalves * ((p.M + 63) / 64);
+        if (t >= 1536) return 9;
+    }
     if (ks_ok<8>(p)) {
         // The choice depends on the LAYER only, never on the batch: the two kernels sum K in different orders, and a sample's map must
         // not depend on how many samples share its launch.  In-engine serial table (tools/cmp_layers.py): deep-K 3x3 (ResNet layers
@@ -1288,8 +1294,9 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     }
     const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
     // cfg 8 / 9: the persistent wave-specialised kernel (conv_ws.hip) for 1x1 stride-1 layers whose chain, if any, is compiled
-    if ((cfg == 8 || cfg == 9) && conv_ws_ok(p)) {
+    if ((cfg >= 8 && cfg <= 11) && conv_ws_ok(p)) {
         ConvParams q = p;
+        q.ws_debug = cfg >= 10 ? 1 : 0;
         q.tail_q = 0;
         q.tail_s = 1;
         bool ws = true;

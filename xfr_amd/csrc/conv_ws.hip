@@ -209,7 +209,7 @@ __device__ __forceinline__ WsPiece ws_piece(const ConvParams& p, const WsEpi& t,
 // dense rows: bias, optional accumulate, one 16-byte store
 __device__ __forceinline__ void ws_dense_piece(const ConvParams& p, const WsPiece& q, int half, float4 v)
 {
-    if (!q.ok) return;
+    if (!q.ok || p.ws_debug == 1) return;          // ws_debug 1 (tuning): the math side alone -- nothing is stored
     const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
     float4* dst = reinterpret_cast<float4*>(half ? p.out1 : p.out0) + q.idx4;
     if (bsel) { const float b = bsel[q.co]; v.x += b; v.y += b; v.z += b; v.w += b; }
@@ -389,6 +389,6 @@ bool conv_ws_ok(const ConvParams& p)
 void launch_conv_ws(const ConvParams& q, int cfg, hipStream_t s)
 {
     const int kind = q.chain.n > 0 ? (chain_sig_is_mfm(q.chain_sig) ? 3 : 1) : 0;
-    if (cfg == 9) ws_launch<16, 4>(q, kind, s);
+    if (cfg == 9 || cfg == 11) ws_launch<16, 4>(q, kind, s);
     else ws_launch<16, 3>(q, kind, s);
 }

@@ -194,6 +194,7 @@ struct xfr_engine {
     TailWs tail_ws[8];
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
+    bool persistent_gemm = false;      // xfr_engine_set_persistent_gemm: conv_ws.hip where the launcher's rule selects it (round 4: measured, off by default)
     bool interpret_chains = false;     // xfr_engine_set_epilogue_fusion bit 2: fused chains run through the interpreted epilogue (tests)
     bool planning_only = false;        // xfr_plan_describe: list what the planner WOULD fuse, whatever the signature table holds
     bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue (STORE raw, [FORK positive
@@ -556,6 +557,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
     p.chain_interpret = e->interpret_chains ? 1 : 0;
+    p.no_ws = e->persistent_gemm ? 0 : 1;
     p.tail_force = 1;
     if (e->tail_balance) {
         p.tail_force = 0;
@@ -1977,6 +1979,13 @@ xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable)
     return XFR_OK;
 }
 
+xfr_status xfr_engine_set_persistent_gemm(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->persistent_gemm = enable != 0;
+    return XFR_OK;
+}
+
 xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
@@ -2339,7 +2348,10 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     HIP_TRY(hipEventCreate(&b));
     const int nstreams = std::max(1, std::min(4, cfg / 1000000));     // > 1: the same launches on several streams at once
     p.tail_force = (cfg / 10000) % 100;
-    launch_conv_gemm(p, 0);
+    // untimed warm-up: as many launches as are timed (at most 200).  The allocations and copies above left the device idle; one launch
+    // does not bring the clocks back, and the first configuration of a sweep row then reads 5-12 % low (round 4: the same kernel measured
+    // first and third in a row)
+    for (int r = 0; r < std::max(1, std::min(reps, 200)); ++r) launch_conv_gemm(p, 0);
     float ms = 0.f;
     if (nstreams == 1) {
         HIP_TRY(hipEventRecord(a, 0));

@@ -210,10 +210,17 @@ class Engine(object):
         _lib.check(self.lib.xfr_engine_set_tail_balance(self._h, int(bool(on))))
         self.options['tail_balance'] = bool(on)
 
+    def set_persistent_gemm(self, on):
+        """The persistent wave-specialised kernel for the short-K 1x1 stride-1 layers (default off; include/xfr_amd.h)."""
+        _lib.check(self.lib.xfr_engine_set_persistent_gemm(self._h, int(bool(on))))
+        self.options['persistent_gemm'] = bool(on)
+
     def apply_options(self, options):
         """Re-apply switches recorded by another Engine handle (WhiteboxNetwork.engine rebuilds engines that are too small)."""
         if 'tail_balance' in options:
             self.set_tail_balance(options['tail_balance'])
+        if 'persistent_gemm' in options:
+            self.set_persistent_gemm(options['persistent_gemm'])
         if 'epilogue_fusion' in options:
             self.set_epilogue_fusion(options['epilogue_fusion'])
         if options.get('pipeline'):
