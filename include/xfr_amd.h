@@ -230,7 +230,10 @@ xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
  * output (bit-identical; +0.6 % on ResNet-101, +2.2 % on ResNet-50-128d).  Bit 2 (tests): fused chains run through the
  * INTERPRETED epilogue -- the path a network outside the compiled signature table takes; the probe-forward and MaxFeatureMap
  * fusions, which only exist compiled, are then off.  enable = 0 gives every elementwise segment its own kernel again (the GEMM
- * launches then contain convolution work only, which is what one wants when profiling the MFMA kernel by itself). */
+ * launches then contain convolution work only, which is what one wants when profiling the MFMA kernel by itself).
+ * Light-CNN's pooling stages (lightcnn.py:252, MaxPool2d(2)(x) + AvgPool2d(2)(x)) run as one forward kernel (sum, argmax bytes, positive-pass
+ * sum) and their two VJPs as the head of the hook chain that follows them (EW_POOL2_IN) whenever bit 0 is set; bit 3 (tests) keeps the
+ * separate kernels / launches: bit-identical either way (round 4). */
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable);
 
 /* Share one forward pass between consecutive calls on the same input (off by default).  While hold = 1, a run call

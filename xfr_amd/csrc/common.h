@@ -32,6 +32,11 @@ enum {
     EW_MAXHALF_OUT = 11,// compiled GEMM epilogue only: the same VJP as a FAN-OUT in the epilogue of the GEMM that produces the Co-channel
                       // gradient: for both halves h the routed gradient runs the REST of the chain as channel c + h*Co of the 2*Co-channel
                       // tensor (operands loaded in place at that channel) and is stored there; p0 = true forward halves, action = Co
+    EW_POOL2_IN = 12, // chain HEAD only (stand-alone kernels): the VJPs of MaxPool2d(2) and AvgPool2d(2) on the SAME input, summed (lightcnn.py:252:
+                      // `maxpool(x) + avgpool(x)`).  The chain runs over the pools' input tensor [C][SB][H][W]; the source gradient is the gradient of
+                      // the sum, [C][SB][H/2][W/2]: g = 0.25 * src[window] + (argmax[window] == this pixel ? src[window] : 0) -- what AVGPOOL_BWD
+                      // followed by an accumulating MAXPOOL_BWD leave in the tensor, bit for bit.  p0 = the max-pool's argmax bytes ([C][B][H/2][W/2],
+                      // window-local index dh * 2 + dw), action = W
     EW_MAXPAIR = 10   // GEMM epilogue only, last step: g = max(g, value of the partner row c ^ 1) -- MaxFeatureMap of a convolution
                       // whose output channels were packed interleaved (row 2c = channel c, row 2c+1 = channel c + Co); the even
                       // rows then store g as channel c of the Co-channel output
@@ -283,6 +288,11 @@ void launch_add2(const float* a, const float* b, float* out, long n, int relu_a,
 void launch_copy_acc(const float* src, float* dst, long n, int accumulate, hipStream_t s);
 void launch_maxpool_fwd(const float* in, float* out, uint8_t* idx, int CN, int H, int W, int OH, int OW,
                         int k, int stride, int pad, hipStream_t s);
+// out_sum = maxpool2x2(in) + avgpool2x2(in), idx = the max-pool's argmax bytes (may be null), out_pos (may be null) = the positive-pass sum
+// (relu_max_pos ? relu(max) : max) + (pos_avg_mode 0: avg, 1: relu(avg), 2: avgpool(relu(in))); bit-identical to the three separate kernels
+bool pool2_fwd_ok(const float* in, const uint8_t* idx, int CN, int H, int W, int OH, int OW);
+void launch_pool2_fwd(const float* in, float* out_sum, uint8_t* idx, float* out_pos, int CN, int H, int W, int OH, int OW, int relu_max_pos,
+                      int pos_avg_mode, hipStream_t s);
 // gin (+)= scatter of gout through the stored argmax; gradient batch SB vs forward batch B
 void launch_maxpool_bwd(const float* gout, const uint8_t* idx, float* gin, int accumulate, int C, int SB, int B,
                         int H, int W, int OH, int OW, int k, int stride, int pad, hipStream_t s);

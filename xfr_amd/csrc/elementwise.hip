@@ -56,6 +56,12 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 const long arow = (long)B * HW, apos = (long)b * HW + hw;
                 const float a = ch.s[0].p0[(long)cs * arow + apos], bb = ch.s[0].p0[(long)(cs + Co) * arow + apos];
                 g = ew_maxhalf_route(src[(long)cs * per_c + r], c < Co ? a : bb, c < Co ? bb : a);
+            } else if (ch.n > 0 && ch.s[0].type == EW_POOL2_IN) {
+                const int W = ch.s[0].action, OW = W >> 1, OHW = HW >> 2;
+                const int ih = hw / W, iw = hw - ih * W;
+                const int win = (ih >> 1) * OW + (iw >> 1);
+                const uint8_t* ix = reinterpret_cast<const uint8_t*>(ch.s[0].p0) + ((long)c * B + b) * OHW;
+                g = ew_pool2_route(src[((long)c * SB + sb) * OHW + win], (int)ix[win], ih & 1, iw & 1);
             } else {
                 g = src[idx];
             }
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 else if (st.type == EW_ADDP) g += st.p0[idx];
                 else if (st.type == EW_AFFINE_C) g = __fadd_rn(__fmul_rn(g, st.p0[c]), st.p1[c]);
                 else if (st.type == EW_RELU) g = fmaxf(g, 0.f);
-                else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_MAXHALF_OUT) { }      // applied at the load / compiled epilogues only
+                else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_MAXHALF_OUT || st.type == EW_POOL2_IN) { }      // applied at the load / compiled epilogues only
                 else st.pstore[idx] = __fadd_rn(__fmul_rn(fmaxf(g, 0.f), st.p0[c]), st.p1[c]);
             }
         }
@@ -151,8 +157,22 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
     if (ld.lp[0]) s0 = reinterpret_cast<const float4*>(ld.lp[0])[aidx];
     if (ld.lp[1]) s1 = reinterpret_cast<const float4*>(ld.lp[1])[aidx];
     if (ld.lp[2]) s2 = reinterpret_cast<const float4*>(ld.lp[2])[aidx];
+    // chain head EW_POOL2_IN: this thread's four pixels lie in two 2x2 windows of one output row
+    const bool head_pool2 = ch.n > 0 && ch.s[0].type == EW_POOL2_IN;
     unsigned b = 0, hw = pos;
-    if (PRIOR || SBa < SB) { b = pos / (unsigned)HW4; hw = pos - b * (unsigned)HW4; }
+    if (PRIOR || SBa < SB || head_pool2) { b = pos / (unsigned)HW4; hw = pos - b * (unsigned)HW4; }
+    unsigned p2_win = 0, p2_ohw = 0;
+    int p2_ph = 0, p2_id0 = 0, p2_id1 = 0;
+    if (head_pool2) {
+        const unsigned W4 = (unsigned)ch.s[0].action >> 2, OW = (unsigned)ch.s[0].action >> 1;
+        const unsigned ih = hw / W4, iw4 = hw - ih * W4;
+        p2_ohw = (unsigned)HW4;                                   // (H/2) * (W/2) = HW / 4
+        p2_win = (ih >> 1) * OW + iw4 * 2u;                        // first of the two windows (even: 2-byte / 8-byte aligned pairs)
+        p2_ph = (int)(ih & 1u);
+        const uint16_t two = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ch.s[0].p0) + ((size_t)c * B + b) * p2_ohw + p2_win);
+        p2_id0 = two & 255;
+        p2_id1 = two >> 8;
+    }
     // chain head EW_MAXHALF_IN: the true forward halves of this position, shared by the gradient streams
     const bool head_maxhalf = ch.n > 0 && ch.s[0].type == EW_MAXHALF_IN;
     int cs = c;
@@ -179,6 +199,11 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
             const float4 gs = src[idx[u] - (long)(c - cs) * per_c];           // the Co-channel gradient, row c % Co
             g[u] = make_float4(ew_maxhalf_route(gs.x, own.x, oth.x), ew_maxhalf_route(gs.y, own.y, oth.y),
                                ew_maxhalf_route(gs.z, own.z, oth.z), ew_maxhalf_route(gs.w, own.w, oth.w));
+        } else if (head_pool2) {
+            // the gradient of the pooled sum, [C][SB][H/2][W/2]: two windows = one aligned float2
+            const float2 go = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(src) + ((size_t)c * SB + (ok[u] ? sb[u] : (int)b)) * p2_ohw + p2_win);
+            g[u] = make_float4(ew_pool2_route(go.x, p2_id0, p2_ph, 0), ew_pool2_route(go.x, p2_id0, p2_ph, 1),
+                               ew_pool2_route(go.y, p2_id1, p2_ph, 0), ew_pool2_route(go.y, p2_id1, p2_ph, 1));
         } else {
             g[u] = src[idx[u]];
         }
@@ -190,7 +215,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
     const int el0 = (int)(((unsigned)c * (unsigned)HW4 + hw) * 4u);
 #pragma unroll
     for (int u = 0; u < SG; ++u)
-        ew_interpret<PRIOR>(ok[u], idx[u], aidx, sb[u], el0, g[u], od[u], s0, s1, s2, v3[u], dst, accumulate, ch, c, eps);
+        ew_interpret<PRIOR>(ok[u], idx[u], aidx, sb[u], el0, g[u], od[u], s0, s1, s2, v3[u], dst, accumulate, ch, c, eps, (long)per_c, (long)per_ca);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -449,6 +474,59 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel_rows(const float* __res
     }
     out[(size_t)plane * OH * OW4 + q] = make_float4(best[0], best[1], best[2], best[3]);
     if (idx) idx[(size_t)plane * OH * OW4 + q] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+}
+
+// lightcnn.py:252 `MaxPool2d(2)(x) + AvgPool2d(2)(x)` in one pass over x (W = 2 OW, W % 8 == 0): the true sum, the max-pool's argmax bytes, and
+// -- where the consumer's hook divides by it -- the positive-pass sum relu(max) + avgpool(relu(x)).  A thread owns four windows of one output
+// row (two aligned float4 loads per input row).  Same arithmetic, in the same order, as maxpool_fwd_kernel_rows<2, 0> (first maximum wins, NaN
+// sticks), avgpool_fwd_kernel_v4<2, 2> (((0 + v00) + v01) + v10) + v11, times 0.25) and add2_kernel_v4 (max + avg): identical bits.
+// pos_avg_mode: 0 = the positive average is the true one, 1 = relu(true average), 2 = average of relu(x) (x signed)
+__global__ __launch_bounds__(NT) void pool2_fwd_kernel(const float* __restrict__ in, float4* __restrict__ out, uint32_t* __restrict__ idx,
+                                                      float4* __restrict__ out_pos, int H, int W, int OH, int OW, int relu_max_pos, int pos_avg_mode)
+{
+    const int plane = blockIdx.y;
+    const int OW4 = OW >> 2;
+    const int q = blockIdx.x * NT + threadIdx.x;
+    if (q >= OH * OW4) return;
+    const int oh = q / OW4, ow0 = (q - oh * OW4) * 4;
+    const float* __restrict__ row0 = in + (size_t)plane * H * W + (size_t)(2 * oh) * W + 2 * ow0;
+    const float* __restrict__ row1 = row0 + W;
+    const float4 a0 = *reinterpret_cast<const float4*>(row0), b0 = *reinterpret_cast<const float4*>(row0 + 4);
+    const float4 a1 = *reinterpret_cast<const float4*>(row1), b1 = *reinterpret_cast<const float4*>(row1 + 4);
+    const float c0[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
+    const float c1[8] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w};
+    float sum[4], psum[4];
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v[4] = {c0[2 * j], c0[2 * j + 1], c1[2 * j], c1[2 * j + 1]};
+        float best = v[0];
+        int bi = 0;
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+            if (v[t] > best || v[t] != v[t]) { best = v[t]; bi = t; }
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc += v[t];
+        const float avg = acc * 0.25f;
+        sum[j] = best + avg;
+        packed |= (uint32_t)bi << (8 * j);
+        if (out_pos) {
+            float pavg = avg;
+            if (pos_avg_mode == 1) pavg = fmaxf(avg, 0.f);
+            else if (pos_avg_mode == 2) {
+                float pacc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pacc += fmaxf(v[t], 0.f);
+                pavg = pacc * 0.25f;
+            }
+            psum[j] = (relu_max_pos ? fmaxf(best, 0.f) : best) + pavg;
+        }
+    }
+    const size_t o = (size_t)plane * OH * OW4 + q;
+    out[o] = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    if (idx) idx[o] = packed;
+    if (out_pos) out_pos[o] = make_float4(psum[0], psum[1], psum[2], psum[3]);
 }
 
 __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
@@ -876,6 +954,8 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
     const long total = (long)C * SB * HW;
     for (int i = 0; i < chain.n; ++i)
         if (accumulate && chain.s[i].pstore == dst) special = true;   // the float4 kernel reads dst before the chain runs
+    // (a chain with a fan-out -- EW_MAXHALF_OUT behind a pool-pair head -- only exists in the float4 interpreter; the planner creates it
+    // for tensors with HW % 4 == 0 in the schedule that carries no traces and no priors, never accumulating)
     // float4 pieces: whole samples when HW % 4 == 0; otherwise (7x7 maps) pieces of the flat [B*HW] stream row, which is
     // fine as long as nothing needs the sample of a piece (no priors, no stream prefix)
     const bool pieces_ok = (HW % 4) == 0 || (((long)B * HW) % 4 == 0 && !prior && SBa == SB);
@@ -967,6 +1047,17 @@ void launch_maxpool_fwd(const float* in, float* out, uint8_t* idx, int CN, int H
     }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long)CN * OH * OW)), dim3(NT), 0, s, in, out, idx, CN, H, W, OH, OW,
                        k, stride, pad);
+}
+bool pool2_fwd_ok(const float* in, const uint8_t* idx, int CN, int H, int W, int OH, int OW)
+{
+    return W == 2 * OW && H == 2 * OH && (W & 7) == 0 && CN <= 65535 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)idx) & 3) == 0;
+}
+void launch_pool2_fwd(const float* in, float* out_sum, uint8_t* idx, float* out_pos, int CN, int H, int W, int OH, int OW, int relu_max_pos,
+                      int pos_avg_mode, hipStream_t s)
+{
+    const dim3 g((OH * (OW / 4) + NT - 1) / NT, CN);
+    hipLaunchKernelGGL(pool2_fwd_kernel, g, dim3(NT), 0, s, in, reinterpret_cast<float4*>(out_sum), reinterpret_cast<uint32_t*>(idx),
+                       reinterpret_cast<float4*>(out_pos), H, W, OH, OW, relu_max_pos, pos_avg_mode);
 }
 void launch_maxpool_bwd(const float* gout, const uint8_t* idx, float* gin, int accumulate, int C, int SB, int B, int H, int W,
                         int OH, int OW, int k, int stride, int pad, hipStream_t s)

@@ -200,6 +200,7 @@ struct xfr_engine {
     bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue (STORE raw, [FORK positive
                                        // BatchNorm], affine, clamp).  Round 3, MI355X: +0.6 % maps/s on ResNet-101, +2.2 % on ResNet-50-128d, bit-identical
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
+    bool fuse_pools = true;            // Light-CNN's maxpool + avgpool pair: one forward kernel (xfr_engine_set_epilogue_fusion bit 0 switches it with the rest)
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
                                        // (both: xfr_engine_set_epilogue_fusion; DESIGN.md section 6 has the measurements)
     int last_trace_firings = 0, last_trace_sb = 0;
@@ -776,6 +777,42 @@ bool fuse_mfm_forward(xfr_engine* e, int k, int B, bool keep_raw, ConvParams& p)
     return true;
 }
 
+// lightcnn.py:252: `pool = MaxPool2d(2)(x) + AvgPool2d(2)(x)` -- MAXPOOL(k), AVGPOOL(k+1) on the same x, G_ADD(k+2) of the two, nobody else
+// reading the pools' outputs: one pass over x writes the sum, the argmax bytes and (if the consumer's hook divides by it) the positive-pass sum,
+// instead of max-pool, average pool (twice with the positive pass) and two adds.  Bit-identical (pool2_fwd_kernel).  false: nothing was launched.
+bool fuse_pool2_forward(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
+{
+    if (!e->fuse_pools || k + 2 > e->fwd_last_op || k + 2 >= (int)e->ops.size()) return false;
+    const xfr_op_desc& dm = e->ops[k].d;
+    const xfr_op_desc& da = e->ops[k + 1].d;
+    const xfr_op_desc& dd = e->ops[k + 2].d;
+    if (da.kind != XFR_OP_AVGPOOL || dd.kind != XFR_OP_G_ADD || da.in0 != dm.in0) return false;
+    if (!((dd.in0 == dm.out && dd.in1 == da.out) || (dd.in0 == da.out && dd.in1 == dm.out))) return false;
+    if (dm.kh != 2 || dm.kw != 2 || dm.stride != 2 || dm.pad != 0 || da.kh != 2 || da.kw != 2 || da.stride != 2) return false;
+    const Tensor& x = e->tens[dm.in0];
+    const Tensor& tm = e->tens[dm.out];
+    const Tensor& ta = e->tens[da.out];
+    const Tensor& ts = e->tens[dd.out];
+    if (tm.consumers.size() != 1 || ta.consumers.size() != 1 || ta.alias >= 0 || tm.need_pv) return false;
+    uint8_t* idx = e->t_bank ? nullptr : e->idx_base() + e->ops[k].idx_off;
+    if (!pool2_fwd_ok(e->T(dm.in0), idx, x.C * B, x.H, x.W, tm.H, tm.W)) return false;
+    float* pos = nullptr;
+    int relu_max = 0, avg_mode = 0;
+    if (want_pos && ts.need_pv) {
+        if (tm.pstate == PS_OTHER) return false;
+        relu_max = tm.pstate == PS_RELU ? 1 : 0;
+        avg_mode = ta.pstate == PS_EQ ? 0 : (ta.pstate == PS_RELU ? 1 : 2);
+        if (avg_mode == 2 && x.nonneg) avg_mode = 0;          // the positive average pool clamps its input only where it is signed (pos_op)
+        pos = e->Pv(dd.out);
+    }
+    launch_pool2_fwd(e->T(dm.in0), e->T(dd.out), idx, pos, x.C * B, x.H, x.W, tm.H, tm.W, relu_max, avg_mode, s);
+    e->fwd_done[k + 1] = 1;
+    e->fwd_done[k + 2] = 1;
+    e->pos_done[k + 1] = 1;
+    e->pos_done[k + 2] = 1;
+    return true;
+}
+
 // forward of op k on true values (and, for "dual" convolutions, the positive output in the same launch)
 xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
 {
@@ -818,6 +855,7 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
             launch_relu(e->T(d.in0), e->T(d.out), n_in, s);
             return XFR_OK;
         case XFR_OP_MAXPOOL:
+            if (fuse_pool2_forward(e, k, B, want_pos, s)) return XFR_OK;
             launch_maxpool_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->idx_base() + o.idx_off, a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, d.pad, s);
             return XFR_OK;
         case XFR_OP_AVGPOOL:
@@ -1189,6 +1227,44 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
         }
         st.swap(out);
     }
+    // ---- 1b. pool pair (lightcnn.py:252: maxpool(x) + avgpool(x), both 2x2 / 2 on the same x).  AVGPOOL_BWD(S -> D), accumulating
+    // MAXPOOL_BWD(S -> D) and the in-place hook chain of D (the two pools' tensor hooks on the accumulated gradient) become ONE chain launch
+    // whose head (EW_POOL2_IN) builds the summed gradient of a pixel from its window's gradient and argmax byte: D is written once
+    // instead of written, read-modified twice and read again (13 -> 9.3 tensor passes per pooling stage with the expanding chain behind it).
+    for (size_t i = 0; e->fuse_pools && i + 1 < st.size(); ++i) {
+        const BwdStep av = st[i], mx = st[i + 1];
+        if (av.kind != ST_AVGPOOL_BWD || mx.kind != ST_MAXPOOL_BWD || av.accumulate || !mx.accumulate) continue;
+        if (av.src_t != mx.src_t || av.dst_t != mx.dst_t || av.dst_t < 0) continue;
+        const xfr_op_desc& da = e->ops[av.op].d;
+        const xfr_op_desc& dm = e->ops[mx.op].d;
+        const Tensor& x = e->tens[av.dst_t];
+        const Tensor& y = e->tens[dm.out];
+        if (da.in0 != av.dst_t || dm.in0 != av.dst_t || da.kh != 2 || da.kw != 2 || da.stride != 2 || dm.kh != 2 || dm.kw != 2 || dm.stride != 2 || dm.pad != 0)
+            continue;
+        if ((x.W & 3) != 0 || (x.H & 1) != 0 || y.H * 2 != x.H || y.W * 2 != x.W || (e->ops[mx.op].idx_off & 3) != 0) continue;
+        BwdStep f;
+        f.kind = ST_EW;
+        f.src_t = av.src_t;
+        f.dst_t = av.dst_t;
+        f.ew_t = av.dst_t;
+        f.accumulate = 0;
+        Sym h = mk(EW_POOL2_IN, -1);
+        h.op = mx.op;
+        h.action = x.W;
+        f.chain.push_back(h);
+        size_t drop = 1;
+        if (i + 2 < st.size()) {
+            const BwdStep& c = st[i + 2];
+            const bool headless = c.chain.empty() || (c.chain[0].type != EW_MAXHALF_IN && c.chain[0].type != EW_POOL2_IN);
+            if (c.kind == ST_EW && c.src_t == av.dst_t && c.dst_t == av.dst_t && !c.accumulate && c.ew_t == av.dst_t && headless &&
+                c.chain.size() + 1 <= XFR_MAX_EW_STEPS) {
+                f.chain.insert(f.chain.end(), c.chain.begin(), c.chain.end());
+                drop = 2;
+            }
+        }
+        st[i] = f;
+        st.erase(st.begin() + i + 1, st.begin() + i + 1 + drop);
+    }
     // ---- 2 + 3, to a fixed point: first among the chain launches only (plan.fused: the schedule of the sweeps that carry
     // priors / captures), then with the backward GEMMs as heads of chains too (plan.fused_gemm)
     // pass 2: additionally the MaxFeatureMap VJP as a fan-out in the epilogue of the GEMM that produces its gradient
@@ -1224,7 +1300,9 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             if (c.kind != ST_EW || c.src_t != b_t || (writes(c, b_t) && !inplace && !restores)) continue;
             // fan-out: GEMM (-> Co channels) followed by the chain whose head is the MaxFeatureMap VJP (over 2 * Co channels)
             bool fan = false;
-            if (pass == 2 && a_conv && !c.chain.empty() && c.chain[0].type == EW_MAXHALF_IN && e->tens[c.ew_t].C == 2 * e->tens[b_t].C &&
+            // ... or behind the chain launch whose head is the pool pair's VJP (1b): the Co-channel gradient between them never reaches HBM
+            const bool a_pool = a_ew && !a.chain.empty() && a.chain[0].type == EW_POOL2_IN && !a.accumulate;
+            if (pass == 2 && (a_conv || a_pool) && !c.chain.empty() && c.chain[0].type == EW_MAXHALF_IN && e->tens[c.ew_t].C == 2 * e->tens[b_t].C &&
                 e->tens[c.ew_t].HW() == e->tens[b_t].HW() && (e->tens[b_t].HW() & 3) == 0) {
                 fan = true;
                 for (const Sym& y : a.chain) if (y.type == EW_MAXHALF_OUT) fan = false;
@@ -1343,6 +1421,7 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
                 break;
             case EW_MASK: q.p0 = e->T(sy.t0); break;
             case EW_MAXHALF_IN: q.p0 = e->T(sy.t0); break;
+            case EW_POOL2_IN: q.p0 = reinterpret_cast<const float*>(e->idx_base() + e->ops[sy.op].idx_off); break;      // the max-pool's argmax bytes
             case EW_MAXHALF_OUT: q.p0 = e->T(sy.t0); break;
             case EW_SCALE_C: q.p0 = e->arena + (plain ? e->ops[sy.op].bn_alpha_t : e->ops[sy.op].bn_alpha_p); break;
             case EW_STORE: q.pstore = e->G(sy.t0); break;
@@ -1960,6 +2039,11 @@ xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
     e->fuse_fwd_only = (enable & 1) != 0;
     e->fuse_probe_fwd = (enable & 2) != 0 && (enable & 4) == 0;     // a dual launch needs the compiled epilogue
     e->interpret_chains = (enable & 4) != 0;
+    // bit 3 (tests): the max-pool + average-pool pair of Light-CNN keeps its separate forward kernels and VJP launches.  The backward
+    // schedules are built with or without the pair's chain head: drop the cached ones when the switch moves.
+    const bool pools = (enable & 1) != 0 && (enable & 8) == 0;
+    if (pools != e->fuse_pools) e->plans.clear();
+    e->fuse_pools = pools;
     e->held_x = nullptr;
     return XFR_OK;
 }

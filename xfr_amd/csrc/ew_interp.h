@@ -18,23 +18,30 @@ __device__ __forceinline__ float4 pick_slot(float4 v0, float4 v1, float4 v2, flo
                        pick1(v0.z, v1.z, v2.z, v3.z, slot), pick1(v0.w, v1.w, v2.w, v3.w, slot));
 }
 
+// chain head EW_POOL2_IN: gradient of pixel (row parity ph, column parity pw) of a 2x2 window whose summed max-pool + average-pool output has
+// gradient go and whose argmax byte is id: the average pool's share (0.f + go) * 0.25f plus the max pool's (all of go to the argmax)
+__device__ __forceinline__ float ew_pool2_route(float go, int id, int ph, int pw)
+{
+    return (id == ph * 2 + pw ? go : 0.f) + go * 0.25f;
+}
+
 // VJP of max(a, b) for the half that holds `own`: all of g to the larger input, half of it on ties (at::maximum backward)
 __device__ __forceinline__ float ew_maxhalf_route(float g, float own, float other)
 {
     return own == other ? g * 0.5f : (own > other ? g : 0.f);
 }
 
+// steps [i0, n) of a chain on one float4 piece; returns the index of an EW_MAXHALF_OUT step it stopped at (the fan-out: the caller routes the
+// gradient to the two halves and runs the rest per half), or n
 template <bool PRIOR>
-__device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int sb, int el0, float4 gv, float4 od, float4 v0, float4 v1,
-                                             float4 v2, float4 v3, float4* __restrict__ dst,
-                                             int accumulate, const EwChain& ch, int c, float eps)
+__device__ __forceinline__ int ew_steps(int i0, float (&g)[4], long idx, long aidx, int sb, int el0, float4 v0, float4 v1, float4 v2, float4 v3,
+                                        const EwChain& ch, int c, float eps)
 {
-    if (!ok) return;
-    float g[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll 1
-    for (int i = 0; i < ch.n; ++i) {
+    for (int i = i0; i < ch.n; ++i) {
         const EwStep& st = ch.s[i];
         const int s0 = st.ls0, s1 = st.ls1;
+        if (st.type == EW_MAXHALF_OUT) return i;
         if (st.type == EW_HOOK) {
             if (s0 == -2) {          // p is not observed: the hook is relu(g) or the identity
                 if (st.action == HOOK_RELU) {
@@ -123,8 +130,8 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int s
         } else if (st.type == EW_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
-        } else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_MAXHALF_OUT) {
-            // MAXHALF_IN was applied where the gradient was loaded (ew_maxhalf_route); MAXPAIR only exists in compiled epilogues
+        } else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_POOL2_IN) {
+            // MAXHALF_IN / POOL2_IN were applied where the gradient was loaded; MAXPAIR only exists in compiled epilogues
         } else {
             const float al = st.p0[c], be = st.p1[c];
             reinterpret_cast<float4*>(st.pstore)[idx] =
@@ -132,8 +139,39 @@ __device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int s
                             __fadd_rn(__fmul_rn(fmaxf(g[2], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[3], 0.f), al), be));
         }
     }
+    return ch.n;
+}
+
+// per_c4 / per_ca4: row strides (in float4 pieces) of the gradient tensors and of the forward-side tensors -- only the fan-out needs them
+template <bool PRIOR>
+__device__ __forceinline__ void ew_interpret(bool ok, long idx, long aidx, int sb, int el0, float4 gv, float4 od, float4 v0, float4 v1,
+                                             float4 v2, float4 v3, float4* __restrict__ dst,
+                                             int accumulate, const EwChain& ch, int c, float eps, long per_c4 = 0, long per_ca4 = 0)
+{
+    if (!ok) return;
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    const int fan = ew_steps<PRIOR>(0, g, idx, aidx, sb, el0, v0, v1, v2, v3, ch, c, eps);
+    if (fan < ch.n) {
+        // EW_MAXHALF_OUT (the VJP of torch.max(split[0], split[1]) as a fan-out, like the compiled GEMM epilogue's): the chain so far ran over
+        // the Co-channel tensor; both halves h route g by the true forward halves, run the REST of the chain as channel c + h * Co of the
+        // 2 * Co-channel tensor (operands in place at that channel: ew_plan_loads) and store there.  The launcher excludes accumulate.
+        const EwStep& st = ch.s[fan];
+        const int Co = st.action;
+        const float4* tin = reinterpret_cast<const float4*>(st.p0);
+        const float4 ta = tin[aidx], tb = tin[aidx + (long)Co * per_ca4];
+        const float av[4] = {ta.x, ta.y, ta.z, ta.w}, bv[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float gh[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gh[q] = ew_maxhalf_route(g[q], h ? bv[q] : av[q], h ? av[q] : bv[q]);
+            const long i4 = idx + (long)(h * Co) * per_c4, a4 = aidx + (long)(h * Co) * per_ca4;
+            ew_steps<PRIOR>(fan + 1, gh, i4, a4, sb, el0, v0, v1, v2, v3, ch, c + h * Co, eps);
+            dst[i4] = make_float4(gh[0], gh[1], gh[2], gh[3]);
+        }
+        return;
+    }
     float4 o = make_float4(g[0], g[1], g[2], g[3]);
     if (accumulate) { o.x += od.x; o.y += od.y; o.z += od.z; o.w += od.w; }
     dst[idx] = o;
 }
-
