@@ -233,7 +233,8 @@ xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
  * launches then contain convolution work only, which is what one wants when profiling the MFMA kernel by itself).
  * Light-CNN's pooling stages (lightcnn.py:252, MaxPool2d(2)(x) + AvgPool2d(2)(x)) run as one forward kernel (sum, argmax bytes, positive-pass
  * sum) and their two VJPs as the head of the hook chain that follows them (EW_POOL2_IN) whenever bit 0 is set; bit 3 (tests) keeps the
- * separate kernels / launches: bit-identical either way (round 4). */
+ * separate kernels / launches: bit-identical either way (round 4).  Light-CNN's first layer (one input channel, 5x5, MaxFeatureMap) runs as a
+ * direct convolution in the GEMM's K order unless bit 4 (tests) is set. */
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable);
 
 /* Share one forward pass between consecutive calls on the same input (off by default).  While hold = 1, a run call

@@ -32,6 +32,10 @@ enum {
     EW_MAXHALF_OUT = 11,// compiled GEMM epilogue only: the same VJP as a FAN-OUT in the epilogue of the GEMM that produces the Co-channel
                       // gradient: for both halves h the routed gradient runs the REST of the chain as channel c + h*Co of the 2*Co-channel
                       // tensor (operands loaded in place at that channel) and is stored there; p0 = true forward halves, action = Co
+    EW_ADDP_CO = 13,  // compiled GEMM epilogue only, behind EW_MAXPAIR: g += p0[channel c of the Co-channel tensor] -- the residual add of a Light-CNN
+                      // resblock (lightcnn.py:88) on the pair maximum; the even rows then store the SUM
+    EW_FORK_POSADD = 14, // ... and, in front of it: pstore[c of Co] = (action & 1 ? relu(g) : g) + (action & 2 ? relu(p0) : p0) -- the Add module's
+                      // positive-pass output (its inputs are overridden by A = relu(true input), whitebox.py:315-330); g unchanged
     EW_POOL2_IN = 12, // chain HEAD only (stand-alone kernels): the VJPs of MaxPool2d(2) and AvgPool2d(2) on the SAME input, summed (lightcnn.py:252:
                       // `maxpool(x) + avgpool(x)`).  The chain runs over the pools' input tensor [C][SB][H][W]; the source gradient is the gradient of
                       // the sum, [C][SB][H/2][W/2]: g = 0.25 * src[window] + (argmax[window] == this pixel ? src[window] : 0) -- what AVGPOOL_BWD
@@ -148,7 +152,7 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld, int fwd_sl
 // chains outside the table run through the interpreter).  Code = op | s0 << 4 | s1 << 7 | store << 10 | step << 11 with
 // s0 / s1 the prefetch slot of p0 / p1 (0..3), 4 = load in place, 7 = none (a hook whose x is its a).
 enum { SIG_END = 0, SIG_HOOK_DIV = 1, SIG_HOOK_RELU = 2, SIG_HOOK_PASS = 3, SIG_RELU = 4, SIG_MASK = 5, SIG_SCALE_C = 6, SIG_SCALE = 7,
-       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11, SIG_MAXPAIR = 12, SIG_MAXHALF_OUT = 13 };
+       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11, SIG_MAXPAIR = 12, SIG_MAXHALF_OUT = 13, SIG_ADDP_CO = 14, SIG_FORK_POSADD = 15 };
 constexpr int sig_op(unsigned c) { return (int)(c & 15u); }
 constexpr int sig_s0(unsigned c) { return (int)((c >> 4) & 7u); }
 constexpr int sig_s1(unsigned c) { return (int)((c >> 7) & 7u); }
@@ -188,6 +192,8 @@ inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
             case EW_FORK_POSBN: op = SIG_FORK_POSBN; break;
             case EW_MAXPAIR: op = SIG_MAXPAIR; break;
             case EW_MAXHALF_OUT: op = SIG_MAXHALF_OUT; break;
+            case EW_ADDP_CO: op = SIG_ADDP_CO; break;
+            case EW_FORK_POSADD: op = SIG_FORK_POSADD; s0 = (unsigned)(st.action & 3); break;      // the two clamp flags are part of the signature
             default: return -1;
         }
         codes[n++] = (uint16_t)(op | (s0 << 4) | (s1 << 7) | (store << 10) | ((unsigned)i << 11));
@@ -291,6 +297,10 @@ void launch_maxpool_fwd(const float* in, float* out, uint8_t* idx, int CN, int H
 // out_sum = maxpool2x2(in) + avgpool2x2(in), idx = the max-pool's argmax bytes (may be null), out_pos (may be null) = the positive-pass sum
 // (relu_max_pos ? relu(max) : max) + (pos_avg_mode 0: avg, 1: relu(avg), 2: avgpool(relu(in))); bit-identical to the three separate kernels
 bool pool2_fwd_ok(const float* in, const uint8_t* idx, int CN, int H, int W, int OH, int OW);
+// 5x5 / stride 1 / pad 2 convolution of a one-channel image with MaxFeatureMap, as a direct convolution reading the GEMM's weight pack (rows
+// interleaved: 2c = channel c, 2c + 1 = channel c + Co); raw (may be null) [2 Co][NB][H][W], omax [Co][NB][H][W]; bit-identical to the GEMM path
+bool stem5_mfm_ok(const float* in, int NB, int H, int W);
+void launch_stem5_mfm(const float* in, const float* wp, int ldw, const float* bias, float* raw, float* omax, int Co, int NB, int H, int W, hipStream_t s);
 void launch_pool2_fwd(const float* in, float* out_sum, uint8_t* idx, float* out_pos, int CN, int H, int W, int OH, int OW, int relu_max_pos,
                       int pos_avg_mode, hipStream_t s);
 // gin (+)= scatter of gout through the stored argmax; gradient batch SB vs forward batch B

@@ -97,6 +97,7 @@ __device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& 
             float4 w = *reinterpret_cast<const float4*>(tile + (cl ^ 1) * LD + mq);
             if (bsel && ok[hf]) { const float b = bsel[cos[hf] ^ 1]; w.x += b; w.y += b; w.z += b; w.w += b; }
             ops[hf].partner = w;
+            ops[hf].co_idx4 = (cos[hf] & 1) ? ~0u : (unsigned)(cos[hf] >> 1) * row4 + (unsigned)mm / 4u;
         }
         if constexpr (sig_has_fanout<SIG>()) { ops[hf].out4 = out4; ops[hf].row4 = row4; ops[hf].arow4 = arow4; }
         if (ok[hf]) {

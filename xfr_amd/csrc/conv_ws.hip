@@ -228,6 +228,7 @@ __device__ __forceinline__ void ws_chain_piece(const ConvParams& p, const WsPiec
     if constexpr (sig_has_maxpair<SIG>()) {
         if (p.bias) { const float b = p.bias[q.co ^ 1]; partner.x += b; partner.y += b; partner.z += b; partner.w += b; }
         ops.partner = partner;
+        ops.co_idx4 = (q.co & 1) ? ~0u : (unsigned)(q.co >> 1) * row4 + mm4;
     }
     if constexpr (sig_has_fanout<SIG>()) { ops.out4 = out4; ops.row4 = row4; ops.arow4 = arow4; }
     epi_steps<SIG, 0>(g, ops, p.chain, q.idx4, q.aidx4, p.chain_eps);

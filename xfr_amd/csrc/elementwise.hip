@@ -1048,9 +1048,77 @@ void launch_maxpool_fwd(const float* in, float* out, uint8_t* idx, int CN, int H
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long)CN * OH * OW)), dim3(NT), 0, s, in, out, idx, CN, H, W, OH, OW,
                        k, stride, pad);
 }
+// ---- Light-CNN's first layer as a direct convolution (lightcnn.py:249: mfm(1, 48, 5, 1, 2)) --------------------------------------------------
+// One input channel, K = 25: as an implicit GEMM the layer is all prologue and epilogue (a 64x64 tile holds 16 MFMAs per wave; round 3: 653 us for
+// 10 GFLOP where its 1.2 GB of output need ~250 us).  Here a thread owns four consecutive pixels, keeps their 5 x 8 input patch in registers and
+// walks the channel PAIRS of the MaxFeatureMap: 25 fused multiply-adds per output in the GEMM's K order (k = dh * 5 + dw, accumulator from 0, then
+// the bias) -- v_mfma_f32_32x32x2_f32 is an fmaf chain, so the bits are the GEMM's -- with the pair's weights as scalar operands; it stores the raw
+// rows where the Split hook and the VJP expect them (keep_raw) and max(row, partner) like the EW_MAXPAIR epilogue (NaN propagates).  Weights and bias
+// are read from the GEMM's own pack: wp[k * ldw + r], row r = 2c + half (channel c + half * Co).
+__global__ __launch_bounds__(NT) void stem5_mfm_kernel(const float* __restrict__ in, const float* __restrict__ wp, int ldw, const float* __restrict__ bias,
+                                                      float* __restrict__ raw, float* __restrict__ omax, int Co, int NB, int H, int W)
+{
+    const int n = blockIdx.y;
+    const int W4 = W >> 2;
+    const int q = blockIdx.x * NT + threadIdx.x;
+    if (q >= H * W4) return;
+    const int h = q / W4, w0 = (q - h * W4) * 4;
+    const float* __restrict__ img = in + (size_t)n * H * W;
+    float x[5][8];                                   // x[dh][j] = pixel (h + dh - 2, w0 - 2 + j), 0 outside the image (padding 2)
+#pragma unroll
+    for (int dh = 0; dh < 5; ++dh) {
+        const int ih = h + dh - 2;
+        const bool rok = (unsigned)ih < (unsigned)H;
+        const float* row = img + (size_t)(rok ? ih : 0) * W + w0;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 l = (rok && w0 > 0) ? *reinterpret_cast<const float4*>(row - 4) : z;
+        const float4 m = rok ? *reinterpret_cast<const float4*>(row) : z;
+        const float4 r = (rok && w0 + 4 < W) ? *reinterpret_cast<const float4*>(row + 4) : z;
+        x[dh][0] = l.z; x[dh][1] = l.w; x[dh][2] = m.x; x[dh][3] = m.y; x[dh][4] = m.z; x[dh][5] = m.w; x[dh][6] = r.x; x[dh][7] = r.y;
+    }
+    const size_t plane = (size_t)H * W;
+    const size_t pix = (size_t)n * plane + (size_t)h * W + w0;
+#pragma unroll 1
+    for (int c = 0; c < Co; ++c) {
+        float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dh = 0; dh < 5; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 5; ++dw) {
+                const float wl = wp[(size_t)(dh * 5 + dw) * ldw + 2 * c], wh = wp[(size_t)(dh * 5 + dw) * ldw + 2 * c + 1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lo[j] = __builtin_fmaf(wl, x[dh][j + dw], lo[j]);
+                    hi[j] = __builtin_fmaf(wh, x[dh][j + dw], hi[j]);
+                }
+            }
+        if (bias) {
+            const float bl = bias[2 * c], bh = bias[2 * c + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { lo[j] += bl; hi[j] += bh; }
+        }
+        if (raw) {
+            *reinterpret_cast<float4*>(raw + (size_t)c * NB * plane + pix) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+            *reinterpret_cast<float4*>(raw + (size_t)(c + Co) * NB * plane + pix) = make_float4(hi[0], hi[1], hi[2], hi[3]);
+        }
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = (lo[j] != lo[j]) ? lo[j] : ((hi[j] != hi[j]) ? hi[j] : fmaxf(lo[j], hi[j]));
+        *reinterpret_cast<float4*>(omax + (size_t)c * NB * plane + pix) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
 bool pool2_fwd_ok(const float* in, const uint8_t* idx, int CN, int H, int W, int OH, int OW)
 {
     return W == 2 * OW && H == 2 * OH && (W & 7) == 0 && CN <= 65535 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)idx) & 3) == 0;
+}
+bool stem5_mfm_ok(const float* in, int NB, int H, int W)
+{
+    return (W & 3) == 0 && NB <= 65535 && (((uintptr_t)in) & 15) == 0;
+}
+void launch_stem5_mfm(const float* in, const float* wp, int ldw, const float* bias, float* raw, float* omax, int Co, int NB, int H, int W, hipStream_t s)
+{
+    hipLaunchKernelGGL(stem5_mfm_kernel, dim3((H * (W / 4) + NT - 1) / NT, NB), dim3(NT), 0, s, in, wp, ldw, bias, raw, omax, Co, NB, H, W);
 }
 void launch_pool2_fwd(const float* in, float* out_sum, uint8_t* idx, float* out_pos, int CN, int H, int W, int OH, int OW, int relu_max_pos,
                       int pos_avg_mode, hipStream_t s)

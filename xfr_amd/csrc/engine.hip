@@ -200,6 +200,7 @@ struct xfr_engine {
     bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue (STORE raw, [FORK positive
                                        // BatchNorm], affine, clamp).  Round 3, MI355X: +0.6 % maps/s on ResNet-101, +2.2 % on ResNet-50-128d, bit-identical
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
+    bool direct_stem = true;           // Light-CNN's 1-channel 5x5 first layer as a direct convolution (xfr_engine_set_epilogue_fusion bit 4 clear; tests set it)
     bool fuse_pools = true;            // Light-CNN's maxpool + avgpool pair: one forward kernel (xfr_engine_set_epilogue_fusion bit 0 switches it with the rest)
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
                                        // (both: xfr_engine_set_epilogue_fusion; DESIGN.md section 6 has the measurements)
@@ -762,6 +763,32 @@ bool fuse_mfm_forward(xfr_engine* e, int k, int B, bool keep_raw, ConvParams& p)
     if (keep_raw) push(EW_STORE).pstore = e->T(o.d.out);
     push(EW_MAXPAIR);
     float* dst = e->T(e->ops[o.pair_max].d.out);
+    // The resblock's Add (lightcnn.py:88: out = mfm(mfm(x)) + x) behind the pair maximum: nobody else reads the maximum (the Add hooks take their
+    // (a, x) from the LAST input, the residual), so the even rows store the sum -- and, where a hook divides by it, the Add's positive-pass output
+    // relu(max) + relu(residual) -- instead of the maximum; the add2 launches (true and positive) go away.
+    int k3 = -1;
+    {
+        const int tmax = e->ops[o.pair_max].d.out;
+        const Tensor& tm = e->tens[tmax];
+        if (e->fuse_pools && tm.consumers.size() == 1 && !e->is_hook_a[tmax] && !tm.need_pv) {
+            const int kc = tm.consumers[0];
+            const OpRec& ad = e->ops[kc];
+            const int other = ad.d.in0 == tmax ? ad.d.in1 : ad.d.in0;
+            if (kc <= e->fwd_last_op && ad.d.kind == XFR_OP_ADD && !ad.fuse_relu && other != tmax && e->tens[other].producer < k &&
+                e->tens[other].alias < 0) {
+                if (keep_raw && e->tens[ad.d.out].need_pv) {
+                    EwStep& q = push(EW_FORK_POSADD);
+                    q.p0 = e->T(other);
+                    q.pstore = e->Pv(ad.d.out);
+                    // pos_op: relu on an input unless it is provably >= 0; bit 0 = the maximum, bit 1 = the residual
+                    q.action = (tm.nonneg ? 0 : 1) | (e->tens[other].nonneg ? 0 : 2);
+                }
+                push(EW_ADDP_CO).p0 = e->T(other);
+                dst = e->T(ad.d.out);
+                k3 = kc;
+            }
+        }
+    }
     {
         EwChain probe = ch;
         EwLoads ld;
@@ -774,6 +801,7 @@ bool fuse_mfm_forward(xfr_engine* e, int k, int B, bool keep_raw, ConvParams& p)
     p.chain_eps = e->eps;
     e->fwd_done[o.pair_split] = 1;
     e->fwd_done[o.pair_max] = 1;
+    if (k3 >= 0) { e->fwd_done[k3] = 1; e->pos_done[k3] = 1; }
     return true;
 }
 
@@ -841,6 +869,14 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
                 p.out1 = e->Pv(d.out);
                 p.nhalves = 2;
             } else p.nhalves = 1;
+            // Light-CNN's first layer (one input channel, 5x5, MaxFeatureMap): a direct convolution instead of a 25-deep GEMM
+            if (o.pair && e->fuse_fwd_only && e->direct_stem && !dual && !p.relu_in && a.C == 1 && d.kh == 5 && d.kw == 5 && d.stride == 1 && d.pad == 2 &&
+                !o.tap_fwd && !o.tap4_fwd && o.pair_max <= e->fwd_last_op && !e->interpret_chains && stem5_mfm_ok(e->T(d.in0), B, a.H, a.W)) {
+                launch_stem5_mfm(e->T(d.in0), p.w, o.ldw, p.bias, want_pos ? e->T(d.out) : nullptr, e->T(e->ops[o.pair_max].d.out), o.pair, B, a.H, a.W, s);
+                e->fwd_done[o.pair_split] = 1;
+                e->fwd_done[o.pair_max] = 1;
+                return XFR_OK;
+            }
             if (o.pair && e->fuse_fwd_only && !dual && !p.relu_in && fuse_mfm_forward(e, k, B, want_pos, p)) { }
             else if (!want_pos && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p);
             else if (want_pos && e->fuse_probe_fwd && !p.relu_in) fuse_probe_forward(e, k, B, p);
@@ -2044,6 +2080,7 @@ xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
     const bool pools = (enable & 1) != 0 && (enable & 8) == 0;
     if (pools != e->fuse_pools) e->plans.clear();
     e->fuse_pools = pools;
+    e->direct_stem = (enable & 16) == 0;          // bit 4 (tests): the first layer of Light-CNN through the GEMM like every other convolution
     e->held_x = nullptr;
     return XFR_OK;
 }
@@ -2655,6 +2692,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     // forward-only runs (encode / the gallery of a triplet step): Conv -> BatchNorm [-> Add] [-> ReLU] epilogues
     const int last_op = e->tens[seed_tensor].producer;
     e->fwd_done.assign(e->ops.size(), 0);
+    e->pos_done.assign(e->ops.size(), 0);
     e->fwd_last_op = last_op;
     for (int k = 0; k <= last_op; ++k) {
         const xfr_op_desc& d = e->ops[k].d;
