@@ -436,8 +436,13 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
 }
 
 // CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue (p.chain_sig), 2 = interpreted chain epilogue
+// Waves per SIMD the MaxFeatureMap epilogue family (CHAIN 3) is compiled for: 6 (<= 80 registers) spills 8 registers of the epilogue into
+// 36 bytes of scratch, 5 (<= 96) does not.  Round 4 measured both on Light-CNN (profiles/r4/experiments/mfm_launch_bounds.txt).
+#ifndef XFR_MFM_WAVES
+#define XFR_MFM_WAVES 6
+#endif
 template <int TCO, int TM, int BK, int NST, int MODE, bool RELU, int CHAIN>
-__global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : 6)) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
+__global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVES)) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     constexpr int MI = TCO / 64;   // MFMA tiles per wave along co
     constexpr int NJ = TM / 64;    // MFMA tiles per wave along m
