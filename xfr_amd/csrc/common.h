@@ -26,6 +26,8 @@ enum {
     EW_AFFINE_C = 6,  // g = g*p0[c] + p1[c]                        (eval BatchNorm forward)
     EW_RELU = 7,      // g = max(g, 0)
     EW_FORK_POSBN = 8,// pstore[g] = max(g,0)*p0[c] + p1[c]         (positive-pass BatchNorm output, g unchanged)
+                      // with p2 != null: ... + (action & 1 ? relu(p2[g]) : p2[g]) -- the positive-pass output of the functional add behind the BatchNorm
+                      // (resnet50_128.py torch.add(shortcut, 1, bn)), whose other operand is already there; the BatchNorm's own positive output is then not stored
     EW_MAXHALF_IN = 9,// chain HEAD only (stand-alone kernels): the VJP of torch.max(split[0], split[1]) (lightcnn.py:62).  The chain runs
                       // over the 2*Co-channel Split tensor, the source gradient has Co channels: g = src[c % Co], routed by the true
                       // forward halves a = p0[c % Co], b = p0[c % Co + Co] (ties split evenly like at::maximum); action = Co
@@ -54,6 +56,7 @@ struct EwStep {
     const float* p0;
     const float* p1;
     float* pstore;     // HOOK: if non-null, p is stored here (g-index);  STORE / FORK_POSBN: destination
+    const float* p2;   // FORK_POSBN: optional addend (g-index), see above
     double* trace;     // HOOK: if non-null, sum(p) per (stream,sample) is accumulated at trace[sb] (stand-alone kernels only)
     float f;           // SCALE: factor
     // HOOK extras for layerwise EBP (whitebox.py:390-392,406-419): at this firing a gradient row sb (stream * B + sample) may
@@ -189,7 +192,7 @@ inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
             case EW_ADDP: op = SIG_ADDP; s0 = slot(st.ls0); break;
             case EW_AFFINE_C: op = SIG_AFFINE_C; break;
             case EW_RELU: op = SIG_RELU; break;
-            case EW_FORK_POSBN: op = SIG_FORK_POSBN; break;
+            case EW_FORK_POSBN: op = SIG_FORK_POSBN; if (st.p2) { store = 1; s1 = (unsigned)(st.action & 1); } break;     // store bit: with addend; s1: its clamp flag
             case EW_MAXPAIR: op = SIG_MAXPAIR; break;
             case EW_MAXHALF_OUT: op = SIG_MAXHALF_OUT; break;
             case EW_ADDP_CO: op = SIG_ADDP_CO; break;
@@ -218,7 +221,7 @@ struct ConvParams {
     int in_nb, out_nb;  // images per channel row of the input / output tensors (>= NB: a launch may cover a batch prefix)
     unsigned in_bytes;  // byte size of the input tensor (buffer descriptor range; < 2^31)
     int force_cfg;      // 0 = heuristic tile choice, else a configuration id (tuning / tests)
-    int ws_debug;       // tuning only (xfr_debug_conv cfg 10 / 11): 1 = the persistent kernel's epilogue waves store nothing
+    int ws_debug;       // tuning only (xfr_debug_conv cfg 18 / 19): 1 = the persistent kernel's epilogue waves store nothing
     int no_ws;          // 1: never pick the persistent wave-specialised kernel (conv_ws.hip) for this launch
     // tail balancing (conv_gemm.hip): the last tiles % CUs tiles of a small grid are cut along K into tail_s parts
     // each, so that every CU gets the same share of the final round; parts meet in tail_ws, the last arriver reduces.

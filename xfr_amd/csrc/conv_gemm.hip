@@ -387,7 +387,10 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
 #pragma unroll
                             for (int e8 = 0; e8 < 4; ++e8) {
                                 const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
-                                if (ok[e8]) st.pstore[gi[e8]] = __fadd_rn(__fmul_rn(fmaxf(g[e8], 0.f), st.p0[co]), st.p1[co]);
+                                if (!ok[e8]) continue;
+                                float v = __fadd_rn(__fmul_rn(fmaxf(g[e8], 0.f), st.p0[co]), st.p1[co]);
+                                if (st.p2) v = __fadd_rn((st.action & 1) ? fmaxf(st.p2[gi[e8]], 0.f) : st.p2[gi[e8]], v);
+                                st.pstore[gi[e8]] = v;
                             }
                         }
                     }
@@ -1300,9 +1303,9 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     }
     const int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
     // cfg 8 / 9: the persistent wave-specialised kernel (conv_ws.hip) for 1x1 stride-1 layers whose chain, if any, is compiled
-    if ((cfg >= 8 && cfg <= 11) && conv_ws_ok(p)) {
+    if ((cfg == 8 || cfg == 9 || cfg == 18 || cfg == 19) && conv_ws_ok(p)) {
         ConvParams q = p;
-        q.ws_debug = cfg >= 10 ? 1 : 0;
+        q.ws_debug = cfg >= 18 ? 1 : 0;             // 18 / 19 (tuning only): 8 / 9 with epilogue waves that store nothing
         q.tail_q = 0;
         q.tail_s = 1;
         bool ws = true;

@@ -390,6 +390,6 @@ bool conv_ws_ok(const ConvParams& p)
 void launch_conv_ws(const ConvParams& q, int cfg, hipStream_t s)
 {
     const int kind = q.chain.n > 0 ? (chain_sig_is_mfm(q.chain_sig) ? 3 : 1) : 0;
-    if (cfg == 9 || cfg == 11) ws_launch<16, 4>(q, kind, s);
+    if (cfg == 9 || cfg == 19) ws_launch<16, 4>(q, kind, s);
     else ws_launch<16, 3>(q, kind, s);
 }

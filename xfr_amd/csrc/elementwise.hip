@@ -124,7 +124,11 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 else if (st.type == EW_AFFINE_C) g = __fadd_rn(__fmul_rn(g, st.p0[c]), st.p1[c]);
                 else if (st.type == EW_RELU) g = fmaxf(g, 0.f);
                 else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_MAXHALF_OUT || st.type == EW_POOL2_IN) { }      // applied at the load / compiled epilogues only
-                else st.pstore[idx] = __fadd_rn(__fmul_rn(fmaxf(g, 0.f), st.p0[c]), st.p1[c]);
+                else {
+                    float v = __fadd_rn(__fmul_rn(fmaxf(g, 0.f), st.p0[c]), st.p1[c]);
+                    if (st.p2) v = __fadd_rn((st.action & 1) ? fmaxf(st.p2[idx], 0.f) : st.p2[idx], v);
+                    st.pstore[idx] = v;
+                }
             }
         }
         if (ok) {

@@ -696,7 +696,9 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
     ch.n = 0;
     auto push = [&](int type) -> EwStep& { EwStep& q = ch.s[ch.n++]; memset(&q, 0, sizeof(q)); q.type = type; q.prior_sb = -1; return q; };
     push(EW_STORE).pstore = e->T(d.out);
+    int fork_at = -1;
     if (e->tens[bn_out].need_pv) {
+        fork_at = ch.n;
         EwStep& q = push(EW_FORK_POSBN);
         q.p0 = e->arena + bn.bn_alpha_p;
         q.p1 = e->arena + (e->with_bias ? bn.bn_beta_pb : bn.bn_beta_p);
@@ -711,7 +713,7 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
     // The residual add behind the BatchNorm joins the chain where the pre-add tensor is nobody's business afterwards: no hook takes its
     // (a, x) from it (the reference's Add hooks both use the LAST input, the residual: whitebox.py:379-381), and the positive pass
     // does not need the sum's inputs (modes that divide by a ReLU input's X compute it from them: then the add keeps its kernel).
-    int final_t = bn_out, k2 = -1;
+    int final_t = bn_out, k2 = -1, pos_add = -1;
     bool fused_add = false;
     if (!bn.fuse_relu && e->tens[bn_out].consumers.size() == 1 && !e->is_hook_a[bn_out]) {
         k2 = e->tens[bn_out].consumers[0];
@@ -724,6 +726,17 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
                 if (ad.fuse_relu) push(EW_RELU);
                 final_t = ad.d.out;
                 fused_add = true;
+                // The FUNCTIONAL add's positive-pass output (resnet50_128.py: torch.add(shortcut, 1, bn); 'norelu' / 'all' divide by it at the ReLU
+                // behind it) is pv(shortcut) + positive BatchNorm: the fork adds the other operand -- already computed -- and stores the SUM; the
+                // BatchNorm's own positive output has no other reader (single consumer, no hook takes its x from it).  One add2 launch per block less.
+                if (e->fuse_pools && fork_at >= 0 && ad.d.kind == XFR_OP_G_ADD && e->tens[ad.d.out].need_pv) {
+                    const Src o2 = pv_src(e, other);
+                    EwStep& q = ch.s[fork_at];
+                    q.p2 = o2.p;
+                    q.action = o2.relu ? 1 : 0;
+                    q.pstore = e->Pv(ad.d.out);
+                    pos_add = k2;
+                }
             }
         }
     }
@@ -746,6 +759,7 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
     p.chain_eps = e->eps;
     e->fwd_done[k1] = 1;
     if (fused_add) e->fwd_done[k2] = 1;
+    if (pos_add >= 0) e->pos_done[pos_add] = 1;
 }
 
 // MaxFeatureMap in the convolution's epilogue (lightcnn.py:48-62: Conv -> Split -> torch.max of the halves).  The forward pack holds

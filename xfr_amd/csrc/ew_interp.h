@@ -134,9 +134,14 @@ __device__ __forceinline__ int ew_steps(int i0, float (&g)[4], long idx, long ai
             // MAXHALF_IN / POOL2_IN were applied where the gradient was loaded; MAXPAIR only exists in compiled epilogues
         } else {
             const float al = st.p0[c], be = st.p1[c];
-            reinterpret_cast<float4*>(st.pstore)[idx] =
-                make_float4(__fadd_rn(__fmul_rn(fmaxf(g[0], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[1], 0.f), al), be),
-                            __fadd_rn(__fmul_rn(fmaxf(g[2], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[3], 0.f), al), be));
+            float4 v = make_float4(__fadd_rn(__fmul_rn(fmaxf(g[0], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[1], 0.f), al), be),
+                                   __fadd_rn(__fmul_rn(fmaxf(g[2], 0.f), al), be), __fadd_rn(__fmul_rn(fmaxf(g[3], 0.f), al), be));
+            if (st.p2) {
+                float4 d = reinterpret_cast<const float4*>(st.p2)[idx];
+                if (st.action & 1) { d.x = fmaxf(d.x, 0.f); d.y = fmaxf(d.y, 0.f); d.z = fmaxf(d.z, 0.f); d.w = fmaxf(d.w, 0.f); }
+                v.x = __fadd_rn(d.x, v.x); v.y = __fadd_rn(d.y, v.y); v.z = __fadd_rn(d.z, v.z); v.w = __fadd_rn(d.w, v.w);
+            }
+            reinterpret_cast<float4*>(st.pstore)[idx] = v;
         }
     }
     return ch.n;
