@@ -259,6 +259,11 @@ xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable);
  * one-tile-per-workgroup kernel it replaces: switching changes no bit (tests/test_gpu_parity.py).  ABI version 3. */
 xfr_status xfr_engine_set_persistent_gemm(xfr_engine* e, int32_t enable);
 
+/* xfr_forward on batches of >= 32 images runs as two half batches on the engine's two internal streams and joins them on the caller's stream
+ * (on by default; enable = 0: one forward on the caller's stream).  Images are independent; a sample's values can differ in the last fp32 bits
+ * from the unsplit run exactly as they do between two batch sizes (tail balancing, see xfr_engine_set_tail_balance).  ABI version 3. */
+xfr_status xfr_engine_set_forward_split(xfr_engine* e, int32_t enable);
+
 /* _mwp_to_saliency (whitebox.py:448-460, ebp_ver 6) on N pooled maps: in N x H x W -> out N x H x W. */
 xfr_status xfr_mwp_to_saliency(xfr_engine* e, const float* pooled_dev, int32_t n, int32_t h, int32_t w,
                                float* sal_dev, void* stream);

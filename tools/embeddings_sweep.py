@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--cells', type=int, default=7, help='RISE grid: cells x cells random mask, bilinearly upsampled')
     ap.add_argument('--parity', type=int, default=8, help='masked probes checked against the CPU oracle (0: skip)')
+    ap.add_argument('--no-split', action='store_true', help='xfr_engine_set_forward_split(0): one forward per batch on the caller\'s stream (round 3)')
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -67,6 +68,8 @@ def main():
         free[k].record(main_s)
     ref = wb.encode(probe)
     wb.encode(bufs[0])                                   # warm-up: engine at this batch size
+    if args.no_split:
+        wb._engine(args.batch).set_forward_split(False)
     picks = {}
     if args.parity:
         rng = np.random.RandomState(1)
@@ -94,7 +97,8 @@ def main():
     dt = time.perf_counter() - t0
     out = {'workload': 'RISE-style embeddings sweep, ResNet-101 224x224, synthetic', 'masks': args.masks, 'batch': args.batch,
            'seconds': dt, 'images_per_s': args.masks / dt, 'forward_TFLOP_per_s': args.masks * 14.419e9 / dt / 1e12,
-           'frac_of_fp32_mfma_peak': args.masks * 14.419e9 / dt / 157.3e12, 'mean_similarity': float(sims.mean())}
+           'frac_of_fp32_mfma_peak': args.masks * 14.419e9 / dt / 157.3e12, 'mean_similarity': float(sims.mean()),
+           'forward_split': not args.no_split}
     if kept:
         from oracle import ebp_oracle as O            # the checker, never the thing measured
         ow = O.OracleWhitebox('stresnet101', sd, ('hooked', None), 'affineonly_with_prior')

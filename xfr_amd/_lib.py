@@ -48,6 +48,7 @@ SYMBOLS = [
     ('xfr_engine_set_inputs_ready', _I, [_P, _I]),
     ('xfr_engine_set_tail_balance', _I, [_P, _I]),
     ('xfr_engine_set_persistent_gemm', _I, [_P, _I]),
+    ('xfr_engine_set_forward_split', _I, [_P, _I]),
     ('xfr_engine_hold_forward', _I, [_P, _I]),
     ('xfr_engine_set_epilogue_fusion', _I, [_P, _I]),
     ('xfr_mwp_to_saliency', _I, [_P, _P, _I, _I, _I, _P, _P]),

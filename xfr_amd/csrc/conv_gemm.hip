@@ -546,10 +546,13 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
             base_m[s] = n * p.H * p.W + (oh * p.stride - p.pad) * p.W + iw0[s];
             unsigned long long mk = 0ull;
             if ((MODE == MODE_TAP || MODE == MODE_TAP4) && m_ok) {
+                // the window is a rectangle: valid columns once (kw tests), then one shifted copy per valid row (kh tests) instead of kh * kw
+                // tests -- the 7x7 stems spent a third of a tile's prologue in this loop
+                unsigned long long vw = 0ull;
+                for (int dw = 0; dw < p.kw; ++dw)
+                    if ((unsigned)(iw0[s] + dw) < (unsigned)p.W) vw |= 1ull << dw;
                 for (int dh = 0; dh < p.kh; ++dh)
-                    for (int dw = 0; dw < p.kw; ++dw)
-                        if ((unsigned)(ih0[s] + dh) < (unsigned)p.H && (unsigned)(iw0[s] + dw) < (unsigned)p.W)
-                            mk |= 1ull << (dh * p.kw + dw);
+                    if ((unsigned)(ih0[s] + dh) < (unsigned)p.H) mk |= vw << (dh * p.kw);
             }
             tapmask[s] = mk;
             voffB[s] = OOB;
@@ -888,9 +891,11 @@ __global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p,
         const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
         base_m = n * p.H * p.W + ih0 * p.W + iw0;
         if (m_ok) {
+            unsigned long long vw = 0ull;
+            for (int dw = 0; dw < p.kw; ++dw)
+                if ((unsigned)(iw0 + dw) < (unsigned)p.W) vw |= 1ull << dw;
             for (int dh = 0; dh < p.kh; ++dh)
-                for (int dw = 0; dw < p.kw; ++dw)
-                    if ((unsigned)(ih0 + dh) < (unsigned)p.H && (unsigned)(iw0 + dw) < (unsigned)p.W) tapmask |= 1ull << (dh * p.kw + dw);
+                if ((unsigned)(ih0 + dh) < (unsigned)p.H) tapmask |= vw << (dh * p.kw);
         }
         voffB[0] = OOB;
     }

@@ -194,6 +194,7 @@ struct xfr_engine {
     TailWs tail_ws[8];
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
+    bool split_forward = true;         // xfr_engine_set_forward_split: forward-only batches of >= 32 images as two halves on the internal streams
     bool persistent_gemm = false;      // xfr_engine_set_persistent_gemm: conv_ws.hip where the launcher's rule selects it (round 4: measured, off by default)
     bool interpret_chains = false;     // xfr_engine_set_epilogue_fusion bit 2: fused chains run through the interpreted epilogue (tests)
     bool planning_only = false;        // xfr_plan_describe: list what the planner WOULD fuse, whatever the signature table holds
@@ -1904,6 +1905,8 @@ xfr_status xfr_engine_tensor_shape(xfr_engine* e, int32_t t, int32_t* c, int32_t
     return XFR_OK;
 }
 
+static xfr_status ensure_streams(xfr_engine* e);
+
 xfr_status xfr_forward(xfr_engine* e, const float* x_dev, int32_t n, int32_t tensor_id, float* out_dev, void* stream)
 {
     xfr_status st = check_run(e, x_dev, n);
@@ -1911,6 +1914,38 @@ xfr_status xfr_forward(xfr_engine* e, const float* x_dev, int32_t n, int32_t ten
     if (tensor_id < 1 || tensor_id >= (int)e->tens.size() || !out_dev) return fail(XFR_INVALID_ARG, "bad tensor id / null output");
     hipStream_t s = (hipStream_t)stream;
     prof_begin(e);
+    // A forward-only batch (whitebox.py:747-785 embeddings; blackbox.py:366-414 scores ~6500 masked copies of a probe with it) as two half
+    // batches on the two internal streams, like the gallery / probe pair of a triplet step: a layer's launches of the two halves fill each
+    // other's prologues, epilogues and tails (round 3: one stream reached 0.52 of the fp32 MFMA peak).  The first half runs in the second
+    // activation region (the one the triplet step's gallery forward uses); images are independent, the halves meet on the caller's stream.
+    const int n0 = (n / 2) & ~3;
+    if (e->split_forward && !e->profile_on && !e->hold_forward && n >= 32 && n0 >= 8) {
+        if (!e->ws_enc) HIP_TRY(hipMalloc(&e->ws_enc, (e->t_region_floats + 4096) * sizeof(float)));
+        st = ensure_streams(e);
+        if (st != XFR_OK) return st;
+        const Tensor& t = e->tens[tensor_id];
+        const size_t in_per_n = (size_t)e->in_c * e->in_h * e->in_w;
+        struct BankGuard { xfr_engine* e; ~BankGuard() { e->t_bank = nullptr; } } bank_guard{e};
+        HIP_TRY(hipEventRecord(e->ev_fork, s));          // after everything already on the caller's stream (inputs, earlier sweeps)
+        HIP_TRY(hipStreamWaitEvent(e->s_a, e->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(e->s_b, e->ev_fork, 0));
+        e->t_bank = e->ws_enc;
+        st = forward_all(e, x_dev, n0, tensor_id, false, e->s_a);
+        if (st != XFR_OK) return st;
+        launch_cnhw_to_nchw(e->T(tensor_id), out_dev, n0, t.C, t.HW(), e->s_a);
+        e->t_bank = nullptr;
+        st = forward_all(e, x_dev + (size_t)n0 * in_per_n, n - n0, tensor_id, false, e->s_b);
+        if (st != XFR_OK) return st;
+        launch_cnhw_to_nchw(e->T(tensor_id), out_dev + (size_t)n0 * t.per_n(), n - n0, t.C, t.HW(), e->s_b);
+        HIP_TRY(hipEventRecord(e->ev_a, e->s_a));
+        HIP_TRY(hipEventRecord(e->ev_b, e->s_b));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_a, 0));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_b, 0));
+        HIP_TRY(hipGetLastError());
+        st = fence_slot0(e, s);
+        if (st != XFR_OK) return st;
+        return prof_end(e, s);
+    }
     st = forward_all(e, x_dev, n, tensor_id, false, s);
     if (st != XFR_OK) return st;
     const Tensor& t = e->tens[tensor_id];
@@ -2111,6 +2146,13 @@ xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     e->tail_balance = enable != 0;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_set_forward_split(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->split_forward = enable != 0;
     return XFR_OK;
 }
 

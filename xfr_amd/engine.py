@@ -210,6 +210,11 @@ class Engine(object):
         _lib.check(self.lib.xfr_engine_set_tail_balance(self._h, int(bool(on))))
         self.options['tail_balance'] = bool(on)
 
+    def set_forward_split(self, on):
+        """Forward-only batches of >= 32 images as two half batches on the internal streams (default on; include/xfr_amd.h)."""
+        _lib.check(self.lib.xfr_engine_set_forward_split(self._h, int(bool(on))))
+        self.options['forward_split'] = bool(on)
+
     def set_persistent_gemm(self, on):
         """The persistent wave-specialised kernel for the short-K 1x1 stride-1 layers (default off; include/xfr_amd.h)."""
         _lib.check(self.lib.xfr_engine_set_persistent_gemm(self._h, int(bool(on))))
@@ -219,6 +224,8 @@ class Engine(object):
         """Re-apply switches recorded by another Engine handle (WhiteboxNetwork.engine rebuilds engines that are too small)."""
         if 'tail_balance' in options:
             self.set_tail_balance(options['tail_balance'])
+        if 'forward_split' in options:
+            self.set_forward_split(options['forward_split'])
         if 'persistent_gemm' in options:
             self.set_persistent_gemm(options['persistent_gemm'])
         if 'epilogue_fusion' in options:
