@@ -454,6 +454,7 @@ def main():
     ap.add_argument('--serial', action='store_true', help='run every step on ONE stream with per-GEMM HIP events; use under rocprofv3 so that kernel durations are not inflated by concurrent streams')
     ap.add_argument('--no-pipeline', action='store_true', help='do not overlap step i+1 forwards with step i backward')
     ap.add_argument('--profile-csv', default=None, help='with --serial: append one record per GEMM launch to this file (profiles/layer_table.py)')
+    ap.add_argument('--launch-log-csv', default=None, help='with --serial: after the timed loop, record 3 more steps with the in-kernel launch log on (one stream) and write it here: per-launch durations from the kernels\' own s_memrealtime stamps (profiles/layer_table.py reads it) -- HIP events misread the first GEMM after an idle queue')
     ap.add_argument('--timeline-json', default=None, help='write the launch-log analysis of the timed schedule (roofline.timeline) to this file')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 10 s sustained loop after the timed region')
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
@@ -525,8 +526,11 @@ def main():
         row0 = fixture_cosine(sal[0], W.fixture)
         ok = ok and row0 is not None and row0 >= ROW0_COS
     if args.serial:
-        eng.set_profile(False)
         eng.profile_csv(None)
+        if args.launch_log_csv and rank == 0:
+            from xfr_amd import tuning as _tuning
+            _tuning.record_launch_log(step, 3, dev, args.launch_log_csv)
+        eng.set_profile(False)
     # host cost of enqueueing one step on an EMPTY queue (no back-pressure from a full HIP queue): median of 5
     idle = []
     for _ in range(5):

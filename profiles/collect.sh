@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect one round's rocprofv3 evidence for bench.py on the GPU box (run from the repo root, e.g. through gpurun):
-#   bash profiles/collect.sh r3      -> gpurun_out/prof_r3/..., summaries copied to profiles/r3/
+#   bash profiles/collect.sh r4      -> gpurun_out/prof_r4/..., summaries copied to profiles/r4/
 # Counters are collected in their own passes (--pmc never together with a trace domain other than the kernel trace).
 # Every BASELINE.json single-GPU configuration gets the same set: resnet101 (no suffix), resnet50_128 (_r50), lightcnn (_lcnn).
 set -u
-R=${1:-r3}
+R=${1:-r4}
 D=gpurun_out/prof_$R
 P=profiles/$R
 export TMPDIR=/tmp
@@ -26,10 +26,12 @@ for spec in resnet101: resnet50_128:_r50 lightcnn:_lcnn; do
   python profiles/pmc_summary.py $D/pmc_write$T > $P/pmc_WRITE_SIZE$T.txt
   rm -f $D/pmc_*$T/${R}_counter_collection.csv
   # per-layer GEMM table (HIP events inside the engine, serial schedule)
-  rm -f $D/layers$T.csv; $B --steps 3 --warmup 2 --no-cpu-baseline --serial --no-sustained --no-profile --profile-csv $D/layers$T.csv > /dev/null 2>&1
+  rm -f $D/layers$T.csv $D/launchlog$T.csv; $B --steps 3 --warmup 2 --no-cpu-baseline --serial --no-sustained --no-profile --profile-csv $D/layers$T.csv --launch-log-csv $D/launchlog$T.csv > /dev/null 2>&1
   python profiles/layer_table.py $D/layers$T.csv > $P/gemm_layers_serial$T.txt
+  # the same launches timed by the kernels themselves (first GEMM of a step included correctly)
+  python profiles/layer_table.py $D/launchlog$T.csv > $P/gemm_layers_inkernel$T.txt
   # the plain bench line (timed three-stream schedule, launch-log roofline, clock, CPU baseline) + the timeline it came from
-  $B --timeline-json $P/gemm_timeline$T.json > $P/bench_default$T.json 2> $D/bench_default$T.err
+  $B --no-secondary --timeline-json $P/gemm_timeline$T.json > $P/bench_default$T.json 2> $D/bench_default$T.err
 done
 # the timed schedule under the profiler (rocprofv3 serialises the queues: kernel mix only)
 rocprofv3 $ST -d $D/pipelined -o $R -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-sustained > $P/bench_pipelined_under_rocprof.json 2> $D/pipelined.err
@@ -52,9 +54,12 @@ python tools/clock_probe.py --steps 10 --serial > $P/clock_probe_serial.json 2> 
 python tools/phase_probe.py 2> /dev/null | grep -v amdgpu > $P/phase_probe_timed.txt
 python tools/phase_probe.py --serial 2> /dev/null | grep -v amdgpu > $P/phase_probe_serial.txt
 python tools/pair_probe.py 2> /dev/null | grep -v amdgpu > $P/pair_probe.txt
-for b in 32 64 96; do python bench.py --batch $b --steps 20 --warmup 4 --no-cpu-baseline --no-sustained 2> /dev/null; done > $P/bench_batch_sweep.jsonl
+for b in 32 64 96; do python bench.py --batch $b --steps 20 --warmup 4 --no-cpu-baseline --no-sustained --no-secondary 2> /dev/null; done > $P/bench_batch_sweep.jsonl
 python tools/embeddings_sweep.py --masks 6500 > $P/embeddings_sweep.json 2> /dev/null
-python tools/conv_sweep.py --cfgs 4,5,7 --reps 100 --set r101 2> /dev/null | grep -v amdgpu > $P/conv_sweep.txt
+python tools/embeddings_sweep.py --masks 6500 --no-split > $P/embeddings_sweep_nosplit.json 2> /dev/null
+# the line the driver sees: the default command, secondary configurations and whole-host CPU figure included
+python bench.py > $P/bench_driver_line.json 2> $D/bench_driver_line.err
+python tools/conv_sweep.py --cfgs 4,5,7,9 --reps 100 --set r101 2> /dev/null | grep -v amdgpu > $P/conv_sweep.txt
 python tools/conv_sweep.py --cfgs 4,7 --reps 100 --set lcnn --nb 128 2> /dev/null | grep -v amdgpu >> $P/conv_sweep.txt
 mkdir -p gpurun_out/$P && cp -r $P/. gpurun_out/$P/
 echo "collected: $(ls $P | tr '\n' ' ')"

@@ -97,7 +97,9 @@ def assert_trace_close(sums, names, gsum, gnames, what='', rtol=1e-4):
     not compute)."""
     n = len(sums)
     assert n in (len(gsum), len(gsum) - 1), '%s: %d firings vs %d in the reference' % (what, n, len(gsum))
-    assert list(names) == [str(x) for x in gnames[:n]], '%s: firing order differs' % what
+    # names: class names, or full str(module) strings (Whitebox.P_layername since round 4, image hook included): compare the class names
+    cls = lambda seq: [str(x).split('(')[0] for x in list(seq)[:n]]      # noqa: E731
+    assert cls(names) == cls(gnames), '%s: firing order differs' % what
     err = np.abs(np.asarray(sums) - gsum[:n]) / np.maximum(np.abs(gsum[:n]), 1e-300)
     i = int(err.argmax())
     assert err.max() <= rtol, '%s: P-sum rel err %.3e at firing %d (%s)' % (what, err.max(), i, names[i])

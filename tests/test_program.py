@@ -121,3 +121,28 @@ def test_create_wbnet_defaults_match_reference():
         create_wbnet('senet50', device='cuda:0')
     with pytest.raises(DeprecationWarning):
         create_wbnet('resnetv4_pytorch', device='cuda:0', ebp_version=3)
+
+
+def test_layernames_equal_the_reference_strings():
+    """Whitebox.P_layername (whitebox.py:393: str(module) of the hooked module of every firing, the image hook last): the lists the layer
+    programs produce -- planner firing order (device-free xfr_plan_describe) + torch module reprs -- against the lists the REAL reference
+    produced under this image's torch (tests/golden/make_golden_names.py), all three backbones, hooked and triplet classifier."""
+    import numpy as np
+    import torch
+    from parity_utils import make_backbone
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_layernames.npz"))
+    if str(gold['torch_version']).split('+')[0] != torch.__version__.split('+')[0]:
+        pytest.skip('fixture was generated under torch %s' % gold['torch_version'])
+    seen = 0
+    for arch, ncls in (('stresnet_mini', 5), ('stresnet101', 7), ('resnet50_128', None), ('lightcnn29v2', 7)):
+        bb, _ = make_backbone(arch, seed=1, num_classes=ncls)
+        prog = bb.build_program()
+        for cls, mark in (('hooked', 'classify'), ('triplet', 'encode')):
+            key = arch + '/' + cls
+            if key not in gold.files:
+                continue
+            for mode in ('affineonly_with_prior', 'norelu'):      # the firing order does not depend on the subtree mode
+                assert prog.layernames(mode, prog.marks[mark]) == [str(x) for x in gold[key]], (key, mode)
+            seen += 1
+    assert seen == 7

@@ -115,6 +115,7 @@ struct BwdPlan {
     std::vector<BwdStep> fused_gemm; // ... and with the chains that follow a backward GEMM run in its epilogue
     std::vector<BwdStep> fused_gemm_nofan; // the same without the MaxFeatureMap fan-out (a compiled-only epilogue step): what the interpreted epilogues run
     std::vector<int> firing_kinds;   // xfr_op_kind per firing, reference order
+    std::vector<int> firing_ops;     // hooked module call (op index) per firing: Whitebox.P_layername is str(module) of these (whitebox.py:393)
     int n_firings = 0;
     int fan_ok = -1;                 // does every fan-out epilogue of fused_gemm have a compiled signature (-1: not checked yet; fanout_compiled)
 };
@@ -591,10 +592,9 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
         if (e->ev_params.size() < e->ev_pool.size()) e->ev_params.resize(e->ev_pool.size());
         const int why = conv_gemm_cannot_launch(p);
         if (why) return fail(XFR_STATE_ERROR, "%s", conv_gemm_refusal(why));          // nothing launched: no event pair, no record
-        // The first GEMM of a profiled run: everything enqueued before it (layout conversion, cross-stream waits of the step before)
-        // must have retired, or its start event -- recorded on a stream that is idle at enqueue time -- is stamped early and the launch
-        // is charged its predecessors (round 3: the stems read 0.87 ms in the per-shape table where rocprofv3 saw 0.37).
-        if (e->ev_used == 0) HIP_TRY(hipStreamSynchronize(s));
+        // (HIP events misread the FIRST GEMM of a profiled run -- 0.87 ms for a 0.37 ms stem in round 3, 1.03 ms with a stream synchronise in
+        // front of it in round 4: the start event is stamped on a queue that has just been idle.  The per-shape tables of profiles/ therefore
+        // also come from the kernels' own stamps: bench.py --serial --launch-log-csv, profiles/layer_table.py.)
         e->ev_params[e->ev_used] = p;
         auto& ev = e->ev_pool[e->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, s));
@@ -1054,6 +1054,7 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan, bool plain)
     // firing order (reference): descending producer index, registration order within a tensor; image last
     std::vector<std::vector<int>> slot(nt);
     plan.firing_kinds.clear();
+    plan.firing_ops.clear();
     plan.firing_tensor.clear();
     for (int k = e->tens[seed_tensor].producer; k >= 0; --k) {
         const int t = e->ops[k].d.out;
@@ -1062,6 +1063,7 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan, bool plain)
             if (e->ops[h.op].d.out > seed_tensor) { slot[t].push_back(-1); continue; }   // call beyond the seed
             slot[t].push_back((int)plan.firing_kinds.size());
             plan.firing_kinds.push_back(e->ops[h.op].d.kind);
+            plan.firing_ops.push_back(h.op);
             plan.firing_tensor.push_back(t);
         }
     }
@@ -2745,6 +2747,10 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     snprintf(line, sizeof(line), "plan seed_tensor %d mode %d firings %d launches %zu (unfused %zu)\n", seed_tensor, subtree_mode,
              plan->n_firings, plan->fused_gemm.size(), plan->steps.size());
     out += line;
+    // the hooked module call behind every firing, reference order (the image hook of op 0, which the engine does not compute, comes last there)
+    out += "firing_ops";
+    for (int op : plan->firing_ops) { snprintf(line, sizeof(line), " %d", op); out += line; }
+    out += "\n";
     // forward-only runs (encode / the gallery of a triplet step): Conv -> BatchNorm [-> Add] [-> ReLU] epilogues
     const int last_op = e->tens[seed_tensor].producer;
     e->fwd_done.assign(e->ops.size(), 0);

@@ -56,6 +56,8 @@ class Resnet50_128(Backbone):
         t = p.batchnorm(t, 'conv1_7x7_s2_bn')
         t = p.relu_(t)
         t = p.maxpool(t, 3, 2, 0, ceil_mode=True)               # resnet50_128.py:16
+        # the reference passes lists / tuples to the pools, and torch prints them as given (Whitebox.P_layername is str(module))
+        p.reprs[len(p.ops) - 1] = 'MaxPool2d(kernel_size=[3, 3], stride=[2, 2], padding=(0, 0), dilation=1, ceil_mode=True)'
         for pre, cin, mid, outc, stride, first in self._blocks():
             block_in = t
             o = p.conv(t, pre + '_1x1_reduce', mid, 1, stride=stride, bias=False)
@@ -74,6 +76,7 @@ class Resnet50_128(Backbone):
             t = p.g_add(sc, o)                                   # functional torch.add: resnet50_128.py:187
             t = p.relu_(t)
         t = p.avgpool(t, 7, 1)
+        p.reprs[len(p.ops) - 1] = 'AvgPool2d(kernel_size=[7, 7], stride=[1, 1], padding=0)'
         t = p.conv(t, 'feat_extract', 128, 1, bias=False)
         p.mark('encode', t)                                      # net(x)[0]: whitebox.py:224
         return p

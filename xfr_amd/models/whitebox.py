@@ -220,7 +220,7 @@ class _PList(object):
             eng = self._wb._engine(self._x.shape[0])
             P = eng.ebp_firing(self._x, self._seed_tensor, self._seed, k)
             # the reference flattens before its Linear layers (resnet.py:245, lightcnn.py:258): those entries are N x D
-            if self._wb.P_layername[k] == 'Linear' or (P.shape[2] == 1 and P.shape[3] == 1):
+            if self._wb.P_layername[k].startswith('Linear(') or (P.shape[2] == 1 and P.shape[3] == 1):
                 P = P.reshape(P.shape[0], -1)
             self._cache[k] = P
         return self._cache[k]
@@ -298,6 +298,13 @@ class Whitebox(object):
         out = eng.mwp_to_saliency(t).cpu().numpy()
         return out[0] if squeeze else out
 
+    def _layernames(self, seed_tensor):
+        key = (self._ebp_subtree_mode, int(seed_tensor))
+        cache = self.__dict__.setdefault('_layername_cache', {})
+        if key not in cache:
+            cache[key] = self.net._program.layernames(self._ebp_subtree_mode, seed_tensor)
+        return list(cache[key])
+
     def _clear(self):
         (self.P, self.P_layername, self.dA, self.A, self.X) = ([], [], [], [], [])
         self.net.clear()
@@ -312,13 +319,15 @@ class Whitebox(object):
         if self.debug_trace:
             eng.set_trace(True)
         _, pooled = eng.ebp(x, seed_tensor, seed.unsqueeze(0), want_mwp=False, want_pooled=True)
-        self.P_layername = eng.firing_names(seed_tensor)         # whitebox.py:393 (class names; the image hook has no entry here)
+        # whitebox.py:393: str(module) of the hooked module behind every entry of P, the image hook (P[-1]) last -- built from the layer program
+        # (Program.layernames), identical to the reference's list under the same torch (tests/test_program.py, golden_layernames.npz)
+        self.P_layername = self._layernames(seed_tensor)
         if self.debug_trace:
             sums, names, nf = eng.get_trace()
-            assert names == self.P_layername
+            assert names == [s.split('(')[0] for s in self.P_layername[:nf]]
             self.P_trace = sums[:nf * n].reshape(nf, n).copy()
             eng.set_trace(False)
-        self.P = _PList(self, x, seed_tensor, seed.unsqueeze(0), len(self.P_layername))
+        self.P = _PList(self, x, seed_tensor, seed.unsqueeze(0), len(self.P_layername) - 1)
         P = np.squeeze(pooled[0].cpu().numpy()).astype(np.float32)
         return self._mwp_to_saliency(P) if not mwp else P
 

@@ -54,6 +54,7 @@ class Program(object):
         self.weight_names = []     # weight table: state_dict keys in table order
         self._widx = {}
         self.ntensors = 1
+        self.reprs = {}            # op index -> str(module) override (module_repr)
         self.marks = {}            # named tensors: 'encode', 'classify'
 
     def _w(self, name):
@@ -141,6 +142,60 @@ class Program(object):
         buf = ctypes.create_string_buffer(need.value)
         _lib.check(lib.xfr_plan_describe(*args, buf, need.value, None))
         return buf.value.decode()
+
+    def firing_ops(self, mode, seed_tensor):
+        """Index (into self.ops) of the hooked module call behind every firing of a sweep seeded at `seed_tensor`, in the reference's firing
+        order -- from the planner, no device needed."""
+        for ln in self.describe(mode, seed_tensor, batch=1).splitlines():
+            if ln.startswith('firing_ops'):
+                return [int(v) for v in ln.split()[1:]]
+        raise RuntimeError('xfr_plan_describe printed no firing_ops line')
+
+    def tensor_channels(self):
+        """Channel count of every tensor id (forward shape inference, channels only)."""
+        ch = {0: self.in_shape[0]}
+        for o in self.ops:
+            k = OpKind(o.kind)
+            if k in (OpKind.CONV, OpKind.LINEAR):
+                ch[o.out] = o.cout
+            elif k == OpKind.CONCAT:
+                ch[o.out] = ch[o.in0] * (1 + o.cout)
+            elif k == OpKind.G_MAXHALVES:
+                ch[o.out] = ch[o.in0] // 2
+            else:
+                ch[o.out] = ch[o.in0]
+        return ch
+
+    def module_repr(self, k, ch=None):
+        """str(module) of hooked op k as THIS torch prints it (Whitebox.P_layername, whitebox.py:393): the string is built by instantiating
+        the same torch module on the meta device; the custom modules of the reference (Add, ConcatChannels, Multiply, Split: resnet.py:104-166,
+        lightcnn.py:33-46) define no extra_repr.  A backbone whose reference module was built with other argument forms (resnet50_128's pools take
+        lists) overrides the string in self.reprs[k]."""
+        if k in self.reprs:
+            return self.reprs[k]
+        import torch
+        o = self.ops[k]
+        kind = OpKind(o.kind)
+        ch = ch or self.tensor_channels()
+        with torch.device('meta'):
+            if kind == OpKind.CONV:
+                return str(torch.nn.Conv2d(ch[o.in0], o.cout, o.kh, stride=o.stride, padding=o.pad, bias=o.w_bias >= 0))
+            if kind == OpKind.BATCHNORM:
+                return str(torch.nn.BatchNorm2d(ch[o.in0], eps=float('%.6g' % o.fparam)))
+            if kind == OpKind.RELU:
+                return str(torch.nn.ReLU(inplace=bool(o.inplace)))
+            if kind == OpKind.MAXPOOL:
+                return str(torch.nn.MaxPool2d(o.kh, o.stride, padding=o.pad, ceil_mode=bool(o.ceil_mode)))
+            if kind == OpKind.AVGPOOL:
+                return str(torch.nn.AvgPool2d(o.kh, o.stride))
+            if kind == OpKind.LINEAR:
+                return str(torch.nn.Linear(ch[o.in0] * o.kh * o.kw, o.cout, bias=o.w_bias >= 0))
+        return LAYER_NAMES[kind] + '()'
+
+    def layernames(self, mode, seed_tensor):
+        """Whitebox.P_layername of a sweep (whitebox.py:393), image hook included (last entry, like the reference's list)."""
+        ch = self.tensor_channels()
+        return [self.module_repr(k, ch) for k in self.firing_ops(mode, seed_tensor)] + [self.module_repr(0, ch)]
 
     def hooked_kinds(self):
         return [OpKind(o.kind) for o in self.ops if o.kind < OpKind.G_ADD]
