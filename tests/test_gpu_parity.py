@@ -516,8 +516,9 @@ def test_epilogue_fusion_is_bit_identical(gpu_device, arch, mode):
 def test_persistent_gemm_is_bit_identical(gpu_device, arch, mode, n):
     """xfr_engine_set_persistent_gemm: the persistent wave-specialised kernel (conv_ws.hip: math waves + epilogue waves, tiles streamed
     through one workgroup) sums K in the order of the one-tile-per-workgroup kernel it replaces and runs the same compiled epilogues --
-    identical bits for encodings and maps, with batches large enough that its launch rule (K <= 256, >= 1536 tiles) selects it for the
-    forward 1x1 layers (BatchNorm / residual / ReLU, MaxFeatureMap epilogues), the dual W / relu(W) launches and the backward chain GEMMs."""
+    identical bits for encodings and maps, with batches large enough that its launch rules (image stems; K <= 256, >= 1536 tiles) select it for
+    the 7x7 stems (gathered input, true and clamped), the forward 1x1 layers (BatchNorm / residual / ReLU, MaxFeatureMap epilogues), the dual
+    W / relu(W) launches and the backward chain GEMMs."""
     bb, sd = make_backbone(arch, seed=6, num_classes=None if arch == 'resnet50_128' else 7)
     subj = GC.engine_subject(arch, bb, mode)
     wb = subj.wb
@@ -528,11 +529,12 @@ def test_persistent_gemm_is_bit_identical(gpu_device, arch, mode, n):
     subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
     eng = wb._engine(2 * n)
     res = {}
-    for on in (1, 0):
-        eng.set_persistent_gemm(on)
-        res[on] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
-                   wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone())
+    for level in (2, 1, 0):         # stems + short-K 1x1 layers | stems only | never (the default)
+        eng.set_persistent_gemm(level)
+        res[level] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
+                      wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone())
     eng.set_persistent_gemm(0)      # the default
-    for a, b in zip(res[1], res[0]):
-        assert torch.isfinite(a).all()
-        assert torch.equal(a, b)
+    for level in (2, 1):
+        for a, b in zip(res[level], res[0]):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--cells', type=int, default=7, help='RISE grid: cells x cells random mask, bilinearly upsampled')
     ap.add_argument('--parity', type=int, default=8, help='masked probes checked against the CPU oracle (0: skip)')
+    ap.add_argument('--ab', type=int, default=0, help='A/B in one process: run the sweep this many times with the forward split on and off, alternating, and print one line per run')
     ap.add_argument('--no-split', action='store_true', help='xfr_engine_set_forward_split(0): one forward per batch on the caller\'s stream (round 3)')
     args = ap.parse_args()
     import numpy as np
@@ -67,7 +68,8 @@ def main():
     for k in range(2):
         free[k].record(main_s)
     ref = wb.encode(probe)
-    wb.encode(bufs[0])                                   # warm-up: engine at this batch size
+    for _ in range(12):                                  # warm-up: engine at this batch size, clocks up (the first sweep of a process reads 5-25 % low)
+        wb.encode(bufs[0])
     if args.no_split:
         wb._engine(args.batch).set_forward_split(False)
     picks = {}
@@ -77,6 +79,25 @@ def main():
         for _ in range(args.parity):
             picks.setdefault(int(rng.choice(full)), []).append(int(rng.randint(0, grids[full[0]].shape[0])))
     kept = {}
+    if args.ab:
+        eng = wb._engine(args.batch)
+        for rep in range(2 * args.ab):
+            on = rep % 2 == 0
+            eng.set_forward_split(on)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            generate(0)
+            for i in range(n_batches):
+                k, n = i % 2, grids[i].shape[0]
+                if i + 1 < n_batches:
+                    generate(i + 1)
+                main_s.wait_event(ready[k])
+                wb.encode(bufs[k][:n])
+                free[k].record(main_s)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(json.dumps({'forward_split': on, 'images_per_s': args.masks / dt, 'frac_of_fp32_mfma_peak': args.masks * 14.419e9 / dt / 157.3e12}), flush=True)
+        return
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     generate(0)

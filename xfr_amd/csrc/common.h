@@ -222,7 +222,7 @@ struct ConvParams {
     unsigned in_bytes;  // byte size of the input tensor (buffer descriptor range; < 2^31)
     int force_cfg;      // 0 = heuristic tile choice, else a configuration id (tuning / tests)
     int ws_debug;       // tuning only (xfr_debug_conv cfg 18 / 19): 1 = the persistent kernel's epilogue waves store nothing
-    int no_ws;          // 1: never pick the persistent wave-specialised kernel (conv_ws.hip) for this launch
+    int ws_level;       // the persistent wave-specialised kernel (conv_ws.hip): 0 = never, 1 = image stems (Cin <= 4), 2 = also the short-K 1x1 layers
     // tail balancing (conv_gemm.hip): the last tiles % CUs tiles of a small grid are cut along K into tail_s parts
     // each, so that every CU gets the same share of the final round; parts meet in tail_ws, the last arriver reduces.
     float* tail_ws;     // scratch for the parts' accumulators (nullptr: never balance); one per stream in flight

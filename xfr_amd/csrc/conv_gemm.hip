@@ -1230,8 +1230,16 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
     // Short-K 1x1 layers on grids of at least two tiles per resident workgroup: the persistent wave-specialised kernel (conv_ws.hip).  It sums K
     // in conv_gemm_kernel's order, so choosing by the grid size (a property of the batch) changes no bit.
-    if (!p.no_ws && p.K <= 256 && conv_ws_ok(p)) {
+    if (p.ws_level >= 2 && p.tap_major != 2 && p.K <= 256 && conv_ws_ok(p)) {
         const long t = (long)((p.CoutTot + 63) / 64) * p.nhalves * ((p.M + 63) / 64);
+        if (t >= 1536) return 9;
+    }
+    // Image stems (Cin <= 4, 7x7) on the persistent kernel: the per-lane window arithmetic once per tile INSIDE a running ring, no prologue
+    // after the first tile; K order of conv_gemm_kernel, same bits.  Measured (round 4, tools/conv_sweep.py row 13): 0.2325 ms against 0.2304
+    // for conv_gemm_kernel once its tap mask is built separably (was 0.264-0.279), 0.212 with epilogue waves that store nothing -- the
+    // 4-byte gather loads bound the layer either way.  Not the default (ws_level 0).
+    if (p.ws_level >= 1 && p.tap_major == 2 && conv_ws_ok(p)) {
+        const long t = (long)((p.CoutTot + 63) / 64) * ((p.M + 63) / 64);
         if (t >= 1536) return 9;
     }
     if (ks_ok<8>(p)) {

@@ -61,12 +61,18 @@ __device__ inline WsTile ws_tile(const ConvParams& p, int lid, int n_co_tiles)
 }
 
 // ---- math waves ---------------------------------------------------------------------------------------------------------
-template <int BK, int NST>
+// MODE: WS_VEC = 1x1 stride-1 layers (16-byte loads of contiguous rows); WS_TAP4 = image stems (Cin <= 4, K packed (kh, kw, 4 channel slots):
+// conv_gemm.hip MODE_TAP4) -- a K-step is four taps x four channel slots, the four k rows a wave gathers are the channels of ONE tap, one shifted,
+// masked per-lane offset per wave and K-step.  RELU: clamp the gathered input at 0 (the positive pass of a signed image).
+enum { WS_VEC = 0, WS_TAP4 = 1 };
+template <int BK, int NST, int MODE, bool RELU>
 __device__ __forceinline__ void ws_math(const ConvParams& p, float* smem, float* handoff, const int wave, const int lane, const int n_co_tiles,
                                         const WsSeq sq)
 {
+    static_assert(MODE == WS_VEC || BK == 16, "the 4-channel tap gather is written for 16-deep K-steps (four taps)");
     constexpr int A_FLOATS = BK * 64, B_FLOATS = BK * 64, STAGE = A_FLOATS + B_FLOATS;
-    constexpr int APW = A_FLOATS / 256 / 4, BPW = B_FLOATS / 256 / 4;       // 16-byte wave-loads per wave and stage
+    constexpr int APW = A_FLOATS / 256 / 4;                                 // 16-byte wave-loads per wave and stage
+    constexpr int BPW = (MODE == WS_VEC) ? B_FLOATS / 256 / 4 : B_FLOATS / 64 / 4;      // 16-byte wave-loads | 4-byte wave-loads (one k row x 64 m)
     constexpr int L = APW + BPW;
     constexpr int NP = 4;                                                   // shares the loads of a K-step are issued in (between the MFMAs)
     static_assert((NST - 2) * L <= 63, "vmcnt is a 6-bit counter");
@@ -80,11 +86,13 @@ __device__ __forceinline__ void ws_math(const ConvParams& p, float* smem, float*
 
     // ---- issue cursor: (tile ordinal, K-step) of the next stage to be filled; it runs NST-1 K-steps ahead of the MFMAs, across tiles
     int is_j = sq.loc, is_kt = 0;
-    unsigned voffA[APW], voffB[BPW];
+    unsigned voffA[APW], voffB[(MODE == WS_VEC) ? BPW : 1];
+    int base_m = 0;                       // WS_TAP4: this lane's m column of the cursor's tile -- input offset of its window's corner, valid taps
+    unsigned long long tapmask = 0ull;
 #pragma unroll
     for (int i = 0; i < APW; ++i) voffA[i] = OOB;
 #pragma unroll
-    for (int i = 0; i < BPW; ++i) voffB[i] = OOB;
+    for (int i = 0; i < ((MODE == WS_VEC) ? BPW : 1); ++i) voffB[i] = OOB;
     __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
     auto set_issue_tile = [&](int j) {
         const WsTile t = ws_tile(p, sq.base + j, n_co_tiles);
@@ -95,12 +103,33 @@ __device__ __forceinline__ void ws_math(const ConvParams& p, float* smem, float*
             const int row = f >> 6, col = f & 63;
             voffA[i] = (unsigned)(row * p.ldw + t.co0 + col) * 4u;
         }
+        if constexpr (MODE == WS_VEC) {
 #pragma unroll
-        for (int i = 0; i < BPW; ++i) {
-            const int f = (wave * BPW + i) * 256 + lane * 4;
-            const int row = f >> 6, col = f & 63;
-            const int m = t.m0 + col;
-            voffB[i] = (m < p.M) ? (unsigned)row * chan_bytes + (unsigned)m * 4u : OOB;      // k rows beyond Cin lie outside the descriptor: 0.0
+            for (int i = 0; i < BPW; ++i) {
+                const int f = (wave * BPW + i) * 256 + lane * 4;
+                const int row = f >> 6, col = f & 63;
+                const int m = t.m0 + col;
+                voffB[i] = (m < p.M) ? (unsigned)row * chan_bytes + (unsigned)m * 4u : OOB;      // k rows beyond Cin lie outside the descriptor: 0.0
+            }
+        } else {
+            const int m = t.m0 + lane;
+            const bool m_ok = m < p.M;
+            const int mm = m_ok ? m : 0;
+            const int ohw = p.OH * p.OW;
+            const int n = mm / ohw;
+            const int r = mm - n * ohw;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            base_m = n * p.H * p.W + ih0 * p.W + iw0;
+            tapmask = 0ull;
+            if (m_ok) {
+                unsigned long long vw = 0ull;
+                for (int dw = 0; dw < p.kw; ++dw)
+                    if ((unsigned)(iw0 + dw) < (unsigned)p.W) vw |= 1ull << dw;
+                for (int dh = 0; dh < p.kh; ++dh)
+                    if ((unsigned)(ih0 + dh) < (unsigned)p.H) tapmask |= vw << (dh * p.kw);
+            }
         }
     };
     bool is_live = is_j < sq.cnt;
@@ -113,9 +142,21 @@ __device__ __forceinline__ void ws_math(const ConvParams& p, float* smem, float*
 #pragma unroll
         for (int i = 0; i < APW; ++i)
             if (mine(i, APW)) bload16(rW, As + (wave * APW + i) * 256, is_live ? voffA[i] : OOB, (unsigned)is_kt * a_step);
+        if constexpr (MODE == WS_VEC) {
 #pragma unroll
-        for (int i = 0; i < BPW; ++i)
-            if (mine(i, BPW)) bload16(rIn, Bs + (wave * BPW + i) * 256, is_live ? voffB[i] : OOB, (unsigned)(is_kt * BK) * chan_bytes);
+            for (int i = 0; i < BPW; ++i)
+                if (mine(i, BPW)) bload16(rIn, Bs + (wave * BPW + i) * 256, is_live ? voffB[i] : OOB, (unsigned)(is_kt * BK) * chan_bytes);
+        } else {
+            if (part <= 0) {
+                const int tap = is_kt * 4 + wave;
+                const int dh = tap / p.kw, dw = tap - dh * p.kw;
+                const bool tap_ok = is_live && tap < p.kh * p.kw;
+                voffB[0] = (tap_ok && ((tapmask >> (tap & 63)) & 1ull)) ? (unsigned)(base_m + dh * p.W + dw) * 4u : OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < BPW; ++i)
+                if (mine(i, BPW)) bload4(rIn, Bs + (wave * BPW + i) * 64, i < p.Cin ? voffB[0] : OOB, (unsigned)i * chan_bytes);
+        }
         if (part < 0 || part == NP - 1) {
             if (++is_kt == nk) {
                 is_kt = 0;
@@ -152,6 +193,7 @@ __device__ __forceinline__ void ws_math(const ConvParams& p, float* smem, float*
                     a_nxt = As[(kk + 2 + lhi) * 64 + a_off];
                     b_nxt = Bs[(kk + 2 + lhi) * 64 + b_off];
                 }
+                if (RELU) b_cur = fmaxf(b_cur, 0.f);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, acc, 0, 0, 0);
                 if ((kk / 2) % (BK / 2 / NP) == 0) issue(st_fill, (kk / 2) / (BK / 2 / NP));
                 a_cur = a_nxt;
@@ -317,7 +359,7 @@ __device__ __forceinline__ void ws_epilogue_dispatch(int sig, const ConvParams& 
 }
 
 // CHAIN: 0 = no chain, 1 = compiled chain (p.chain_sig), 3 = compiled MaxFeatureMap chain (the two register families of conv_gemm.hip)
-template <int BK, int NST, int CHAIN>
+template <int BK, int NST, int CHAIN, int MODE, bool RELU>
 __global__ __launch_bounds__(WS_NT, 6) void conv_ws_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -329,7 +371,7 @@ __global__ __launch_bounds__(WS_NT, 6) void conv_ws_kernel(const ConvParams p, c
     const WsSeq sq = ws_seq(n_co_tiles * n_m_tiles);
     if (wave == 0) stamp(p, 0, lane, 0, 2);
     if (wave < 4) {
-        ws_math<BK, NST>(p, smem, handoff, wave, lane, n_co_tiles, sq);
+        ws_math<BK, NST, MODE, RELU>(p, smem, handoff, wave, lane, n_co_tiles, sq);
     } else {
         const int nk = (p.K + BK - 1) / BK;
         if constexpr (CHAIN == 0) ws_epilogue<-1>(p, handoff, wave - 4, lane, n_co_tiles, sq, nk);
@@ -348,42 +390,48 @@ int ws_num_cus()
     return n;
 }
 
-template <int BK, int NST, int CHAIN>
-int ws_blocks_per_cu(size_t lds)
+template <int BK, int NST, int CHAIN, int MODE, bool RELU>
+void ws_launch_one(const ConvParams& q, hipStream_t s)
 {
-    static const int n = [lds] {
+    const int n_co = ((q.CoutTot + 63) / 64) * q.nhalves;
+    const int n_m = (q.M + 63) / 64;
+    const size_t lds = ((size_t)NST * BK * 128 + 4 * 32 * WS_LD) * sizeof(float);
+    // resident workgroups per CU, asked once per instantiation: a persistent grid must not be larger than what is co-resident
+    static const int per_cu = [lds] {
         int b = 0;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws_kernel<BK, NST, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, conv_ws_kernel<BK, NST, CHAIN>, WS_NT, lds) != hipSuccess || b < 1) b = 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws_kernel<BK, NST, CHAIN, MODE, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, conv_ws_kernel<BK, NST, CHAIN, MODE, RELU>, WS_NT, lds) != hipSuccess || b < 1) b = 1;
         return b;
     }();
-    return n;
+    const int grid = std::min(n_co * n_m, per_cu * ws_num_cus());
+    hipLaunchKernelGGL((conv_ws_kernel<BK, NST, CHAIN, MODE, RELU>), dim3(grid), dim3(WS_NT), lds, s, q, n_co, n_m);
 }
 
 template <int BK, int NST>
 void ws_launch(const ConvParams& q, int chain_kind, hipStream_t s)
 {
-    const int n_co = ((q.CoutTot + 63) / 64) * q.nhalves;
-    const int n_m = (q.M + 63) / 64;
-    const size_t lds = ((size_t)NST * BK * 128 + 4 * 32 * WS_LD) * sizeof(float);
-    int per_cu;
-    if (chain_kind == 3) per_cu = ws_blocks_per_cu<BK, NST, 3>(lds);
-    else if (chain_kind == 1) per_cu = ws_blocks_per_cu<BK, NST, 1>(lds);
-    else per_cu = ws_blocks_per_cu<BK, NST, 0>(lds);
-    const int grid = std::min(n_co * n_m, per_cu * ws_num_cus());
-    if (chain_kind == 3) hipLaunchKernelGGL((conv_ws_kernel<BK, NST, 3>), dim3(grid), dim3(WS_NT), lds, s, q, n_co, n_m);
-    else if (chain_kind == 1) hipLaunchKernelGGL((conv_ws_kernel<BK, NST, 1>), dim3(grid), dim3(WS_NT), lds, s, q, n_co, n_m);
-    else hipLaunchKernelGGL((conv_ws_kernel<BK, NST, 0>), dim3(grid), dim3(WS_NT), lds, s, q, n_co, n_m);
+    if (q.tap_major == 2) {
+        // image stems: 16-deep K-steps only; no MaxFeatureMap stem has 3 or 4 input channels
+        if (q.relu_in) ws_launch_one<16, 4, 0, WS_TAP4, true>(q, s);
+        else if (chain_kind == 1) ws_launch_one<16, 4, 1, WS_TAP4, false>(q, s);
+        else ws_launch_one<16, 4, 0, WS_TAP4, false>(q, s);
+        return;
+    }
+    if (chain_kind == 3) ws_launch_one<BK, NST, 3, WS_VEC, false>(q, s);
+    else if (chain_kind == 1) ws_launch_one<BK, NST, 1, WS_VEC, false>(q, s);
+    else ws_launch_one<BK, NST, 0, WS_VEC, false>(q, s);
 }
 
 }  // namespace
 
 bool conv_ws_ok(const ConvParams& p)
 {
-    if (!(p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && p.out_stride == 1 && p.OH == p.H && p.OW == p.W)) return false;
-    if ((p.M & 3) != 0 || ((p.out_nb * p.OH * p.OW) & 3) != 0 || p.relu_in) return false;
+    if ((p.M & 3) != 0 || ((p.out_nb * p.OH * p.OW) & 3) != 0 || p.out_stride != 1) return false;      // dense float4 output rows
     if (p.K < 32) return false;                         // at least two K-steps per tile (the hand-off protocol counts on it)
-    return true;
+    if (p.tap_major == 2)                               // image stem: (kh, kw, 4 channel slots) pack, at most 64 taps, one half
+        return p.Cin <= 4 && p.kh * p.kw <= 64 && p.nhalves == 1 && (!p.relu_in || p.chain.n == 0) && p.co_pair == 0;
+    if (!(p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W)) return false;
+    return !p.relu_in;
 }
 
 // q: chain already planned (conv_gemm.hip plan_chain): chain_sig >= 0 or no chain at all

@@ -196,7 +196,7 @@ struct xfr_engine {
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
     bool split_forward = true;         // xfr_engine_set_forward_split: forward-only batches of >= 32 images as two halves on the internal streams
-    bool persistent_gemm = false;      // xfr_engine_set_persistent_gemm: conv_ws.hip where the launcher's rule selects it (round 4: measured, off by default)
+    int persistent_gemm = 0;           // xfr_engine_set_persistent_gemm: conv_ws.hip for 0 = nothing (default: round 4 measured no gain), 1 = the image stems, 2 = also the short-K 1x1 layers
     bool interpret_chains = false;     // xfr_engine_set_epilogue_fusion bit 2: fused chains run through the interpreted epilogue (tests)
     bool planning_only = false;        // xfr_plan_describe: list what the planner WOULD fuse, whatever the signature table holds
     bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue (STORE raw, [FORK positive
@@ -561,7 +561,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
     p.chain_interpret = e->interpret_chains ? 1 : 0;
-    p.no_ws = e->persistent_gemm ? 0 : 1;
+    p.ws_level = e->persistent_gemm;
     p.tail_force = 1;
     if (e->tail_balance) {
         p.tail_force = 0;
@@ -2161,7 +2161,8 @@ xfr_status xfr_engine_set_forward_split(xfr_engine* e, int32_t enable)
 xfr_status xfr_engine_set_persistent_gemm(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
-    e->persistent_gemm = enable != 0;
+    if (enable < 0 || enable > 2) return fail(XFR_INVALID_ARG, "xfr_engine_set_persistent_gemm: level must be 0, 1 or 2");
+    e->persistent_gemm = enable;
     return XFR_OK;
 }
 
