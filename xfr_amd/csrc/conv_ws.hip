@@ -395,9 +395,9 @@ void ws_launch_one(const ConvParams& q, hipStream_t s)
 {
     const int n_co = ((q.CoutTot + 63) / 64) * q.nhalves;
     const int n_m = (q.M + 63) / 64;
-    const size_t lds = ((size_t)NST * BK * 128 + 4 * 32 * WS_LD) * sizeof(float);
+    constexpr size_t lds = ((size_t)NST * BK * 128 + 4 * 32 * WS_LD) * sizeof(float);
     // resident workgroups per CU, asked once per instantiation: a persistent grid must not be larger than what is co-resident
-    static const int per_cu = [lds] {
+    static const int per_cu = [] {
         int b = 0;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws_kernel<BK, NST, CHAIN, MODE, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, conv_ws_kernel<BK, NST, CHAIN, MODE, RELU>, WS_NT, lds) != hipSuccess || b < 1) b = 1;
