@@ -538,3 +538,51 @@ def test_persistent_gemm_is_bit_identical(gpu_device, arch, mode, n):
         for a, b in zip(res[level], res[0]):
             assert torch.isfinite(a).all()
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('mode', ['affineonly', 'affineonly_with_prior', 'all'])
+def test_maxfeaturemap_net_outside_the_signature_table(gpu_device, mode):
+    """A Conv -> Split -> max network whose merged fan-out chain is NOT in chain_sigs.inc (a Multiply between two MaxFeatureMap layers: the
+    backward GEMM's chain is [conv hook, Multiply VJP, Multiply hook, MAXHALF fan-out, Split hook]).  The fan-out only exists as a compiled
+    epilogue; round 3 launched it anyway and every ebp call of such a net failed with XFR_STATE_ERROR.  Now the plan falls back to the schedule
+    without fan-outs (interpreted chain behind the GEMM, the MaxFeatureMap VJP as the head of its own chain launch): the maps must equal the
+    CPU oracle's (a tape evaluated op by op)."""
+    from oracle import ebp_oracle as O
+    from xfr_amd.engine import Engine
+    from xfr_amd.program import Program
+    g = torch.Generator().manual_seed(11)
+    H = 16
+    sd = {'c1.weight': torch.randn((8, 1, 3, 3), generator=g) * 0.4, 'c1.bias': torch.randn((8,), generator=g) * 0.1,
+          'c2.weight': torch.randn((8, 4, 3, 3), generator=g) * 0.2, 'c2.bias': torch.randn((8,), generator=g) * 0.1,
+          'fc.weight': torch.randn((5, 4 * H * H), generator=g) * 0.05, 'fc.bias': torch.randn((5,), generator=g) * 0.1}
+    prog = Program((1, H, H))
+    t = prog.g_maxhalves(prog.split(prog.conv(0, 'c1', 8, 3, pad=1)))
+    t = prog.multiply(t, 3.0)
+    t = prog.g_maxhalves(prog.split(prog.conv(t, 'c2', 8, 3, pad=1)))
+    t = prog.mark('classify', prog.linear(t, 'fc', 5, (H, H)))
+    text = prog.describe(mode, t, batch=4)
+    fan = [ln for ln in text.splitlines() if ln.startswith('bwd CONV_BWD') and ' SIG' in ln and any(c.endswith('d') and len(c) == 4 for c in ln.split(' SIG')[1].split()[:-1])]
+    assert any('compiled=-1' in ln for ln in fan), text          # the planner WOULD fan out here, and no compiled epilogue exists for that chain
+
+    n = 4
+    x = torch.rand((n, 1, H, H), generator=g)
+    Pn = torch.zeros((n, 5))
+    Pn[:, 2] = 1.0
+    eng = Engine(prog, n, gpu_device)
+    eng.load_weights(sd)
+    eng.set_mode(mode)
+    _, pooled = eng.ebp(x.to(gpu_device), t, Pn.unsqueeze(0).to(gpu_device), want_mwp=False, want_pooled=True)
+    got = pooled[0].cpu().numpy()
+
+    def forward(tape, xx):
+        u = tape.g_max_halves(tape.split(tape.conv(tape.input(xx), 'c1', stride=1, pad=1)))
+        u = tape.multiply(u, 3.0)
+        u = tape.g_max_halves(tape.split(tape.conv(u, 'c2', stride=1, pad=1)))
+        return tape.linear(tape.g_flatten(u), 'fc')
+    for i in range(n):
+        tape = O.Tape({k: v.clone() for k, v in sd.items()})
+        out = forward(tape, x[i:i + 1])
+        P, names = tape.backward(out, Pn[i:i + 1], mode, 1e-16)
+        want = P[-2].sum(dim=1)[0].numpy()          # MWP at the first convolution's output, channel-pooled (whitebox.py:499)
+        assert_map_close(got[i], want, 'out-of-table MaxFeatureMap net, sample %d, %s' % (i, mode))
+    eng.close()
