@@ -306,7 +306,9 @@ xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32
                              const float* dense_prior_dev, float* pooled_dev, void* stream);
 
 /* Whitebox.P[firing] of a standard EBP sweep (whitebox.py:394): out_dev receives N x C x H x W; (c,h,w) receive its shape
- * (out_dev == NULL: shape query only, nothing is run). */
+ * (out_dev == NULL: shape query only, nothing is run).  firing == xfr_firing_count: the hook on the first convolution's INPUT (the
+ * reference's P[-1], the MWP at the image): relu(image) * relu(backward-data of that convolution with relu(W)), a gather kernel run on
+ * demand -- nothing on the hot path reads it (round 4). */
 xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, int32_t seed_tensor, const float* seed_dev,
                                 int32_t firing, float* out_dev, int32_t* c, int32_t* h, int32_t* w, void* stream);
 

@@ -135,12 +135,11 @@ def test_whitebox_P_surface(gpu_device):
     assert len(wb.P) == len(ow.P) == len(wb.P_layername)
     assert [n.split('(')[0] for n in wb.P_layername] == [n.split('(')[0] for n in ow.P_layername]
     assert wb.P_layername[-1].startswith('Conv2d(3, 64, kernel_size=(7, 7)') or wb.P_layername[-1].startswith('Conv2d(')
-    for k in (0, 7, 23, len(ow.P) - 2, -2, -5):
+    for k in (0, 7, 23, len(ow.P) - 2, -2, -5, -1):           # -1: the MWP at the image (the first layer's backward-data pass, on demand)
         got, want = wb.P[k].cpu().numpy(), ow.P[k].numpy()
         assert got.shape == want.shape
+        assert np.abs(want).max() > 0
         assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-30), k
-    with pytest.raises(IndexError):
-        wb.P[-1]
     with pytest.raises(IndexError):
         wb.P[len(ow.P)]
     nf = len(ow.P) - 1
@@ -335,3 +334,30 @@ def test_rccl_entry_points_world_size_1(gpu_device):
     _lib.check(lib.xfr_comm_destroy(comm))
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize('arch,mode', [('lightcnn29v2', 'affineonly'), ('resnet50_128', 'norelu'), ('stresnet_mini', 'affineonly_with_prior')])
+def test_image_mwp_of_every_backbone(gpu_device, arch, mode):
+    """Whitebox.P[-1] (the hook on the first convolution's input, whitebox.py:394) against the oracle: Light-CNN's one-channel 5x5 first layer
+    with interleaved MaxFeatureMap rows, ResNet-50-128d's bias-free 7x7 / 2 (4-channel tap pack), the STR stem; triplet classifier."""
+    from oracle import ebp_oracle as O
+    import golden_cases as GC
+    from parity_utils import emb_dim
+    from xfr_amd import synth
+    bb, sd = make_backbone(arch, seed=4, num_classes=None if arch == 'resnet50_128' else 7)
+    subj = GC.engine_subject(arch, bb, mode)
+    D = emb_dim(arch)
+    xm, xn = synth.unit_rows(1, D, seed=1) / 2500, synth.unit_rows(1, D, seed=2) / 2500
+    subj.set_cls(xm, xn)
+    ow = O.OracleWhitebox(arch, sd, ('hooked', None), mode)
+    ow.set_triplet_classifier(xm, xn)
+    x = make_images(arch, 1, seed=9)
+    P2 = torch.zeros(1, 2)
+    P2[0, 0] = 1
+    subj.wb.ebp(x, P2)
+    ow.ebp(x, P2)
+    assert len(subj.wb.P) == len(ow.P)
+    for k in (-1, -2):
+        got, want = subj.wb.P[k].cpu().numpy(), ow.P[k].numpy()
+        assert got.shape == want.shape and np.abs(want).max() > 0
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max(), (arch, k)

@@ -303,6 +303,9 @@ bool pool2_fwd_ok(const float* in, const uint8_t* idx, int CN, int H, int W, int
 // 5x5 / stride 1 / pad 2 convolution of a one-channel image with MaxFeatureMap, as a direct convolution reading the GEMM's weight pack (rows
 // interleaved: 2c = channel c, 2c + 1 = channel c + Co); raw (may be null) [2 Co][NB][H][W], omax [Co][NB][H][W]; bit-identical to the GEMM path
 bool stem5_mfm_ok(const float* in, int NB, int H, int W);
+// Whitebox.P[-1]: out[n][ci][ih][iw] = relu(img) * relu(conv_backward_data(g, relu(W))) for the first convolution (on demand only)
+void launch_image_mwp(const float* g, const float* wp, const float* img, float* out, int Cin, int N, int H, int W, int Cout, int OH, int OW,
+                      int kh, int kw, int stride, int pad, int ldw, int kmode, int co_pair, hipStream_t s);
 void launch_stem5_mfm(const float* in, const float* wp, int ldw, const float* bias, float* raw, float* omax, int Co, int NB, int H, int W, hipStream_t s);
 void launch_pool2_fwd(const float* in, float* out_sum, uint8_t* idx, float* out_pos, int CN, int H, int W, int OH, int OW, int relu_max_pos,
                       int pos_avg_mode, hipStream_t s);

@@ -1112,9 +1112,56 @@ __global__ __launch_bounds__(NT) void stem5_mfm_kernel(const float* __restrict__
     }
 }
 
+// Whitebox.P[-1] (whitebox.py:394, the hook on the FIRST convolution's input): p = relu(image) * relu(z), z = the backward-data pass of that
+// convolution with relu(W) on the gradient that leaves its output's hooks.  Nothing on the hot path reads it (the saliency tap is P[-2]), so this is
+// a plain gather kernel run on demand: a thread owns one input pixel of one channel and walks the output positions whose window covers it.
+// g: [Cout][SB][OH][OW] (SB == N here), wp: the forward pack of relu(W) ([K][ldw], k_of(tap, ci) per kmode: 0 = (ci, kh, kw), 1 = (kh, kw, ci),
+// 2 = (kh, kw, 4 channel slots); column co_pair ? interleaved halves : co), img: [Cin][N][H][W], out: NCHW.
+__global__ __launch_bounds__(NT) void image_mwp_kernel(const float* __restrict__ g, const float* __restrict__ wp, const float* __restrict__ img,
+                                                      float* __restrict__ out, int Cin, int N, int H, int W, int Cout, int OH, int OW, int kh,
+                                                      int kw, int stride, int pad, int ldw, int kmode, int co_pair)
+{
+    const long total = (long)N * Cin * H * W;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int iw = (int)(i % W);
+        const int ih = (int)((i / W) % H);
+        const int ci = (int)((i / ((long)W * H)) % Cin);
+        const int n = (int)(i / ((long)W * H * Cin));
+        float z = 0.f;
+        for (int dh = 0; dh < kh; ++dh) {
+            const int t = ih + pad - dh;
+            if (t < 0 || t % stride) continue;
+            const int oh = t / stride;
+            if (oh >= OH) continue;
+            for (int dw = 0; dw < kw; ++dw) {
+                const int u = iw + pad - dw;
+                if (u < 0 || u % stride) continue;
+                const int ow = u / stride;
+                if (ow >= OW) continue;
+                const int tap = dh * kw + dw;
+                const long k = kmode == 2 ? (long)tap * 4 + ci : (kmode == 1 ? (long)tap * Cin + ci : (long)ci * kh * kw + tap);
+                const float* wrow = wp + k * ldw;
+                const float* gp = g + ((long)n * OH + oh) * OW + ow;
+                for (int co = 0; co < Cout; ++co) {
+                    const int col = co_pair ? (co % co_pair) * 2 + co / co_pair : co;
+                    z = __builtin_fmaf(gp[(long)co * N * OH * OW], wrow[col], z);
+                }
+            }
+        }
+        const float a = fmaxf(img[((long)ci * N + n) * H * W + (long)ih * W + iw], 0.f);
+        out[i] = a * fmaxf(z, 0.f);
+    }
+}
+
 bool pool2_fwd_ok(const float* in, const uint8_t* idx, int CN, int H, int W, int OH, int OW)
 {
     return W == 2 * OW && H == 2 * OH && (W & 7) == 0 && CN <= 65535 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)idx) & 3) == 0;
+}
+void launch_image_mwp(const float* g, const float* wp, const float* img, float* out, int Cin, int N, int H, int W, int Cout, int OH, int OW,
+                      int kh, int kw, int stride, int pad, int ldw, int kmode, int co_pair, hipStream_t s)
+{
+    hipLaunchKernelGGL(image_mwp_kernel, dim3(grid_for((long)N * Cin * H * W)), dim3(NT), 0, s, g, wp, img, out, Cin, N, H, W, Cout, OH, OW, kh,
+                       kw, stride, pad, ldw, kmode, co_pair);
 }
 bool stem5_mfm_ok(const float* in, int NB, int H, int W)
 {

@@ -2420,7 +2420,26 @@ xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, in
     BwdPlan* plan = nullptr;
     st = get_plan(e, seed_tensor, &plan);
     if (st != XFR_OK) return st;
-    if (firing < 0 || firing >= plan->n_firings) return fail(XFR_INVALID_ARG, "firing %d outside [0, %d)", firing, plan->n_firings);
+    if (firing < 0 || firing > plan->n_firings) return fail(XFR_INVALID_ARG, "firing %d outside [0, %d]", firing, plan->n_firings);
+    if (firing == plan->n_firings) {
+        // the image hook, Whitebox.P[-1]: one standard sweep leaves the gradient of the first convolution's output (after its hooks) in G(1);
+        // its backward-data pass with relu(W) and the hook p = relu(image) * relu(z) run as one gather kernel (nothing on the path reads this)
+        if (c) *c = e->in_c;
+        if (h) *h = e->in_h;
+        if (w) *w = e->in_w;
+        if (!out_dev) return XFR_OK;
+        e->rc_priors = e->rc_caps = false;
+        e->store_slot = -1;
+        st = ebp_core(e, x_dev, n, 1, seed_tensor, seed_dev, s);
+        if (st != XFR_OK) return st;
+        const OpRec& o = e->ops[0];
+        const xfr_op_desc& d = o.d;
+        const Tensor& t1 = e->tens[d.out];
+        launch_image_mwp(e->G(d.out), e->arena + o.w_pos, e->T(0), out_dev, e->in_c, n, e->in_h, e->in_w, d.cout, t1.H, t1.W, d.kh, d.kw, d.stride,
+                         d.pad, o.ldw, o.tap4_fwd ? 2 : (o.tap_fwd ? 1 : 0), o.pair, s);
+        HIP_TRY(hipGetLastError());
+        return XFR_OK;
+    }
     const Tensor& x = e->tens[plan->firing_tensor[firing]];
     if (c) *c = x.C;
     if (h) *h = x.H;

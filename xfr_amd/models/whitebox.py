@@ -198,7 +198,7 @@ class _PList(object):
     """`Whitebox.P` (whitebox.py:294,394): the MWP tensors of the last sweep in firing order.  The reference clones every one
     of them on every sweep; the engine hands back the channel-pooled P[-2] its callers read (whitebox.py:499,524) and recomputes
     any entry on demand with one more sweep that stores that firing (xfr_ebp_store_firing).  len(P) counts the image hook
-    P[-1] like the reference does; its tensor needs the first layer's backward-data pass, which the engine does not run."""
+    P[-1] like the reference does; its tensor is the first layer's backward-data pass (a gather kernel run on demand, round 4)."""
 
     def __init__(self, wb, x, seed_tensor, seed, n_firings):
         self._wb, self._x, self._seed_tensor, self._seed = wb, x, seed_tensor, seed
@@ -214,8 +214,6 @@ class _PList(object):
             k += self._n
         if not (0 <= k < self._n):
             raise IndexError('P index %d out of range (%d entries)' % (i, self._n))
-        if k == self._n - 1:
-            raise IndexError('xfr_amd does not compute P[-1] (the MWP at the image): nothing on the path reads it')
         if k not in self._cache:
             eng = self._wb._engine(self._x.shape[0])
             P = eng.ebp_firing(self._x, self._seed_tensor, self._seed, k)
