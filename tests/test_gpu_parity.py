@@ -43,7 +43,7 @@ def _check_factory():
     (64, 16, 16, 2, 32, 1, 2, 0),      # strided 1x1
     (128, 8, 8, 2, 40, 8, 1, 0),       # Linear on a flattened 8x8 map (64 taps)
 ])
-@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8, 9, 10, 10004, 20004, 30005, 80004, 20006, 30008])
+@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8, 9, 10, 12, 10004, 20004, 30005, 80004, 20006, 30008, 20012])
 def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
     """The MFMA implicit-GEMM kernel against plain PyTorch fp32 conv2d on the CPU."""
     from xfr_amd import _lib

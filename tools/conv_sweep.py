@@ -28,6 +28,8 @@ LCNN = [
     (128, 16, 16, 256, 3, 1, 1), (192, 16, 16, 384, 3, 1, 1), (96, 32, 32, 192, 3, 1, 1), (48, 64, 64, 96, 3, 1, 1),
     (1, 128, 128, 96, 5, 1, 2), (48, 64, 64, 96, 1, 1, 0), (96, 32, 32, 192, 1, 1, 0), (192, 16, 16, 384, 1, 1, 0),
     (128, 16, 16, 256, 1, 1, 0), (192, 16, 16, 256, 3, 1, 1), (96, 32, 32, 384, 3, 1, 1),
+    # backward-data GEMMs onto 96 channels (row 11 ff.): Cout = 96 fills a 64-row tile pair to 75 %
+    (192, 32, 32, 96, 3, 1, 1), (384, 32, 32, 96, 3, 1, 1), (192, 64, 64, 96, 1, 1, 0),
 ]
 
 

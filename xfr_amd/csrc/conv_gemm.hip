@@ -160,13 +160,14 @@ __device__ __forceinline__ void chain_epilogue_dispatch(int sig, const ConvParam
 // Everything after the K loop of a 64x64 block tile whose wave (wrow, wcol) holds the 32x32 quadrant acc[0][0]: the exchange of a
 // tail tile's K-parts, then the epilogue.  Shared by the two kernels below.  CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue
 // (p.chain_sig), 2 = interpreted chain epilogue; LDS_OK: the workgroup's LDS holds the four 32 x 36 transposition tiles.
-template <int CHAIN, bool LDS_OK>
+// ROW: the four waves lie side by side along m (a 32 x 128 block tile) instead of 2 x 2 (64 x 64); either way a wave holds one 32 x 32 quadrant.
+template <int CHAIN, bool LDS_OK, bool ROW = false>
 __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[1][1], float* smem, const int tid, const int lane, const int wave,
                                                const int co0, const int m0, const int half, const int tail_t, const int part, const int nparts,
                                                float* __restrict__ osel, const float* __restrict__ bsel)
 {
-    constexpr int MI = 1, NJ = 1, TCO = 64, TM = 64;
-    const int wrow = wave >> 1, wcol = wave & 1;
+    constexpr int MI = 1, NJ = 1, TCO = 64, TM = 64;         // (TCO / 2, TM / 2 below = the 32 rows / columns of a wave's quadrant in both layouts)
+    const int wrow = ROW ? 0 : wave >> 1, wcol = ROW ? wave : wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     if (tail_t >= 0) {
         // K-part of a tail tile: park the accumulators, count arrivals; the last part to arrive sums all parts in
@@ -447,11 +448,15 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
 template <int TCO, int TM, int BK, int NST, int MODE, bool RELU, int CHAIN>
 __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVES)) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
-    constexpr int MI = TCO / 64;   // MFMA tiles per wave along co
-    constexpr int NJ = TM / 64;    // MFMA tiles per wave along m
+    // TCO == 32 (with TM == 128): the four waves side by side along m -- a block tile for layers whose channel count leaves a 64-row tile half
+    // empty (Light-CNN: 96 = 3 x 32).  Same K-steps, same accumulator order: same bits as the 64 x 64 tile.
+    constexpr bool ROW = TCO == 32;
+    static_assert(!ROW || TM == 128, "the 32-row tile is 32 x 128");
+    constexpr int MI = ROW ? 1 : TCO / 64;   // MFMA tiles per wave along co
+    constexpr int NJ = ROW ? 1 : TM / 64;    // MFMA tiles per wave along m
     constexpr int A_FLOATS = BK * TCO, B_FLOATS = BK * TM;
     constexpr int STAGE = A_FLOATS + B_FLOATS;
-    constexpr int A_PER_WAVE = A_FLOATS / 256 / 4;                        // 16-byte wave-loads per wave per stage
+    constexpr int A_PER_WAVE = ROW ? A_FLOATS / 64 / 4 : A_FLOATS / 256 / 4;   // 4-byte (32-row tile) | 16-byte wave-loads per wave per stage
     constexpr int B_PER_WAVE = (MODE == MODE_VEC) ? B_FLOATS / 256 / 4    // 16-byte wave-loads
                                                   : B_FLOATS / 64 / 4;    // 4-byte wave-loads (one k row x 64 m)
     constexpr int L = A_PER_WAVE + B_PER_WAVE;
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wrow = wave >> 1, wcol = wave & 1;
+    const int wrow = ROW ? 0 : wave >> 1, wcol = ROW ? wave : wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     stamp(p, wave, lane, 0);
 
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
     unsigned voffA[A_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < A_PER_WAVE; ++i) {
-        const int f = (wave * A_PER_WAVE + i) * 256 + lane * 4;
+        const int f = ROW ? (wave * A_PER_WAVE + i) * 64 + lane : (wave * A_PER_WAVE + i) * 256 + lane * 4;
         const int row = f / TCO, col = f - row * TCO;
         voffA[i] = (unsigned)(row * p.ldw + co0 + col) * 4u;
     }
@@ -598,8 +603,11 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
         const int k0 = kt * BK;
         const bool live = kt < nk;      // steps past the end load nothing real (uniform vmcnt accounting)
 #pragma unroll
-        for (int i = 0; i < A_PER_WAVE; ++i)
-            if (mine(i, A_PER_WAVE)) bload16(rW, As + (wave * A_PER_WAVE + i) * 256, live ? voffA[i] : OOB, (unsigned)kt * a_step);
+        for (int i = 0; i < A_PER_WAVE; ++i) {
+            if (!mine(i, A_PER_WAVE)) continue;
+            if constexpr (ROW) bload4(rW, As + (wave * A_PER_WAVE + i) * 64, live ? voffA[i] : OOB, (unsigned)kt * a_step);
+            else bload16(rW, As + (wave * A_PER_WAVE + i) * 256, live ? voffA[i] : OOB, (unsigned)kt * a_step);
+        }
         if (MODE == MODE_VEC) {
 #pragma unroll
             for (int i = 0; i < B_PER_WAVE; ++i)
@@ -683,8 +691,8 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(kt_lo + s, s, -1);
 
-    const int a_off = wrow * (TCO / 2) + l31;
-    const int b_off = wcol * (TM / 2) + l31;
+    const int a_off = ROW ? l31 : wrow * (TCO / 2) + l31;
+    const int b_off = ROW ? wcol * 32 + l31 : wcol * (TM / 2) + l31;
 
     int st = 0;
     for (int kt = kt_lo; kt < nk; ++kt) {
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
     stamp(p, wave, lane, 2);
     stamp(p, wave, lane, 3);
 
-    block_epilogue<CHAIN, true>(p, acc, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel);      // the launcher allocates at least the four 32 x 36 tiles
+    block_epilogue<CHAIN, true, ROW>(p, acc, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel);      // the launcher allocates at least the four 32 x 36 tiles
     stamp(p, wave, lane, 4);
 }
 
@@ -1091,7 +1099,7 @@ bool launch_one(const ConvParams& p, hipStream_t s)
             grid = q.tail_q + r * S;
         }
     }
-    if constexpr (TCO == 64 && TM == 64) {
+    if constexpr ((TCO == 64 && TM == 64) || (TCO == 32 && TM == 128)) {
         if (q.chain.n > 0) {      // fused micro-program (no relu_in)
             if (plan_chain(q)) return false;
             g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
@@ -1176,7 +1184,7 @@ bool launch_cfg(const ConvParams& p, hipStream_t s)
 {
     const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H && p.OW == p.W);
     if (vec) return launch_one<TCO, TM, BK, NST, MODE_VEC>(p, s);
-    if (p.tap_major == 2) return launch_one<TCO, TM, 16, 4, MODE_TAP4>(p, s);
+    if (p.tap_major == 2) return launch_one<64, 64, 16, 4, MODE_TAP4>(p, s);
     if (p.tap_major && (p.Cin % BK) == 0) return launch_one<TCO, TM, BK, NST, MODE_TAP>(p, s);
     if (p.tap_major) return launch_one<TCO, TM, 16, 4, MODE_TAP>(p, s);
     return launch_one<TCO, TM, 16, 4, MODE_GEN>(p, s);
@@ -1241,6 +1249,14 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     if (p.ws_level >= 1 && p.tap_major == 2 && conv_ws_ok(p)) {
         const long t = (long)((p.CoutTot + 63) / 64) * ((p.M + 63) / 64);
         if (t >= 1536) return 9;
+    }
+    // Channel counts that leave the last 64-row tile at most half full (Light-CNN: 96 = 64 + 32): the 32 x 128 block tile wastes no MFMA row.
+    // A property of the layer; K order of the 64 x 64 tile, so the bits do not move where that one ran before.
+    {
+        const int rem = p.CoutTot % 64;
+#ifndef XFR_NO_ROW_TILE      /* A/B builds only (profiles/r4/experiments/row_tile_ab.txt) */
+        if (rem > 0 && rem <= 32 && p.tap_major != 2 && p.out_stride == 1 && p.CoutTot > 32) return 12;
+#endif
     }
     if (ks_ok<8>(p)) {
         // The choice depends on the LAYER only, never on the batch: the two kernels sum K in different orders, and a sample's map must
@@ -1334,5 +1350,6 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     if (cfg == 6 && ks_ok<8>(p)) return launch_cfg_ks<8, 3>(p, s);
     if (cfg == 7 && ks_ok<4>(p)) return launch_cfg_ks<4, 4>(p, s);
     if (cfg == 5) return launch_cfg<64, 64, 32, 3>(p, s);
+    if (cfg == 12) return launch_cfg<32, 128, 16, 3>(p, s);          // the 32 x 128 block tile (four waves side by side along m)
     return launch_cfg<64, 64, 16, 3>(p, s);
 }
