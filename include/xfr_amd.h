@@ -234,7 +234,9 @@ xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
  * Light-CNN's pooling stages (lightcnn.py:252, MaxPool2d(2)(x) + AvgPool2d(2)(x)) run as one forward kernel (sum, argmax bytes, positive-pass
  * sum) and their two VJPs as the head of the hook chain that follows them (EW_POOL2_IN) whenever bit 0 is set; bit 3 (tests) keeps the
  * separate kernels / launches: bit-identical either way (round 4).  Light-CNN's first layer (one input channel, 5x5, MaxFeatureMap) runs as a
- * direct convolution in the GEMM's K order unless bit 4 (tests) is set. */
+ * direct convolution in the GEMM's K order unless bit 4 (tests) is set.  Backward chain GEMMs that cover the two streams of a contrastive sweep
+ * walk their column tiles stream-interleaved (ConvParams::pair_m: the chain's forward-side operands are fetched once for both streams, -13 % GEMM
+ * FETCH_SIZE on ResNet-101; which workgroup computes which tile is all that changes) unless bit 5 (A/B measurements) is set. */
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable);
 
 /* Share one forward pass between consecutive calls on the same input (off by default).  While hold = 1, a run call

@@ -222,6 +222,10 @@ struct ConvParams {
     unsigned in_bytes;  // byte size of the input tensor (buffer descriptor range; < 2^31)
     int force_cfg;      // 0 = heuristic tile choice, else a configuration id (tuning / tests)
     int ws_debug;       // tuning only (xfr_debug_conv cfg 18 / 19): 1 = the persistent kernel's epilogue waves store nothing
+    int pair_m;         // > 0: the launch covers exactly TWO gradient streams of pair_m = B * OH * OW columns each (M = 2 * pair_m): where pair_m is a
+                        // multiple of the tile width the m-tiles are walked stream-interleaved (tile 2j = stream 0's j-th, 2j + 1 = stream 1's j-th),
+                        // so the forward-side operands of the epilogue chain -- the same for both streams -- are fetched from HBM once and hit L2 the
+                        // second time.  Which workgroup computes which tile changes; no arithmetic does.
     int ws_level;       // the persistent wave-specialised kernel (conv_ws.hip): 0 = never, 1 = image stems (Cin <= 4), 2 = also the short-K 1x1 layers
     // tail balancing (conv_gemm.hip): the last tiles % CUs tiles of a small grid are cut along K into tail_s parts
     // each, so that every CU gets the same share of the final round; parts meet in tail_ws, the last arriver reduces.

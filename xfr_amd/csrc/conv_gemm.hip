@@ -492,8 +492,9 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
         part = 0;
         nparts = 1;
     }
-    const int tile_m = lid / n_co_tiles;
+    int tile_m = lid / n_co_tiles;
     const int tile_co_all = lid - tile_m * n_co_tiles;
+    if (p.pair_m > 0 && (p.pair_m % TM) == 0) tile_m = (tile_m >> 1) + (tile_m & 1) * (p.pair_m / TM);      // ConvParams::pair_m
     const int n_co_half = n_co_tiles / p.nhalves;
     const int half = tile_co_all / n_co_half;
     const int tile_co = tile_co_all - half * n_co_half;
@@ -850,8 +851,9 @@ __global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p,
         part = 0;
         nparts = 1;
     }
-    const int tile_m = lid / n_co_tiles;
+    int tile_m = lid / n_co_tiles;
     const int tile_co_all = lid - tile_m * n_co_tiles;
+    if (p.pair_m > 0 && (p.pair_m % TM) == 0) tile_m = (tile_m >> 1) + (tile_m & 1) * (p.pair_m / TM);      // ConvParams::pair_m
     const int n_co_half = n_co_tiles / p.nhalves;
     const int half = tile_co_all / n_co_half;
     const int tile_co = tile_co_all - half * n_co_half;

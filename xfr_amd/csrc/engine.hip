@@ -203,6 +203,7 @@ struct xfr_engine {
                                        // BatchNorm], affine, clamp).  Round 3, MI355X: +0.6 % maps/s on ResNet-101, +2.2 % on ResNet-50-128d, bit-identical
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
     bool direct_stem = true;           // Light-CNN's 1-channel 5x5 first layer as a direct convolution (xfr_engine_set_epilogue_fusion bit 4 clear; tests set it)
+    bool pair_tiles = true;            // backward chain GEMMs over two streams walk their m-tiles stream-interleaved (xfr_engine_set_epilogue_fusion bit 5 clear)
     bool fuse_pools = true;            // Light-CNN's maxpool + avgpool pair: one forward kernel (xfr_engine_set_epilogue_fusion bit 0 switches it with the rest)
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
                                        // (both: xfr_engine_set_epilogue_fusion; DESIGN.md section 6 has the measurements)
@@ -1519,6 +1520,7 @@ void bwd_conv_params(xfr_engine* e, const BwdPlan& plan, const BwdStep& st, int 
         p.chain_B = B;
         p.chain_eps = e->eps;
         p.accumulate = 0;
+        if (e->pair_tiles && SBa == 2 * B) p.pair_m = B * p.OH * p.OW;     // the two streams' tiles of one position side by side (ConvParams::pair_m)
     }
     p.chain_interpret = e->interpret_chains ? 1 : 0;
 }
@@ -2131,6 +2133,7 @@ xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
     const bool pools = (enable & 1) != 0 && (enable & 8) == 0;
     if (pools != e->fuse_pools) e->plans.clear();
     e->fuse_pools = pools;
+    e->pair_tiles = (enable & 32) == 0;           // bit 5 (A/B measurements): tile order of the two-stream backward GEMMs as before round 4
     e->direct_stem = (enable & 16) == 0;          // bit 4 (tests): the first layer of Light-CNN through the GEMM like every other convolution
     e->held_x = nullptr;
     return XFR_OK;
