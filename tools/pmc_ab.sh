@@ -1,9 +1,11 @@
+#!/bin/bash
+# per-launch-shape FETCH_SIZE / WRITE_SIZE of one model: bash tools/pmc_ab.sh MODEL [FUSION]
 export TMPDIR=/tmp
-D=gpurun_out/pmc_ab; mkdir -p $D
-for f in 3 35; do
-PB="python bench.py --model resnet101 --fusion $f --steps 2 --warmup 1 --no-cpu-baseline --no-profile --serial --no-sustained"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch$f -o x -- $PB > /dev/null 2> $D/fetch$f.err
-python profiles/pmc_summary.py $D/fetch$f | head -3 > $D/fetch$f.txt
-rm -rf $D/fetch$f
+M=${1:-resnet101}; F=${2:-3}
+D=gpurun_out/pmc_grid; mkdir -p $D
+for c in FETCH_SIZE WRITE_SIZE; do
+PB="python bench.py --model $M --fusion $F --steps 2 --warmup 1 --no-cpu-baseline --no-profile --serial --no-sustained --no-secondary"
+rocprofv3 --pmc $c --output-format csv -d $D/$c -o x -- $PB > /dev/null 2> $D/$c.err
+python profiles/pmc_by_grid.py $D/$c 45 > $D/${c}_by_grid_$M.txt
+rm -rf $D/$c
 done
-head -3 $D/fetch3.txt $D/fetch35.txt
