@@ -236,7 +236,11 @@ xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
  * separate kernels / launches: bit-identical either way (round 4).  Light-CNN's first layer (one input channel, 5x5, MaxFeatureMap) runs as a
  * direct convolution in the GEMM's K order unless bit 4 (tests) is set.  Backward chain GEMMs that cover the two streams of a contrastive sweep
  * walk their column tiles stream-interleaved (ConvParams::pair_m: the chain's forward-side operands are fetched once for both streams, -13 % GEMM
- * FETCH_SIZE on ResNet-101; which workgroup computes which tile is all that changes) unless bit 5 (A/B measurements) is set. */
+ * FETCH_SIZE on ResNet-101; which workgroup computes which tile is all that changes) unless bit 5 (A/B measurements) is set.  The block-input
+ * gradient of a down-sampling residual block (shortcut AvgPool2d(2) [+ ConcatChannels], main path through a 1x1 / stride 2 convolution:
+ * resnet.py:111-149) is built per pixel in the head of the hook chain that consumes it (EW_AVGUP_IN) from the pooled gradient and the
+ * compact result of the strided GEMM, instead of by a slice copy, a hook launch, the pool's VJP and a read-modify-write scatter: same
+ * operands, same operations, same bits; bit 6 (tests) keeps the separate launches. */
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable);
 
 /* Share one forward pass between consecutive calls on the same input (off by default).  While hold = 1, a run call

@@ -43,6 +43,13 @@ enum {
                       // the sum, [C][SB][H/2][W/2]: g = 0.25 * src[window] + (argmax[window] == this pixel ? src[window] : 0) -- what AVGPOOL_BWD
                       // followed by an accumulating MAXPOOL_BWD leave in the tensor, bit for bit.  p0 = the max-pool's argmax bytes ([C][B][H/2][W/2],
                       // window-local index dh * 2 + dw), action = W
+    EW_AVGUP_IN = 15, // chain HEAD only (stand-alone kernels): the block-input gradient of a down-sampling residual block whose shortcut is
+                      // AvgPool2d(2) (+ ConcatChannels) and whose main path starts with a 1x1 / stride 2 convolution (resnet.py:111-149), built in place of
+                      // four launches (slice copy, the pooled tensor's hook, the average pool's VJP, the strided GEMM's read-modify-write):
+                      //   g(ih, iw) = (0 + hook(src[ih/2, iw/2])) * 0.25  [+ p2[ih/2, iw/2] on the even (ih, iw): the GEMM's result, kept compact]
+                      // src = the pooled tensor's gradient ([C][SB][H/2][W/2]: the first C rows of the concatenated gradient); the hook of the pooled
+                      // tensor is EW_HOOK's arithmetic on one value (action = HOOK_* or -1 for none, p0 / p1 its a / x at pooled resolution, null p0:
+                      // not observed); prior_sb = W.  Same operands, same operations as the four launches: same bits.
     EW_MAXPAIR = 10   // GEMM epilogue only, last step: g = max(g, value of the partner row c ^ 1) -- MaxFeatureMap of a convolution
                       // whose output channels were packed interleaved (row 2c = channel c, row 2c+1 = channel c + Co); the even
                       // rows then store g as channel c of the Co-channel output
@@ -226,6 +233,8 @@ struct ConvParams {
                         // multiple of the tile width the m-tiles are walked stream-interleaved (tile 2j = stream 0's j-th, 2j + 1 = stream 1's j-th),
                         // so the forward-side operands of the epilogue chain -- the same for both streams -- are fetched from HBM once and hit L2 the
                         // second time.  Which workgroup computes which tile changes; no arithmetic does.
+    int as_strided;     // a stride-2 1x1 backward-data GEMM whose result stays on its own (compact) grid (EW_AVGUP_IN): tile configuration -- hence K
+                        // order -- of the scattering launch it replaces
     int ws_level;       // the persistent wave-specialised kernel (conv_ws.hip): 0 = never, 1 = image stems (Cin <= 4), 2 = also the short-K 1x1 layers
     // tail balancing (conv_gemm.hip): the last tiles % CUs tiles of a small grid are cut along K into tail_s parts
     // each, so that every CU gets the same share of the final round; parts meet in tail_ws, the last arriver reduces.

@@ -1240,7 +1240,7 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
     // Short-K 1x1 layers on grids of at least two tiles per resident workgroup: the persistent wave-specialised kernel (conv_ws.hip).  It sums K
     // in conv_gemm_kernel's order, so choosing by the grid size (a property of the batch) changes no bit.
-    if (p.ws_level >= 2 && p.tap_major != 2 && p.K <= 256 && conv_ws_ok(p)) {
+    if (p.ws_level >= 2 && p.tap_major != 2 && p.K <= 256 && !p.as_strided && conv_ws_ok(p)) {
         const long t = (long)((p.CoutTot + 63) / 64) * p.nhalves * ((p.M + 63) / 64);
         if (t >= 1536) return 9;
     }
@@ -1266,7 +1266,7 @@ int conv_gemm_pick_cfg(const ConvParams& p)
         // 3 / 4) -4..-12 %, 1x1 with K = 512 or K >= 2048 -3..-14 %, K = 1024 +4 % (stays on K1); strided 1x1 convolutions (forward:
         // gathered input, backward: scattered output) -35 % against the generic-gather kernel.  Split-K for every K >= 512 layer is
         // 0.4 % slower in the timed three-stream schedule (32 KB rings crowd out the other streams' workgroups).
-        if (p.kh == 1 && (p.stride == 2 || p.out_stride == 2)) return 7;
+        if (p.kh == 1 && (p.stride == 2 || p.out_stride == 2 || p.as_strided)) return 7;
         if ((p.kh > 1 && p.K >= 2048) || (p.kh == 1 && (p.K == 512 || p.K >= 2048))) return 7;
     }
     // Deep-K launches of at most two tiles per CU (layer 3/4 of a 32-image batch) prefer 32-deep K-steps: half the barriers
@@ -1336,20 +1336,21 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     {
         // tuning hook (A/B runs of the timed step on one box, tools/ab_env.sh): XFR_CFG_REMAP="4:5,7:6" sends every launch the rules above give
         // configuration 4 to 5 and 7 to 6.  Read once; unset in production.
-        static int remap[32], init = 0;
-        if (!init) {
-            for (int i = 0; i < 32; ++i) remap[i] = i;
+        struct Remap { int v[32]; };
+        static const Remap remap = [] {                        // function-local static: initialised once, thread-safe
+            Remap r;
+            for (int i = 0; i < 32; ++i) r.v[i] = i;
             if (const char* e = getenv("XFR_CFG_REMAP")) {
                 int a = 0, b = 0, n = 0;
                 while (sscanf(e, "%d:%d%n", &a, &b, &n) == 2) {
-                    if (a >= 0 && a < 32 && b >= 0 && b < 32) remap[a] = b;
+                    if (a >= 0 && a < 32 && b >= 0 && b < 32) r.v[a] = b;
                     e += n;
                     if (*e == ',') ++e;
                 }
             }
-            init = 1;
-        }
-        if (p.force_cfg <= 0 && cfg >= 0 && cfg < 32) cfg = remap[cfg];
+            return r;
+        }();
+        if (p.force_cfg <= 0 && cfg >= 0 && cfg < 32) cfg = remap.v[cfg];
     }
     // cfg 8 / 9: the persistent wave-specialised kernel (conv_ws.hip) for 1x1 stride-1 layers whose chain, if any, is compiled
     if ((cfg == 8 || cfg == 9 || cfg == 18 || cfg == 19) && conv_ws_ok(p)) {

@@ -56,6 +56,13 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 const long arow = (long)B * HW, apos = (long)b * HW + hw;
                 const float a = ch.s[0].p0[(long)cs * arow + apos], bb = ch.s[0].p0[(long)(cs + Co) * arow + apos];
                 g = ew_maxhalf_route(src[(long)cs * per_c + r], c < Co ? a : bb, c < Co ? bb : a);
+            } else if (ch.n > 0 && ch.s[0].type == EW_AVGUP_IN) {
+                const EwStep& h = ch.s[0];
+                const int W = h.prior_sb, PW = W >> 1, PHW = HW >> 2;
+                const int ih = hw / W, iw = hw - ih * W;
+                const long arow = ((long)c * B + b) * PHW;
+                g = ew_avgup_pixel(h, src + ((long)c * SB + sb) * PHW, h.p0 ? h.p0 + arow : nullptr, h.p1 ? h.p1 + arow : nullptr,
+                                   h.p2 ? h.p2 + ((long)c * SB + sb) * PHW : nullptr, (ih >> 1) * PW + (iw >> 1), !((ih | iw) & 1), eps);
             } else if (ch.n > 0 && ch.s[0].type == EW_POOL2_IN) {
                 const int W = ch.s[0].action, OW = W >> 1, OHW = HW >> 2;
                 const int ih = hw / W, iw = hw - ih * W;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 else if (st.type == EW_ADDP) g += st.p0[idx];
                 else if (st.type == EW_AFFINE_C) g = __fadd_rn(__fmul_rn(g, st.p0[c]), st.p1[c]);
                 else if (st.type == EW_RELU) g = fmaxf(g, 0.f);
-                else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_MAXHALF_OUT || st.type == EW_POOL2_IN) { }      // applied at the load / compiled epilogues only
+                else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_MAXHALF_OUT || st.type == EW_POOL2_IN || st.type == EW_AVGUP_IN) { }      // applied at the load / compiled epilogues only
                 else {
                     float v = __fadd_rn(__fmul_rn(fmaxf(g, 0.f), st.p0[c]), st.p1[c]);
                     if (st.p2) v = __fadd_rn((st.action & 1) ? fmaxf(st.p2[idx], 0.f) : st.p2[idx], v);
@@ -163,8 +170,10 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
     if (ld.lp[2]) s2 = reinterpret_cast<const float4*>(ld.lp[2])[aidx];
     // chain head EW_POOL2_IN: this thread's four pixels lie in two 2x2 windows of one output row
     const bool head_pool2 = ch.n > 0 && ch.s[0].type == EW_POOL2_IN;
+    // chain head EW_AVGUP_IN: the four pixels (any W: a piece may straddle two rows) take their window's pooled gradient
+    const bool head_avgup = ch.n > 0 && ch.s[0].type == EW_AVGUP_IN;
     unsigned b = 0, hw = pos;
-    if (PRIOR || SBa < SB || head_pool2) { b = pos / (unsigned)HW4; hw = pos - b * (unsigned)HW4; }
+    if (PRIOR || SBa < SB || head_pool2 || head_avgup) { b = pos / (unsigned)HW4; hw = pos - b * (unsigned)HW4; }
     unsigned p2_win = 0, p2_ohw = 0;
     int p2_ph = 0, p2_id0 = 0, p2_id1 = 0;
     if (head_pool2) {
@@ -203,6 +212,21 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel_v4(const float4* __restric
             const float4 gs = src[idx[u] - (long)(c - cs) * per_c];           // the Co-channel gradient, row c % Co
             g[u] = make_float4(ew_maxhalf_route(gs.x, own.x, oth.x), ew_maxhalf_route(gs.y, own.y, oth.y),
                                ew_maxhalf_route(gs.z, own.z, oth.z), ew_maxhalf_route(gs.w, own.w, oth.w));
+        } else if (head_avgup) {
+            const EwStep& h = ch.s[0];
+            const int W = h.prior_sb, PW = W >> 1, PHW = HW4;                  // (H / 2) * (W / 2) = HW / 4
+            const size_t grow = ((size_t)c * SB + (ok[u] ? sb[u] : (int)b)) * PHW, arow = ((size_t)c * B + b) * PHW;
+            const float* gp = reinterpret_cast<const float*>(src) + grow;
+            const float* ap = h.p0 ? h.p0 + arow : nullptr;
+            const float* xp = h.p1 ? h.p1 + arow : nullptr;
+            const float* tp = h.p2 ? h.p2 + grow : nullptr;
+            float r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int px = (int)hw * 4 + q, ih = px / W, iw = px - ih * W;
+                r[q] = ew_avgup_pixel(h, gp, ap, xp, tp, (ih >> 1) * PW + (iw >> 1), !((ih | iw) & 1), eps);
+            }
+            g[u] = make_float4(r[0], r[1], r[2], r[3]);
         } else if (head_pool2) {
             // the gradient of the pooled sum, [C][SB][H/2][W/2]: two windows = one aligned float2
             const float2 go = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(src) + ((size_t)c * SB + (ok[u] ? sb[u] : (int)b)) * p2_ohw + p2_win);

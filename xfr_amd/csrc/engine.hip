@@ -103,6 +103,8 @@ struct BwdStep {
     struct Sym { int type; int action; int t0; int x_t; float f; int op; int slot; bool tap; };
     std::vector<Sym> chain;   // ST_EW: the chain; ST_CONV_BWD: epilogue chain fused into the GEMM (may be empty)
     int ew_t = -1;     // tensor whose shape the chain runs over
+    bool compact = false;   // ST_CONV_BWD of a 1x1 / stride 2 convolution: the result stays on the sampled grid, dense, at the start of dst_t's gradient
+                            // region (the chain head EW_AVGUP_IN of the launch that follows puts it in place)
 };
 
 struct BwdPlan {
@@ -203,6 +205,8 @@ struct xfr_engine {
                                        // BatchNorm], affine, clamp).  Round 3, MI355X: +0.6 % maps/s on ResNet-101, +2.2 % on ResNet-50-128d, bit-identical
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
     bool direct_stem = true;           // Light-CNN's 1-channel 5x5 first layer as a direct convolution (xfr_engine_set_epilogue_fusion bit 4 clear; tests set it)
+    bool fuse_avgup = true;            // down-sampling blocks: slice copy + pooled hook + average-pool VJP + strided GEMM's read-modify-write as the head of the
+                                       // hook chain that follows (EW_AVGUP_IN; xfr_engine_set_epilogue_fusion bit 6 clear)
     bool pair_tiles = true;            // backward chain GEMMs over two streams walk their m-tiles stream-interleaved (xfr_engine_set_epilogue_fusion bit 5 clear)
     bool fuse_pools = true;            // Light-CNN's maxpool + avgpool pair: one forward kernel (xfr_engine_set_epilogue_fusion bit 0 switches it with the rest)
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
@@ -1230,6 +1234,7 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
     auto reads = [&](const BwdStep& b, int t) {
         if (b.kind != ST_ZERO && b.src_t == t) return true;
         for (const Sym& y : b.chain) if (y.type == EW_ADDP && y.t0 == t) return true;
+        for (const Sym& y : b.chain) if (y.type == EW_AVGUP_IN && y.slot == t) return true;      // the compact GEMM result in t's gradient region
         if (b.accumulate && b.dst_t == t) return true;
         return false;
     };
@@ -1324,6 +1329,82 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
     // pass 2: additionally the MaxFeatureMap VJP as a fan-out in the epilogue of the GEMM that produces its gradient
     for (int pass = 0; pass < 3; ++pass) {
     if (pass == 1) plan.fused = st;
+    if (pass == 1 && e->fuse_avgup) {
+        // ---- 2b (GEMM-fused schedules only: no traces, priors or stores there).  Down-sampling residual block, shortcut = AvgPool2d(2) [+ ConcatChannels],
+        // main path entered through a 1x1 / stride 2 convolution (resnet.py:111-149).  Its block-input gradient D was built by five launches:
+        //   COPY S -> P (channel prefix), EW P (the pooled tensor's hook, in place), AVGPOOL_BWD P -> D, ..., CONV_BWD -> D (scatter, read-modify-write),
+        //   EW D -> E (the block input's hook chain).
+        // Now the GEMM leaves its result compact and the last launch builds D's value per pixel in its head (EW_AVGUP_IN): D is never written,
+        // three launches are gone and the GEMM stores rows instead of scattering dwords.
+        for (size_t i0 = 0; i0 < st.size(); ++i0) {
+            const BwdStep cp = st[i0];
+            if (cp.kind != ST_COPY || cp.accumulate || cp.dst_t < 0 || cp.src_t < 0) continue;
+            const int S = cp.src_t, P = cp.dst_t;
+            const Tensor& tp = e->tens[P];
+            if (cp.copy_elems_per_sb != tp.C || e->tens[S].C < tp.C || e->tens[S].H != tp.H || e->tens[S].W != tp.W) continue;
+            auto next_touch = [&](size_t from, int t) {
+                size_t k = from;
+                for (; k < st.size(); ++k)
+                    if (reads(st[k], t) || writes(st[k], t)) break;
+                return k;
+            };
+            size_t i1 = next_touch(i0 + 1, P);
+            if (i1 >= st.size()) continue;
+            Sym hook = mk(EW_AVGUP_IN, -1);
+            hook.action = -1;
+            size_t i2 = i1;
+            if (st[i1].kind == ST_EW) {          // the pooled tensor's hook, in place
+                const BwdStep& h = st[i1];
+                if (h.src_t != P || h.dst_t != P || h.accumulate || h.chain.size() != 1 || h.chain[0].type != EW_HOOK || h.chain[0].tap) continue;
+                hook.action = h.chain[0].action;
+                if (hook.action == HOOK_DIV) { hook.t0 = h.chain[0].t0; hook.x_t = h.chain[0].x_t; }     // otherwise p is not observed in this schedule
+                i2 = next_touch(i1 + 1, P);
+                if (i2 >= st.size()) continue;
+            }
+            const BwdStep av = st[i2];
+            if (av.kind != ST_AVGPOOL_BWD || av.src_t != P || av.accumulate || av.dst_t < 0) continue;
+            const xfr_op_desc& da = e->ops[av.op].d;
+            const int D = av.dst_t;
+            const Tensor& td = e->tens[D];
+            if (da.kh != 2 || da.kw != 2 || da.stride != 2 || da.pad != 0 || td.H != 2 * tp.H || td.W != 2 * tp.W || td.C != tp.C) continue;
+            if (next_touch(i2 + 1, P) < st.size()) continue;          // nobody else wants the pooled gradient
+            const size_t i3 = next_touch(i2 + 1, D);
+            if (i3 >= st.size()) continue;
+            const BwdStep& cv = st[i3];
+            if (cv.kind != ST_CONV_BWD || cv.dst_t != D || !cv.accumulate || !cv.chain.empty()) continue;
+            const xfr_op_desc& dc = e->ops[cv.op].d;
+            if (dc.kh != 1 || dc.kw != 1 || dc.stride != 2 || dc.pad != 0 || dc.in0 != D || e->tens[dc.out].H != tp.H || e->tens[dc.out].W != tp.W) continue;
+            const size_t i4 = next_touch(i3 + 1, D);
+            if (i4 >= st.size()) continue;
+            const BwdStep& ew = st[i4];
+            if (ew.kind != ST_EW || ew.src_t != D || ew.dst_t == D || ew.accumulate || ew.ew_t != D || ew.chain.empty()) continue;
+            if (ew.chain[0].type == EW_MAXHALF_IN || ew.chain[0].type == EW_POOL2_IN || ew.chain[0].type == EW_AVGUP_IN) continue;
+            if ((int)ew.chain.size() + 1 > XFR_MAX_EW_STEPS) continue;
+            bool bad = false;
+            for (const Sym& y : ew.chain)
+                if ((y.type == EW_STORE || y.type == EW_ADDP) && (y.t0 == D || y.t0 == S)) bad = true;
+            if (next_touch(i4 + 1, D) < st.size()) {       // a later reader of D would want the tensor that is no longer written
+                size_t k = next_touch(i4 + 1, D);
+                if (reads(st[k], D)) bad = true;
+            }
+            for (size_t k = i0 + 1; k <= i4 && !bad; ++k)
+                if (writes(st[k], S)) bad = true;            // S is now read where the chain runs
+            if (bad) continue;
+            hook.op = td.W;
+            hook.slot = D;
+            BwdStep f = ew;
+            f.src_t = S;
+            f.chain.insert(f.chain.begin(), hook);
+            st[i4] = f;
+            st[i3].compact = true;
+            st[i3].accumulate = 0;
+            // erase back to front
+            st.erase(st.begin() + i2);
+            if (i1 != i2) st.erase(st.begin() + i1);
+            st.erase(st.begin() + i0);
+            --i0;
+        }
+    }
     if (pass == 2) plan.fused_gemm_nofan = st;
     bool changed = true;
     while (changed) {
@@ -1476,6 +1557,14 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
             case EW_MASK: q.p0 = e->T(sy.t0); break;
             case EW_MAXHALF_IN: q.p0 = e->T(sy.t0); break;
             case EW_POOL2_IN: q.p0 = reinterpret_cast<const float*>(e->idx_base() + e->ops[sy.op].idx_off); break;      // the max-pool's argmax bytes
+            case EW_AVGUP_IN:
+                // sy.action: the pooled tensor's hook (or -1), sy.t0 / sy.x_t: its a / x tensors (-1: not observed / x == a), sy.op: full-res width,
+                // sy.slot: the tensor whose gradient region holds the compact GEMM result (-1: none)
+                q.p0 = sy.t0 >= 0 ? e->T(sy.t0) : nullptr;
+                q.p1 = sy.x_t >= 0 ? e->Pv(sy.x_t) : nullptr;
+                q.p2 = sy.slot >= 0 ? e->G(sy.slot) : nullptr;
+                q.prior_sb = sy.op;
+                break;
             case EW_MAXHALF_OUT: q.p0 = e->T(sy.t0); break;
             case EW_SCALE_C: q.p0 = e->arena + (plain ? e->ops[sy.op].bn_alpha_t : e->ops[sy.op].bn_alpha_p); break;
             case EW_STORE: q.pstore = e->G(sy.t0); break;
@@ -1502,7 +1591,14 @@ void bwd_conv_params(xfr_engine* e, const BwdPlan& plan, const BwdStep& st, int 
     p.CoutTot = a.C; p.nhalves = 1; p.ldw = o.ldb;
     p.K = o.Kb;
     p.accumulate = st.accumulate;
-    if (d.stride == 1) {
+    if (st.compact) {
+        // 1x1 stride-s, result left on the sampled grid (dense rows of t.H x t.W per sample): EW_AVGUP_IN places it
+        p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0;
+        p.OH = t.H; p.OW = t.W;
+        p.out_H = t.H; p.out_W = t.W; p.out_stride = 1;
+        p.accumulate = 0;
+        p.as_strided = 1;
+    } else if (d.stride == 1) {
         // backward-data of a stride-1 convolution == convolution with the flipped, transposed kernel and padding k-1-p
         p.kh = d.kh; p.kw = d.kw; p.stride = 1; p.pad = d.kh - 1 - d.pad;
         p.OH = a.H; p.OW = a.W;
@@ -2133,6 +2229,11 @@ xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
     const bool pools = (enable & 1) != 0 && (enable & 8) == 0;
     if (pools != e->fuse_pools) e->plans.clear();
     e->fuse_pools = pools;
+    {
+        const bool avgup = (enable & 1) != 0 && (enable & 64) == 0;   // bit 6 (tests): the down-sampling blocks' shortcut VJP as separate launches
+        if (avgup != e->fuse_avgup) e->plans.clear();
+        e->fuse_avgup = avgup;
+    }
     e->pair_tiles = (enable & 32) == 0;           // bit 5 (A/B measurements): tile order of the two-stream backward GEMMs as before round 4
     e->direct_stem = (enable & 16) == 0;          // bit 4 (tests): the first layer of Light-CNN through the GEMM like every other convolution
     e->held_x = nullptr;

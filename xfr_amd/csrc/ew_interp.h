@@ -25,6 +25,27 @@ __device__ __forceinline__ float ew_pool2_route(float go, int id, int ph, int pw
     return (id == ph * 2 + pw ? go : 0.f) + go * 0.25f;
 }
 
+// chain head EW_AVGUP_IN: one pixel.  gp / tp: the pooled gradient and the compact GEMM result at this pixel's window (tp only read on the even
+// pixels), ap / xp: the pooled tensor's hook operands at the window (EW_HOOK's arithmetic, one value)
+__device__ __forceinline__ float ew_avgup_pixel(const EwStep& st, const float* __restrict__ gp, const float* __restrict__ ap, const float* __restrict__ xp,
+                                                const float* __restrict__ tp, int pidx, bool on_grid, float eps)
+{
+    float g = gp[pidx];
+    if (st.action == HOOK_RELU && !ap) g = fmaxf(g, 0.f);
+    else if (st.action >= 0 && ap) {
+        const float a = fmaxf(ap[pidx], 0.f);
+        const float zh = fmaxf(g, 0.f);
+        const float pr = a * zh;
+        if (st.action == HOOK_DIV) {
+            const float x = xp ? fmaxf(xp[pidx], 0.f) : a;
+            g = __fdiv_rn(pr, x + eps);
+        } else if (st.action == HOOK_RELU) g = zh;
+    }
+    g = (0.f + g) * 0.25f;                      // avgpool_bwd_kernel: acc = 0; acc += g; acc * (1 / 4)
+    if (on_grid && tp) g = tp[pidx] + g;        // the scattering GEMM's read-modify-write: v = acc + old
+    return g;
+}
+
 // VJP of max(a, b) for the half that holds `own`: all of g to the larger input, half of it on ties (at::maximum backward)
 __device__ __forceinline__ float ew_maxhalf_route(float g, float own, float other)
 {
@@ -130,7 +151,7 @@ __device__ __forceinline__ int ew_steps(int i0, float (&g)[4], long idx, long ai
         } else if (st.type == EW_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = fmaxf(g[q], 0.f);
-        } else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_POOL2_IN) {
+        } else if (st.type == EW_MAXHALF_IN || st.type == EW_MAXPAIR || st.type == EW_POOL2_IN || st.type == EW_AVGUP_IN) {
             // MAXHALF_IN / POOL2_IN were applied where the gradient was loaded; MAXPAIR only exists in compiled epilogues
         } else {
             const float al = st.p0[c], be = st.p1[c];
