@@ -1405,6 +1405,52 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             --i0;
         }
     }
+    if (pass == 2 && e->fuse_avgup) {
+        // ---- 3b (after the GEMM -> chain merges of pass 1).  First block of a stage: the GEMM that produces the gradient of the block's Add output ends [.., STORE(t), relu] -> D, where D (the
+        // shortcut operand's gradient) and t (the main-path operand's) have different readers, and the main path's chain EW(t -> u) starts with the
+        // same relu.  Both then continue from relu(v): the chain runs on in the GEMM's epilogue as [.., relu, STORE(D), rest] -> u -- the signature of
+        // every other block's epilogue -- and the stand-alone launch is gone.
+        for (size_t i = 0; i < st.size(); ++i) {
+            BwdStep& a = st[i];
+            if (a.kind != ST_CONV_BWD || scatter_conv(a) || a.compact || a.accumulate || a.chain.size() < 2 || a.dst_t < 0) continue;
+            const size_t n = a.chain.size();
+            const Sym r1 = a.chain[n - 1], s1 = a.chain[n - 2];
+            auto plain_relu = [](const Sym& y) { return y.type == EW_HOOK && y.action == HOOK_RELU && !y.tap; };
+            if (!plain_relu(r1) || s1.type != EW_STORE) continue;
+            const int t = s1.t0, D = a.dst_t;
+            if (t == D || t < 0) continue;
+            size_t j = i + 1;
+            for (; j < st.size(); ++j)
+                if (reads(st[j], t) || writes(st[j], t)) break;
+            if (j >= st.size()) continue;
+            const BwdStep c = st[j];
+            if (c.kind != ST_EW || c.src_t != t || c.accumulate || c.dst_t == t || c.dst_t == D || c.chain.empty() || !plain_relu(c.chain[0])) continue;
+            if (e->tens[c.ew_t].C != e->tens[D].C || e->tens[c.ew_t].HW() != e->tens[D].HW()) continue;
+            bool bad = false, other_readers = false;
+            for (const Sym& y : c.chain)
+                if ((y.type == EW_STORE || y.type == EW_ADDP) && (y.t0 == D || y.t0 == t)) bad = true;
+            for (size_t k = j + 1; k < st.size(); ++k) {
+                if (reads(st[k], t)) { other_readers = true; break; }
+                if (writes(st[k], t)) break;
+            }
+            const int u = c.dst_t;
+            for (size_t k = i + 1; k < j && !bad; ++k) {
+                if (writes(st[k], u) || reads(st[k], u)) bad = true;
+                for (const Sym& y : c.chain)
+                    if (y.type == EW_ADDP && writes(st[k], y.t0)) bad = true;
+            }
+            if (bad || n - 2 + (other_readers ? 1 : 0) + 1 + c.chain.size() > XFR_MAX_EW_STEPS) continue;
+            std::vector<Sym> merged(a.chain.begin(), a.chain.begin() + (n - 2));
+            if (other_readers) merged.push_back(s1);
+            merged.push_back(c.chain[0]);
+            merged.push_back(mk(EW_STORE, D));
+            merged.insert(merged.end(), c.chain.begin() + 1, c.chain.end());
+            a.chain = merged;
+            a.ew_t = D;
+            a.dst_t = u;
+            st.erase(st.begin() + j);
+        }
+    }
     if (pass == 2) plan.fused_gemm_nofan = st;
     bool changed = true;
     while (changed) {
@@ -2847,6 +2893,8 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     e->max_batch = batch; e->in_c = in_c; e->in_h = in_h; e->in_w = in_w; e->n_weights = n_weights;
     e->mode = subtree_mode;
     e->planning_only = true;
+    // tools/gen_chain_sigs.py lists the chains of the test / A-B fusion levels too (XFR_DESCRIBE_FUSION = an xfr_engine_set_epilogue_fusion value)
+    if (const char* f = getenv("XFR_DESCRIBE_FUSION")) xfr_engine_set_epilogue_fusion(e, atoi(f));
     xfr_status st = build(e, ops, n_ops);
     if (st == XFR_OK) st = layout_arena(e, false);
     if (st == XFR_OK) st = layout_workspace(e);
@@ -2927,6 +2975,10 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
             ew_plan_loads(ch, e->G(b.dst_t), ld, b.kind == ST_CONV_BWD ? EW_FWD_SLOTS_WIDE : EW_FWD_SLOTS_BASE);
             if (b.kind == ST_CONV_BWD) emit_sig(ch);
             else { snprintf(line, sizeof(line), " steps %d", ch.n); out += line; }
+            if (getenv("XFR_DESCRIBE_TYPES")) {
+                out += " types";
+                for (const auto& y : b.chain) { snprintf(line, sizeof(line), " %d:%d:%d", y.type, y.action, y.t0); out += line; }
+            }
         }
         out += "\n";
     }
