@@ -92,9 +92,22 @@ def test_residual_blocks_leave_no_glue_launches():
     prog = PROGRAMS['stresnet101']
     lines = prog.describe('affineonly_with_prior', prog.marks['encode']).splitlines()
     kinds = [ln.split()[1] for ln in lines if ln.startswith('bwd ')]
-    assert kinds.count('COPY') == 4, kinds               # the AvgPool2d(1,1) shortcuts of the four downsample blocks
+    # the slice copy of the stride-1 first block (layer 1) stays; the three down-sampling blocks' copies, pooled hooks, average-pool VJPs and
+    # scattering GEMMs are the head of the block-input chain (EW_AVGUP_IN), and no stand-alone chain follows a first block's Add-output GEMM
+    assert kinds.count('COPY') == 1, kinds
+    assert kinds.count('AVGPOOL_BWD') == 1, kinds        # the global pool in front of the embedding
+    assert kinds.count('EW') == 7, kinds             # seed, top, three block inputs, the layer-1 slice hook, the stem
     m = re.match(r'plan seed_tensor (\d+) mode 1 firings (\d+) launches (\d+)', lines[0])
-    assert int(m.group(3)) <= 124
+    assert int(m.group(3)) <= 111
+    # with the switch off (epilogue-fusion bit 6) the separate launches are back, every GEMM chain still compiled
+    os.environ['XFR_DESCRIBE_FUSION'] = '67'
+    try:
+        lines67 = prog.describe('affineonly_with_prior', prog.marks['encode']).splitlines()
+    finally:
+        del os.environ['XFR_DESCRIBE_FUSION']
+    kinds67 = [ln.split()[1] for ln in lines67 if ln.startswith('bwd ')]
+    assert kinds67.count('COPY') == 4 and kinds67.count('AVGPOOL_BWD') == 4, kinds67
+    assert all('compiled=-1' not in ln for ln in lines67)
 
 
 def test_plan_describe_argument_checks():
