@@ -50,6 +50,8 @@ enum {
                       // src = the pooled tensor's gradient ([C][SB][H/2][W/2]: the first C rows of the concatenated gradient); the hook of the pooled
                       // tensor is EW_HOOK's arithmetic on one value (action = HOOK_* or -1 for none, p0 / p1 its a / x at pooled resolution, null p0:
                       // not observed); prior_sb = W.  Same operands, same operations as the four launches: same bits.
+                      // action = -2: no pooled source -- the tensor was a zero fill plus strided 1x1 GEMMs (projection shortcut + main path,
+                      // resnet50_128.py): g = p2 on the even pixels, 0 elsewhere; the GEMMs accumulate on the compact grid.
     EW_MAXPAIR = 10   // GEMM epilogue only, last step: g = max(g, value of the partner row c ^ 1) -- MaxFeatureMap of a convolution
                       // whose output channels were packed interleaved (row 2c = channel c, row 2c+1 = channel c + Co); the even
                       // rows then store g as channel c of the Co-channel output

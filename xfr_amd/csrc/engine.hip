@@ -1405,6 +1405,60 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             --i0;
         }
     }
+    if (pass == 1 && e->fuse_avgup) {
+        // ---- 2b'.  The same block input where the shortcut is a strided 1x1 projection (resnet50_128.py): ZERO D, CONV_BWD -> D (scatter), ...,
+        // CONV_BWD -> D (scatter), EW D -> E.  Both GEMMs now work on the compact grid (the second accumulates there: dense rows), the zero fill
+        // is gone and the chain's head puts the sum on the even pixels (EW_AVGUP_IN without a pooled source).
+        for (size_t i0 = 0; i0 < st.size(); ++i0) {
+            if (st[i0].kind != ST_ZERO || st[i0].dst_t < 0) continue;
+            const int D = st[i0].dst_t;
+            const Tensor& td = e->tens[D];
+            auto next_touch = [&](size_t from, int t) {
+                size_t k = from;
+                for (; k < st.size(); ++k)
+                    if (reads(st[k], t) || writes(st[k], t)) break;
+                return k;
+            };
+            std::vector<size_t> gemms;
+            size_t k = next_touch(i0 + 1, D);
+            bool ok = true;
+            int gh = -1, gw = -1;
+            while (k < st.size() && st[k].kind == ST_CONV_BWD) {
+                const BwdStep& cv = st[k];
+                const xfr_op_desc& dc = e->ops[cv.op].d;
+                const Tensor& tg = e->tens[dc.out];
+                if (cv.dst_t != D || !cv.accumulate || !cv.chain.empty() || dc.kh != 1 || dc.kw != 1 || dc.stride != 2 || dc.pad != 0 || dc.in0 != D ||
+                    td.H != 2 * tg.H || td.W != 2 * tg.W || (gh >= 0 && (gh != tg.H || gw != tg.W))) { ok = false; break; }
+                gh = tg.H; gw = tg.W;
+                gemms.push_back(k);
+                k = next_touch(k + 1, D);
+            }
+            if (!ok || gemms.empty() || k >= st.size()) continue;
+            const BwdStep& ew = st[k];
+            if (ew.kind != ST_EW || ew.src_t != D || ew.dst_t == D || ew.accumulate || ew.ew_t != D || ew.chain.empty()) continue;
+            if (ew.chain[0].type == EW_MAXHALF_IN || ew.chain[0].type == EW_POOL2_IN || ew.chain[0].type == EW_AVGUP_IN) continue;
+            if ((int)ew.chain.size() + 1 > XFR_MAX_EW_STEPS) continue;
+            bool bad = false;
+            for (const Sym& y : ew.chain)
+                if ((y.type == EW_STORE || y.type == EW_ADDP) && y.t0 == D) bad = true;
+            {
+                const size_t k2 = next_touch(k + 1, D);
+                if (k2 < st.size() && reads(st[k2], D)) bad = true;
+            }
+            if (bad) continue;
+            Sym head = mk(EW_AVGUP_IN, -1);
+            head.action = -2;
+            head.op = td.W;
+            head.slot = D;
+            st[k].chain.insert(st[k].chain.begin(), head);
+            for (size_t q = 0; q < gemms.size(); ++q) {
+                st[gemms[q]].compact = true;
+                st[gemms[q]].accumulate = q == 0 ? 0 : 1;
+            }
+            st.erase(st.begin() + i0);
+            --i0;
+        }
+    }
     if (pass == 2 && e->fuse_avgup) {
         // ---- 3b (after the GEMM -> chain merges of pass 1).  First block of a stage: the GEMM that produces the gradient of the block's Add output ends [.., STORE(t), relu] -> D, where D (the
         // shortcut operand's gradient) and t (the main-path operand's) have different readers, and the main path's chain EW(t -> u) starts with the
@@ -1642,7 +1696,7 @@ void bwd_conv_params(xfr_engine* e, const BwdPlan& plan, const BwdStep& st, int 
         p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0;
         p.OH = t.H; p.OW = t.W;
         p.out_H = t.H; p.out_W = t.W; p.out_stride = 1;
-        p.accumulate = 0;
+        p.accumulate = st.accumulate;           // a second strided GEMM onto the same tensor adds to the first one's rows
         p.as_strided = 1;
     } else if (d.stride == 1) {
         // backward-data of a stride-1 convolution == convolution with the flipped, transposed kernel and padding k-1-p

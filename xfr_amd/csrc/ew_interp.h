@@ -30,6 +30,7 @@ __device__ __forceinline__ float ew_pool2_route(float go, int id, int ph, int pw
 __device__ __forceinline__ float ew_avgup_pixel(const EwStep& st, const float* __restrict__ gp, const float* __restrict__ ap, const float* __restrict__ xp,
                                                 const float* __restrict__ tp, int pidx, bool on_grid, float eps)
 {
+    if (st.action == -2) return on_grid ? tp[pidx] : 0.f;      // no pooled source (both contributions are strided GEMMs): the zero fill + scatters
     float g = gp[pidx];
     if (st.action == HOOK_RELU && !ap) g = fmaxf(g, 0.f);
     else if (st.action >= 0 && ap) {
