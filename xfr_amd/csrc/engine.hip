@@ -1252,8 +1252,21 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             // readers use the alias
             if (b.kind != ST_ZERO && b.src_t >= 0 && alias[b.src_t] >= 0) b.src_t = alias[b.src_t];
             const int d = b.dst_t;
-            if (b.kind == ST_COPY && !b.accumulate && d >= 0 && e->tens[d].C == e->tens[b.src_t].C &&
-                b.copy_elems_per_sb == e->tens[d].C) {
+            // ... or a channel-prefix slice (ConcatChannels VJP: rows [0, C_d) of the source, same row stride) whose first toucher is the in-place hook
+            // flush of d: that launch then reads the source's rows directly
+            const bool full_copy = b.kind == ST_COPY && d >= 0 && e->tens[d].C == e->tens[b.src_t].C && b.copy_elems_per_sb == e->tens[d].C;
+            bool prefix_copy = false;
+            if (b.kind == ST_COPY && !b.accumulate && d >= 0 && !full_copy && e->fuse_avgup && e->tens[b.src_t].C > e->tens[d].C &&
+                b.copy_elems_per_sb == e->tens[d].C && e->tens[b.src_t].HW() == e->tens[d].HW()) {
+                for (size_t j = i + 1; j < st.size(); ++j) {
+                    const BwdStep& c = st[j];
+                    if (c.dst_t == d || (c.kind != ST_ZERO && c.src_t == d) || writes(c, b.src_t)) {
+                        prefix_copy = c.kind == ST_EW && c.src_t == d && c.dst_t == d && !c.accumulate && !writes(c, b.src_t);
+                        break;
+                    }
+                }
+            }
+            if (b.kind == ST_COPY && !b.accumulate && d >= 0 && (full_copy || prefix_copy)) {
                 // forward only if every later accumulating writer of d can take an addend in its chain
                 bool ok = true;
                 bool later_writer = false, later_reader = false;
@@ -1338,10 +1351,13 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
         // three launches are gone and the GEMM stores rows instead of scattering dwords.
         for (size_t i0 = 0; i0 < st.size(); ++i0) {
             const BwdStep cp = st[i0];
-            if (cp.kind != ST_COPY || cp.accumulate || cp.dst_t < 0 || cp.src_t < 0) continue;
+            // (the slice copy may already have been forwarded into the pooled tensor's hook launch: EW S -> P, one hook)
+            const bool fwd_hook = cp.kind == ST_EW && cp.src_t != cp.dst_t && cp.chain.size() == 1 && cp.chain[0].type == EW_HOOK && !cp.chain[0].tap &&
+                                  cp.ew_t == cp.dst_t;
+            if ((cp.kind != ST_COPY && !fwd_hook) || cp.accumulate || cp.dst_t < 0 || cp.src_t < 0) continue;
             const int S = cp.src_t, P = cp.dst_t;
             const Tensor& tp = e->tens[P];
-            if (cp.copy_elems_per_sb != tp.C || e->tens[S].C < tp.C || e->tens[S].H != tp.H || e->tens[S].W != tp.W) continue;
+            if ((cp.kind == ST_COPY && cp.copy_elems_per_sb != tp.C) || e->tens[S].C < tp.C || e->tens[S].H != tp.H || e->tens[S].W != tp.W) continue;
             auto next_touch = [&](size_t from, int t) {
                 size_t k = from;
                 for (; k < st.size(); ++k)
@@ -1353,7 +1369,10 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             Sym hook = mk(EW_AVGUP_IN, -1);
             hook.action = -1;
             size_t i2 = i1;
-            if (st[i1].kind == ST_EW) {          // the pooled tensor's hook, in place
+            if (fwd_hook) {
+                hook.action = cp.chain[0].action;
+                if (hook.action == HOOK_DIV) { hook.t0 = cp.chain[0].t0; hook.x_t = cp.chain[0].x_t; }
+            } else if (st[i1].kind == ST_EW) {          // the pooled tensor's hook, in place
                 const BwdStep& h = st[i1];
                 if (h.src_t != P || h.dst_t != P || h.accumulate || h.chain.size() != 1 || h.chain[0].type != EW_HOOK || h.chain[0].tap) continue;
                 hook.action = h.chain[0].action;
