@@ -5,6 +5,7 @@ truncated triplet EBP from averaged unit-norm encodings, weighted-subtree EBP wi
 with the ebp_version 8 / 9 / 10 parameterisations (uint8 saliency path).
 
 CPU part: the oracle behind the same caller functions.  GPU part: the HIP engine behind them."""
+import os
 import types
 
 import numpy as np
@@ -65,8 +66,17 @@ def test_convert_from_numpy_matches_reference_preprocessing():
     # preprocess_loader (whitebox.py:808-825), in-memory branch of image_loader: (image, tensor[3,H,W], fn=None)
     items = list(WB.Whitebox.preprocess_loader(wb, [probe, f]))
     assert len(items) == 2 and items[0][2] is None and torch.equal(items[0][1], want[0]) and items[1][0] is f
+    # file-name branch (utils.py:86-90): decode, / 255, centre crop (the identity on a 224 x 224 file), then the float path above
+    import tempfile
+    import PIL.Image
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, 'probe.png')
+        PIL.Image.fromarray(probe).save(fn)
+        items = list(WB.Whitebox.preprocess_loader(wb, [fn]))
+    assert len(items) == 1 and items[0][2] == fn and np.array_equal(items[0][0], f)
+    assert torch.equal(items[0][1], convert_resnet101v4_image((f * 255).astype(np.uint8)))
     with pytest.raises(NotImplementedError):
-        list(WB.Whitebox.preprocess_loader(wb, ['some_file.jpg']))
+        list(WB.Whitebox.preprocess_loader(wb, [42]))
 
 
 def _check_r101(wb, gold, mode, key_check):

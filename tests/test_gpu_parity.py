@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI (ctypes -> libxfr_amd.so);
 the HIP engine is compared with the golden vectors captured from the real reference and with the CPU oracle."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -110,6 +111,23 @@ def test_embeddings_and_mean_ebp(gpu_device):
     assert emb.shape == (5, 512) and np.abs(emb - want).max() <= 1e-5
     emb2 = wb.embeddings([xi.numpy() for xi in x], norm=False)
     assert np.abs(emb2 - ow.encode(x).numpy()).max() <= 1e-4 * np.abs(emb2).max()
+    # file names / a DataFrame (whitebox.py:752-766 through image_loader + convert_from_numpy): the same encodings as the arrays they hold
+    import tempfile
+    import PIL.Image
+    import pandas as pd
+    rs = np.random.RandomState(5)
+    pics = [rs.randint(0, 256, size=(224, 224, 3)).astype(np.uint8) for _ in range(3)]
+    with tempfile.TemporaryDirectory() as d:
+        fns = []
+        for i, pic in enumerate(pics):
+            fns.append(os.path.join(d, 'im%d.png' % i))
+            PIL.Image.fromarray(pic).save(fns[-1])
+        e_files = wb.embeddings(fns, norm=False)
+        e_frame = wb.embeddings(pd.DataFrame([{'Filename': f, 'SubjectID': str(i)} for i, f in enumerate(fns)]), norm=False)
+    xt = torch.cat([wb.convert_from_numpy(pic.astype(float) / 255) for pic in pics])
+    e_want = ow.encode(xt).numpy()
+    assert e_files.shape == (3, 512) and np.array_equal(e_files, e_frame)
+    assert np.abs(e_files - e_want).max() <= 1e-4 * np.abs(e_want).max()
     ones = torch.ones((1, 11))
     got = wb.ebp(x[:1], ones)                            # mean EBP saliency
     assert_map_close_robust(got, ow.ebp(x[:1], ones), 'mean_ebp')

@@ -24,6 +24,13 @@ from .lightcnn import lightcnn_preprocess
 from .resnet import convert_resnet101v4_image
 
 
+def _is_dataframe(obj):
+    """pandas.DataFrame without importing pandas unless the caller already did (whitebox.py:752)."""
+    import sys
+    pd = sys.modules.get('pandas')
+    return pd is not None and isinstance(obj, pd.DataFrame)
+
+
 class _TripletClassifier(object):
     """Stand-in for the nn.Linear(D, 2, bias=False) that set_triplet_classifier installs
     (whitebox.py:95-96,123-124,220).  It is created after hook registration, hence un-hooked."""
@@ -558,16 +565,19 @@ class Whitebox(object):
         return self.net.encode(x)
 
     def embeddings(self, images, norm=True):
-        """whitebox.py:747-785 for tensors / numpy arrays already in network format."""
-        if isinstance(images[0], torch.Tensor):
+        """whitebox.py:747-785: tensors / numpy arrays already in network format, or -- through xfr_amd.image_loader, the restatement of
+        xfr.utils.image_loader -- an inpainting-game DataFrame or a list of file names / H x W x 3 arrays."""
+        from ..image_loader import image_loader
+        if _is_dataframe(images):
+            imagesT = [self.convert_from_numpy(im)[0] for im in image_loader(images)]
+        elif isinstance(images[0], torch.Tensor):
             assert images[0].ndim == 3
             imagesT = images
         elif isinstance(images[0], np.ndarray):
             assert images[0].shape[0] in (1, 3)
             imagesT = [torch.from_numpy(im).float() for im in images]
         else:
-            raise NotImplementedError('embeddings(): DataFrame / file inputs go through xfr.utils.image_loader, '
-                                      'which is outside the hot path')
+            imagesT = [self.convert_from_numpy(im)[0] for im in image_loader(images)]
         if not isinstance(imagesT, torch.Tensor):
             imagesT = torch.stack(list(imagesT))
         batches = torch.split(imagesT, self.batch_size, dim=0)
@@ -598,13 +608,9 @@ class Whitebox(object):
 
     def preprocess_loader(self, images, returnImageIndex=False, repeats=1):
         """whitebox.py:808-825: iterate (displayable image, tensor, fn) over `images`.  The reference pulls the images through
-        xfr.utils.image_loader, which also reads files and DataFrames; that loader (and its face cropping) is outside the hot
-        path, so only the in-memory branch is provided: H x W x 3 arrays (xfr/utils.py:82-85: fn is None for those)."""
+        xfr.utils.image_loader (here: xfr_amd.image_loader): H x W x 3 arrays (fn is None for those), file names, DataFrames."""
+        from ..image_loader import image_loader
         if returnImageIndex or repeats != 1:
             raise NotImplementedError('preprocess_loader: the reference itself only unpacks (image, fn) pairs (whitebox.py:817)')
-        for im in images:
-            if not isinstance(im, np.ndarray):
-                raise NotImplementedError('preprocess_loader(): file names / DataFrames go through xfr.utils.image_loader, '
-                                          'which is outside the hot path')
-            assert im.ndim == 3 and im.shape[2] == 3
-            yield im, self.convert_from_numpy(im)[0], None
+        for im, fn in image_loader(images, returnFileName=True):
+            yield im, self.convert_from_numpy(im)[0], fn
