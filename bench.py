@@ -221,7 +221,6 @@ def make_workload(args, dev, rank, cpu_only=False):
     from xfr_amd import shard, synth
     W = Workload()
     W.model = args.model
-    W.replicas = 1
     sd_holder = {}
     if not cpu_only:
         from xfr_amd.engine import Engine
@@ -296,15 +295,7 @@ def make_workload(args, dev, rank, cpu_only=False):
         xs = synth.synth_images(B, (1, 128, 128), seed=1234 + rank, scale255=False)
         if not cpu_only:
             prog = bb.build_program()
-            # Two engine replicas of B / 2 images on their own streams: Light-CNN's 61 large launches per step leave the chip without a GEMM for
-            # 9 % of a two-stream step; four streams fill that (+3.6 %, profiles/r4/experiments/replica_probe.txt).  The ResNets lose 1-8 % when
-            # their batch is halved, so they keep one engine.  --serial (the one-stream schedule of the profiler legs) runs one engine.
-            W.replicas = int(getattr(args, 'replicas', None) or (1 if getattr(args, 'serial', False) else 2))
-            if W.replicas > 1:
-                from xfr_amd.engine import EngineReplicas
-                eng = EngineReplicas(prog, B, dev, replicas=W.replicas)
-            else:
-                eng = Engine(prog, B, dev)
+            eng = Engine(prog, B, dev)
             x = xs.to(dev)
             seed = torch.zeros((1, B, 80013), device=dev)
             seed[0, :, 0] = 1.0
@@ -320,8 +311,6 @@ def make_workload(args, dev, rank, cpu_only=False):
         W.flop_per_unit = 3 * F_FWD['lightcnn']
         W.metric = 'EBP saliency maps/sec, Light-CNN-29v2 128x128 (80013-way hooked classifier)'
         W.work = 'Light-CNN-29v2 excitation backprop, batch=%d synthetic images per GPU, mode %s' % (B, W.mode)
-        if not cpu_only and W.replicas > 1:
-            W.work += ' (%d engine replicas of %d images on concurrent streams)' % (W.replicas, -(-B // W.replicas))
         W.fixture = None
         W.pmc_tag = '_lcnn' if (B == 128 and W.mode == 'affineonly') else None
         W.cpu_what = 'Light-CNN-29v2 ebp call(s) over the 80013-way classifier'
@@ -454,7 +443,6 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=None, help='triplets (Light-CNN: images) per GPU per step; default: the BASELINE.json batch of the model')
     ap.add_argument('--mode', default=None)
-    ap.add_argument('--replicas', type=int, default=None, help='--model lightcnn: engine replicas that share a step\'s batch on concurrent streams (default 2; 1 with --serial)')
     ap.add_argument('--model', default='resnet101', choices=['resnet101', 'resnet50_128', 'lightcnn'],
                     help='resnet101 = the BASELINE.json headline; the other two are its secondary configurations')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -605,11 +593,6 @@ def main():
             roof['frac_of_sustained'] = achieved / roof['peak_sustained']
         if W.pmc_tag is not None:
             roof.update(pmc_traffic(ROOT, W.pmc_tag))
-            reps = getattr(W, 'replicas', 1)
-            if reps > 1 and roof.get('traffic') is not None:
-                # the PMC passes run --serial = ONE engine at the full batch; the timed schedule launches every layer once per replica at 1 / R of it
-                roof['traffic'] /= reps
-                roof['traffic_unit'] += '; PMC passes: one engine at the full batch, divided by the %d replicas of the timed schedule' % reps
         if args.timeline_json:
             json.dump(tl, open(args.timeline_json, 'w'), indent=1)
         # the same launches with the elementwise epilogues un-fused (convolution work only): reference figure for the MFMA

@@ -187,53 +187,6 @@ def test_fresh_inputs_are_safe_under_pipelining(gpu_device):
     eng.close()
 
 
-def test_engine_replicas_equal_single_engine_parts(gpu_device):
-    """EngineReplicas (engine.py): a batch cut into R parts on R engines / streams returns, bit for bit, what ONE engine returns for each part as a
-    batch of its own -- in the plain mode, pipelined with resident inputs over several calls, and in profile mode (parts one after the other).
-    Ragged: 7 images over 2 replicas = 4 + 3; the replicas received their parameters by copying replica 0's arena."""
-    from xfr_amd.engine import Engine, EngineReplicas
-    bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=5)
-    prog = bb.build_program()
-    cls_t = prog.marks['classify']
-    one = Engine(prog, 4, gpu_device)
-    one.load_weights(sd)
-    one.set_mode('affineonly_with_prior')
-    rep = EngineReplicas(prog, 7, gpu_device, replicas=2)
-    rep.load_weights(sd)
-    rep.set_mode('affineonly_with_prior')
-    assert rep.part == 4 and torch.equal(rep.engines[1].weight_arena(), one.weight_arena())
-    xs = [make_images('stresnet_mini', 7, seed=s).to(gpu_device) for s in (1, 2)]
-    seeds = []
-    for s in (1, 2):
-        sd_ = torch.zeros((1, 7, 5), device=gpu_device)
-        sd_[0, torch.arange(7), torch.arange(7) % 5] = 1.0 + s
-        seeds.append(sd_)
-    torch.cuda.synchronize()
-    want = []
-    for x, sd_ in zip(xs, seeds):
-        parts = [one.ebp(x[lo:hi], cls_t, sd_[:, lo:hi], want_mwp=True) for lo, hi in ((0, 4), (4, 7))]
-        want.append((torch.cat([m for m, _ in parts], dim=1).clone(), torch.cat([q for _, q in parts], dim=1).clone()))
-    for pipeline, ready in ((0, False), (2, True), (2, False)):
-        rep.set_pipeline(pipeline)
-        for _ in range(3):
-            got = [rep.ebp(x, cls_t, sd_, want_mwp=True, inputs_ready=ready) for x, sd_ in zip(xs, seeds)]
-            torch.cuda.synchronize()
-            for (m, q), (wm, wq) in zip(got, want):
-                assert m.shape == (1, 7) + tuple(wm.shape[2:]) and torch.equal(m, wm) and torch.equal(q, wq)
-    rep.set_pipeline(0)
-    rep.set_profile(True)
-    m, q = rep.ebp(xs[0], cls_t, seeds[0], want_mwp=True)
-    ms, n_launch, fl = rep.get_profile()
-    rep.set_profile(False)
-    assert torch.equal(m, want[0][0]) and n_launch > 0 and fl > 0 and ms > 0
-    sal = rep.mwp_to_saliency(q[0])
-    assert sal.shape == (7,) + tuple(q.shape[2:]) and bool(torch.isfinite(sal).all().item())
-    with pytest.raises(ValueError):
-        rep.ebp(torch.zeros((8, 3, 224, 224), device=gpu_device), cls_t, torch.zeros((1, 8, 5), device=gpu_device))
-    rep.close()
-    one.close()
-
-
 # ---- multi-rank --------------------------------------------------------------------------------------------------------
 def _run_ranks(cmd, world, port, extra_env=None, timeout=900):
     """world processes on ONE GPU (gloo rendezvous on 127.0.0.1): the multi-process code path of the tools without an 8-GPU node."""

@@ -359,133 +359,3 @@ class Engine(object):
         _lib.check(self.lib.xfr_engine_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
         return ms.value, n.value, fl.value
 
-
-
-class EngineReplicas(object):
-    """R engines of ONE backbone on ONE device, each on its own caller-side stream (plus its own internal forward streams): a batch is cut into R
-    contiguous parts whose sweeps run concurrently.  The parts are independent images -- the reference's own multi-GPU generator shards its
-    work the same way, one process per part (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:193-216) -- so part r's maps are
-    bit-for-bit what a single engine returns for those images as a batch of their own.
-
-    When it pays (measured on one MI355X, tools/replica_probe.py, profiles/r4/experiments/replica_probe.txt): Light-CNN-29v2 EBP at 128 images
-    per step runs 61 large launches on two streams and has NO GEMM in flight for 9 % of the step; two replicas of 64 fill those gaps: +3.6 %.
-    The ResNets' grids are too small to halve (ResNet-50-128d -1 %, ResNet-101 -8 %): keep one engine there.  The cost is one more copy of the
-    packed parameters per replica; activations and gradients are per image, so they do not grow.
-
-    The handle offers the subset of `Engine` a batched sweep needs; everything else is reached through `.engines[r]`."""
-
-    def __init__(self, program, max_batch, device, replicas=2):
-        if int(replicas) < 1:
-            raise ValueError('replicas must be >= 1')
-        self.replicas = int(replicas)
-        self.max_batch = int(max_batch)
-        self.part = -(-self.max_batch // self.replicas)            # images per replica (the last part may be shorter)
-        self.engines = [Engine(program, self.part, device) for _ in range(self.replicas)]
-        self.device = self.engines[0].device
-        self.program = program
-        with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream(self.device) for _ in range(self.replicas)]
-        self.lib = self.engines[0].lib
-
-    def close(self):
-        for e in self.engines:
-            e.close()
-
-    # -- parameters: replica 0 packs (or receives the broadcast), the others copy its arena device-to-device -------------------------
-    def load_weights(self, state_dict):
-        self.engines[0].load_weights(state_dict)
-        self.sync_replicas()
-
-    def weight_arena(self):
-        return self.engines[0].weight_arena()
-
-    def mark_weights_loaded(self):
-        self.engines[0].mark_weights_loaded()
-        self.sync_replicas()
-
-    def sync_replicas(self):
-        src = self.engines[0].weight_arena()
-        for e in self.engines[1:]:
-            e.weight_arena().copy_(src)
-            e.mark_weights_loaded()
-        torch.cuda.current_stream(self.device).synchronize()
-
-    # -- switches: the same on every replica ------------------------------------------------------------------------------------------
-    def _all(self, name, *a, **k):
-        for e in self.engines:
-            getattr(e, name)(*a, **k)
-
-    def set_mode(self, *a, **k):
-        self._all('set_mode', *a, **k)
-
-    def set_pipeline(self, on):
-        self._all('set_pipeline', on)
-
-    def set_epilogue_fusion(self, on):
-        self._all('set_epilogue_fusion', on)
-
-    def set_tail_balance(self, on):
-        self._all('set_tail_balance', on)
-
-    def set_persistent_gemm(self, level):
-        self._all('set_persistent_gemm', level)
-
-    def set_profile(self, on):
-        """Per-launch HIP events (Engine.set_profile).  While on, the parts run one after the other on the caller's stream: the one-stream
-        schedule a profiler can attribute, like a single engine's."""
-        self._profile = bool(on)
-        self._all('set_profile', on)
-
-    def get_profile(self):
-        """(GEMM ms, GEMM launches, executed GEMM FLOPs) of the last call, summed over the parts."""
-        rows = [e.get_profile() for e in self.engines]
-        return tuple(sum(r[i] for r in rows) for i in range(3))
-
-    def tensor_shape(self, tid):
-        return self.engines[0].tensor_shape(tid)
-
-    def memory(self):
-        m = [e.memory() for e in self.engines]
-        return sum(a for a, _ in m), sum(b for _, b in m)
-
-    def mwp_to_saliency(self, pooled):
-        return self.engines[0].mwp_to_saliency(pooled)
-
-    # -- the sweep --------------------------------------------------------------------------------------------------------------------
-    def _parts(self, n):
-        return [(lo, min(n, lo + self.part)) for lo in range(0, n, self.part)]
-
-    def ebp(self, x, seed_tensor, seed, want_mwp=False, want_pooled=True, inputs_ready=False):
-        """`Engine.ebp` over R concurrent parts: seed S x N x D -> (mwp S x N x C1 x H1 x W1 or None, pooled S x N x H1 x W1 or None).
-        inputs_ready: x AND seed are resident and valid on the device (nothing pending on the caller's stream): the replicas' streams then
-        do not wait for the caller's stream and part r's sweep of call i+1 queues directly behind part r's sweep of call i."""
-        n = x.shape[0]
-        if n > self.max_batch:
-            raise ValueError('batch %d exceeds max_batch %d' % (n, self.max_batch))
-        if getattr(self, '_profile', False):
-            outs = [e.ebp(x[lo:hi], seed_tensor, seed[:, lo:hi], want_mwp=want_mwp, want_pooled=want_pooled)
-                    for (lo, hi), e in zip(self._parts(n), self.engines)]
-            return (torch.cat([m for m, _ in outs], dim=1) if want_mwp else None,
-                    torch.cat([p for _, p in outs], dim=1) if want_pooled else None)
-        cur = torch.cuda.current_stream(self.device)
-        ready = bool(inputs_ready) and x.is_cuda and seed.is_cuda
-        fork = None
-        if not ready:
-            fork = torch.cuda.Event()
-            fork.record(cur)
-        outs = []
-        for (lo, hi), e, s in zip(self._parts(n), self.engines, self.streams):
-            if fork is not None:
-                s.wait_event(fork)
-            with torch.cuda.stream(s):
-                m, p = e.ebp(x[lo:hi], seed_tensor, seed[:, lo:hi], want_mwp=want_mwp, want_pooled=want_pooled, inputs_ready=ready)
-            for t in (m, p):
-                if t is not None:
-                    t.record_stream(cur)          # consumed on the caller's stream below
-            outs.append((m, p))
-            done = torch.cuda.Event()
-            done.record(s)
-            cur.wait_event(done)
-        mwp = torch.cat([m for m, _ in outs], dim=1) if want_mwp else None
-        pooled = torch.cat([p for _, p in outs], dim=1) if want_pooled else None
-        return mwp, pooled
