@@ -240,7 +240,9 @@ xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
  * gradient of a down-sampling residual block (shortcut AvgPool2d(2) [+ ConcatChannels], main path through a 1x1 / stride 2 convolution:
  * resnet.py:111-149) is built per pixel in the head of the hook chain that consumes it (EW_AVGUP_IN) from the pooled gradient and the
  * compact result of the strided GEMM, instead of by a slice copy, a hook launch, the pool's VJP and a read-modify-write scatter: same
- * operands, same operations, same bits; bit 6 (tests) keeps the separate launches. */
+ * operands, same operations, same bits; bit 6 (tests) keeps the separate launches.  Where the shortcut is a projection (resnet50_128.py), the
+ * main path's hook chain of that block runs as a side branch of the Add-output GEMM's epilogue (the gradient is saved, the branch stored, the saved
+ * value restored for the shortcut's chain) instead of as a launch of its own: same operations on the same operands; bit 7 (tests) keeps the launch. */
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable);
 
 /* Share one forward pass between consecutive calls on the same input (off by default).  While hold = 1, a run call

@@ -110,6 +110,27 @@ def test_residual_blocks_leave_no_glue_launches():
     assert all('compiled=-1' not in ln for ln in lines67)
 
 
+def test_projection_shortcut_blocks_branch_in_the_gemm_epilogue():
+    """ResNet-50-128d (projection shortcuts): the main path's hook chain of a stage's first block runs as a side branch of the Add-output GEMM's
+    epilogue (EW_STORE actions 1 / 2, fuse_plan 3c): 60 backward launches, no stand-alone two-step chain, every chain compiled; with the switch
+    off (epilogue-fusion bit 7) the four launches are back, still compiled."""
+    prog = PROGRAMS['resnet50_128']
+    for mode in ('norelu', 'affineonly', 'affineonly_with_prior', 'all'):
+        lines = prog.describe(mode, prog.marks['encode'], batch=64).splitlines()
+        m = re.match(r'plan seed_tensor (\d+) mode (\d) firings (\d+) launches (\d+)', lines[0])
+        assert int(m.group(4)) == 60, lines[0]
+        bwd = [ln for ln in lines if ln.startswith('bwd ')]
+        assert not [ln for ln in bwd if ln.split()[1] == 'EW' and ln.rstrip().endswith('steps 2')], mode
+        assert all('compiled=-1' not in ln for ln in lines), mode
+    os.environ['XFR_DESCRIBE_FUSION'] = '131'
+    try:
+        lines131 = prog.describe('norelu', prog.marks['encode'], batch=64).splitlines()
+    finally:
+        del os.environ['XFR_DESCRIBE_FUSION']
+    assert ' launches 64 ' in lines131[0] and all('compiled=-1' not in ln for ln in lines131)
+    assert len([ln for ln in lines131 if ln.startswith('bwd EW') and ln.rstrip().endswith('steps 2')]) == 4
+
+
 def test_plan_describe_argument_checks():
     lib = _lib.load()
     prog = PROGRAMS['stresnet_mini']

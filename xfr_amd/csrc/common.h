@@ -21,7 +21,9 @@ enum {
     EW_MASK = 1,      // g = p0[a] > 0 ? g : 0                      (in-place ReLU VJP)
     EW_SCALE_C = 2,   // g *= p0[c]                                 (BatchNorm VJP with relu(gamma)*invstd)
     EW_SCALE = 3,     // g *= f                                     (Multiply VJP)
-    EW_STORE = 4,     // pstore[g] = g
+    EW_STORE = 4,     // pstore[g] = g.  action 1: no store -- SAVE g (a branch point); action 2: pstore[g] = g, then g = the saved value: the steps
+                      // between a save and its store-restore are a side BRANCH of the chain (GEMM epilogues: the main path's hook chain of a
+                      // projection-shortcut block next to the shortcut's, resnet50_128.py; one save per chain)
     EW_ADDP = 5,      // g += p0[g]                                 (gradient fan-in / residual add)
     EW_AFFINE_C = 6,  // g = g*p0[c] + p1[c]                        (eval BatchNorm forward)
     EW_RELU = 7,      // g = max(g, 0)
@@ -197,7 +199,7 @@ inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
             case EW_MASK: op = SIG_MASK; s0 = slot(st.ls0); break;
             case EW_SCALE_C: op = SIG_SCALE_C; break;
             case EW_SCALE: op = SIG_SCALE; break;
-            case EW_STORE: op = SIG_STORE; break;
+            case EW_STORE: op = SIG_STORE; if (st.action == 1 || st.action == 2) s0 = (unsigned)st.action; break;     // s0: 7 plain, 1 save, 2 store + restore
             case EW_ADDP: op = SIG_ADDP; s0 = slot(st.ls0); break;
             case EW_AFFINE_C: op = SIG_AFFINE_C; break;
             case EW_RELU: op = SIG_RELU; break;

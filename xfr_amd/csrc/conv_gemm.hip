@@ -101,7 +101,8 @@ __device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& 
         }
         if constexpr (sig_has_fanout<SIG>()) { ops[hf].out4 = out4; ops[hf].row4 = row4; ops[hf].arow4 = arow4; }
         if (ok[hf]) {
-            epi_steps<SIG, 0>(g, ops[hf], p.chain, idx4[hf], aidx4[hf], p.chain_eps);
+            float sv[4] = {0.f, 0.f, 0.f, 0.f};
+            epi_steps<SIG, 0>(g, sv, ops[hf], p.chain, idx4[hf], aidx4[hf], p.chain_eps);
             if constexpr (sig_has_fanout<SIG>()) {
                 // stored by the fan-out
             } else if constexpr (sig_has_maxpair<SIG>()) {
@@ -296,7 +297,7 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int hf = 0; hf < 4; ++hf) {
-                    float g[4], pv0[4], pv1[4], pv2[4], pv3[4];
+                    float g[4], pv0[4], pv1[4], pv2[4], pv3[4], sv[4] = {0.f, 0.f, 0.f, 0.f};
                     int gi[4], ai[4];
                     bool ok[4];
 #pragma unroll
@@ -369,8 +370,11 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
                             for (int e8 = 0; e8 < 4; ++e8) g[e8] *= st.f;
                         } else if (type == EW_STORE) {
 #pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8)
+                            for (int e8 = 0; e8 < 4; ++e8) {
+                                if (st.action == 1) { sv[e8] = g[e8]; continue; }
                                 if (ok[e8]) st.pstore[gi[e8]] = g[e8];
+                                if (st.action == 2) g[e8] = sv[e8];
+                            }
                         } else if (type == EW_ADDP) {
 #pragma unroll
                             for (int e8 = 0; e8 < 4; ++e8)

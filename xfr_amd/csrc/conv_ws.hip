@@ -273,7 +273,8 @@ __device__ __forceinline__ void ws_chain_piece(const ConvParams& p, const WsPiec
         ops.co_idx4 = (q.co & 1) ? ~0u : (unsigned)(q.co >> 1) * row4 + mm4;
     }
     if constexpr (sig_has_fanout<SIG>()) { ops.out4 = out4; ops.row4 = row4; ops.arow4 = arow4; }
-    epi_steps<SIG, 0>(g, ops, p.chain, q.idx4, q.aidx4, p.chain_eps);
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    epi_steps<SIG, 0>(g, sv, ops, p.chain, q.idx4, q.aidx4, p.chain_eps);
     if constexpr (sig_has_fanout<SIG>()) {
         // stored by the fan-out
     } else if constexpr (sig_has_maxpair<SIG>()) {

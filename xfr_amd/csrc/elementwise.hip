@@ -73,6 +73,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 g = src[idx];
             }
         }
+        float sv = 0.f;          // EW_STORE action 1 / 2: the value saved at a branch point
 #pragma unroll 1
         for (int i = 0; i < ch.n; ++i) {
             const EwStep& st = ch.s[i];
@@ -126,7 +127,10 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                 if (st.type == EW_MASK) g = (st.p0[aidx] > 0.f) ? g : 0.f;
                 else if (st.type == EW_SCALE_C) g = g * st.p0[c];
                 else if (st.type == EW_SCALE) g = g * st.f;
-                else if (st.type == EW_STORE) st.pstore[idx] = g;
+                else if (st.type == EW_STORE) {
+                    if (st.action == 1) sv = g;
+                    else { st.pstore[idx] = g; if (st.action == 2) g = sv; }
+                }
                 else if (st.type == EW_ADDP) g += st.p0[idx];
                 else if (st.type == EW_AFFINE_C) g = __fadd_rn(__fmul_rn(g, st.p0[c]), st.p1[c]);
                 else if (st.type == EW_RELU) g = fmaxf(g, 0.f);

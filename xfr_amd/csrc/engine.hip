@@ -207,6 +207,8 @@ struct xfr_engine {
     bool direct_stem = true;           // Light-CNN's 1-channel 5x5 first layer as a direct convolution (xfr_engine_set_epilogue_fusion bit 4 clear; tests set it)
     bool fuse_avgup = true;            // down-sampling blocks: slice copy + pooled hook + average-pool VJP + strided GEMM's read-modify-write as the head of the
                                        // hook chain that follows (EW_AVGUP_IN; xfr_engine_set_epilogue_fusion bit 6 clear)
+    bool fuse_branch = true;           // projection-shortcut blocks: the main path's hook chain as a side branch of the Add-output GEMM's epilogue (EW_STORE actions
+                                       // 1 / 2; xfr_engine_set_epilogue_fusion bit 7 clear)
     bool pair_tiles = true;            // backward chain GEMMs over two streams walk their m-tiles stream-interleaved (xfr_engine_set_epilogue_fusion bit 5 clear)
     bool fuse_pools = true;            // Light-CNN's maxpool + avgpool pair: one forward kernel (xfr_engine_set_epilogue_fusion bit 0 switches it with the rest)
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
@@ -1524,6 +1526,61 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             st.erase(st.begin() + j);
         }
     }
+    if (pass == 2 && e->fuse_branch) {
+        // ---- 3c.  First block of a stage with a PROJECTION shortcut (resnet50_128.py): the GEMM that produces the gradient of the block's Add output
+        // ends [.., mask, STORE(t), rest_s] -> D: D, the shortcut branch's gradient, continues in the epilogue, and t, the Add output's gradient, is
+        // stored for the main path, whose own hook chain EW(t -> u) = [rest_m] was a launch of its own.  Both chains start from the same value:
+        // [.., mask, SAVE, rest_m, STORE(u) + RESTORE, rest_s] -> D runs the main path's chain as a side branch on the saved value -- the same
+        // operations on the same operands, t is never written, the launch is gone.
+        for (size_t i = 0; i < st.size(); ++i) {
+            BwdStep& a = st[i];
+            if (a.kind != ST_CONV_BWD || scatter_conv(a) || a.compact || a.accumulate || a.dst_t < 0 || a.chain.empty()) continue;
+            int k = -1;
+            bool plain = true;
+            for (size_t q = 0; q < a.chain.size(); ++q) {
+                const Sym& y = a.chain[q];
+                if (y.type == EW_STORE && y.action == 0 && k < 0) k = (int)q;
+                else if (y.type == EW_STORE && y.action != 0) plain = false;                 // one branch per chain
+                if (y.type == EW_MAXHALF_OUT || y.type == EW_MAXPAIR || y.type == EW_ADDP_CO || y.type == EW_FORK_POSADD) plain = false;
+            }
+            if (k < 0 || !plain) continue;
+            const int t = a.chain[k].t0, D = a.dst_t;
+            if (t < 0 || t == D) continue;
+            size_t j = i + 1;
+            for (; j < st.size(); ++j)
+                if (reads(st[j], t) || writes(st[j], t)) break;
+            if (j >= st.size()) continue;
+            const BwdStep c = st[j];
+            if (c.kind != ST_EW || c.src_t != t || c.accumulate || c.dst_t < 0 || c.dst_t == t || c.dst_t == D || c.chain.empty()) continue;
+            if (e->tens[c.ew_t].C != e->tens[a.ew_t >= 0 ? a.ew_t : D].C || e->tens[c.ew_t].HW() != e->tens[a.ew_t >= 0 ? a.ew_t : D].HW()) continue;
+            const int u = c.dst_t;
+            bool bad = false;
+            for (const Sym& y : c.chain) {
+                if (y.type != EW_HOOK && y.type != EW_MASK && y.type != EW_SCALE_C && y.type != EW_SCALE && y.type != EW_RELU) bad = true;   // plain per-element steps only
+                if (y.type == EW_HOOK && y.tap) bad = true;
+            }
+            for (size_t q = j + 1; q < st.size() && !bad; ++q) {        // nobody else reads t before it is rewritten
+                if (reads(st[q], t)) bad = true;
+                if (writes(st[q], t)) break;
+            }
+            for (size_t q = i + 1; q < j && !bad; ++q)
+                if (writes(st[q], u) || reads(st[q], u)) bad = true;
+            for (const Sym& y : a.chain)
+                if ((y.type == EW_STORE || y.type == EW_ADDP) && y.t0 == u) bad = true;
+            if (bad || a.chain.size() + 1 + c.chain.size() > (size_t)XFR_MAX_EW_STEPS) continue;
+            std::vector<Sym> merged(a.chain.begin(), a.chain.begin() + k);
+            Sym save = mk(EW_STORE, -1);
+            save.action = 1;
+            merged.push_back(save);
+            merged.insert(merged.end(), c.chain.begin(), c.chain.end());
+            Sym back = mk(EW_STORE, u);
+            back.action = 2;
+            merged.push_back(back);
+            merged.insert(merged.end(), a.chain.begin() + k + 1, a.chain.end());
+            a.chain = merged;
+            st.erase(st.begin() + j);
+        }
+    }
     if (pass == 2) plan.fused_gemm_nofan = st;
     bool changed = true;
     while (changed) {
@@ -1686,7 +1743,7 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
                 break;
             case EW_MAXHALF_OUT: q.p0 = e->T(sy.t0); break;
             case EW_SCALE_C: q.p0 = e->arena + (plain ? e->ops[sy.op].bn_alpha_t : e->ops[sy.op].bn_alpha_p); break;
-            case EW_STORE: q.pstore = e->G(sy.t0); break;
+            case EW_STORE: q.pstore = sy.t0 >= 0 ? e->G(sy.t0) : nullptr; break;      // action 1 (save) has no destination
             case EW_ADDP: q.p0 = e->G(sy.t0); break;
             default: break;
         }
@@ -2352,6 +2409,11 @@ xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
         const bool avgup = (enable & 1) != 0 && (enable & 64) == 0;   // bit 6 (tests): the down-sampling blocks' shortcut VJP as separate launches
         if (avgup != e->fuse_avgup) e->plans.clear();
         e->fuse_avgup = avgup;
+    }
+    {
+        const bool branch = (enable & 1) != 0 && (enable & 128) == 0;   // bit 7 (tests): the main path's chain of a projection-shortcut block as its own launch
+        if (branch != e->fuse_branch) e->plans.clear();
+        e->fuse_branch = branch;
     }
     e->pair_tiles = (enable & 32) == 0;           // bit 5 (A/B measurements): tile order of the two-stream backward GEMMs as before round 4
     e->direct_stem = (enable & 16) == 0;          // bit 4 (tests): the first layer of Light-CNN through the GEMM like every other convolution

@@ -59,6 +59,7 @@ template <bool PRIOR>
 __device__ __forceinline__ int ew_steps(int i0, float (&g)[4], long idx, long aidx, int sb, int el0, float4 v0, float4 v1, float4 v2, float4 v3,
                                         const EwChain& ch, int c, float eps)
 {
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};          // EW_STORE action 1 / 2: the value saved at a branch point
 #pragma unroll 1
     for (int i = i0; i < ch.n; ++i) {
         const EwStep& st = ch.s[i];
@@ -141,7 +142,16 @@ __device__ __forceinline__ int ew_steps(int i0, float (&g)[4], long idx, long ai
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] *= st.f;
         } else if (st.type == EW_STORE) {
-            reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(g[0], g[1], g[2], g[3]);
+            if (st.action == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sv[q] = g[q];
+            } else {
+                reinterpret_cast<float4*>(st.pstore)[idx] = make_float4(g[0], g[1], g[2], g[3]);
+                if (st.action == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = sv[q];
+                }
+            }
         } else if (st.type == EW_ADDP) {
             const float4 d = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[idx];
             g[0] += d.x; g[1] += d.y; g[2] += d.z; g[3] += d.w;
