@@ -10,7 +10,10 @@ P=profiles/$R
 export TMPDIR=/tmp
 mkdir -p "$D" "$P"
 ST="--kernel-trace --stats --output-format csv"
-for spec in resnet101: resnet50_128:_r50 lightcnn:_lcnn; do
+# optional 2nd argument: the model specs to (re)collect, e.g. "resnet50_128:_r50" after a change that only touches that backbone's schedule; the
+# model-independent files further down are then skipped
+SPECS=${2:-"resnet101: resnet50_128:_r50 lightcnn:_lcnn"}
+for spec in $SPECS; do
   M=${spec%%:*}; T=${spec##*:}
   B="python bench.py --model $M"
   # one stream: the schedule whose kernel durations a profiler can attribute
@@ -33,6 +36,12 @@ for spec in resnet101: resnet50_128:_r50 lightcnn:_lcnn; do
   # the plain bench line (timed three-stream schedule, launch-log roofline, clock, CPU baseline) + the timeline it came from
   $B --no-secondary --timeline-json $P/gemm_timeline$T.json > $P/bench_default$T.json 2> $D/bench_default$T.err
 done
+if [ -n "${2:-}" ]; then
+  python bench.py > $P/bench_driver_line.json 2> $D/bench_driver_line.err
+  mkdir -p gpurun_out/$P && cp -r $P/. gpurun_out/$P/
+  echo "collected ($SPECS): $(ls $P | tr '\n' ' ')"
+  exit 0
+fi
 # the timed schedule under the profiler (rocprofv3 serialises the queues: kernel mix only)
 rocprofv3 $ST -d $D/pipelined -o $R -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-sustained > $P/bench_pipelined_under_rocprof.json 2> $D/pipelined.err
 cp $D/pipelined/${R}_kernel_stats.csv $P/kernel_stats_pipelined.csv
