@@ -242,7 +242,11 @@ xfr_status xfr_engine_set_inputs_ready(xfr_engine* e, int32_t ready);
  * compact result of the strided GEMM, instead of by a slice copy, a hook launch, the pool's VJP and a read-modify-write scatter: same
  * operands, same operations, same bits; bit 6 (tests) keeps the separate launches.  Where the shortcut is a projection (resnet50_128.py), the
  * main path's hook chain of that block runs as a side branch of the Add-output GEMM's epilogue (the gradient is saved, the branch stored, the saved
- * value restored for the shortcut's chain) instead of as a launch of its own: same operations on the same operands; bit 7 (tests) keeps the launch. */
+ * value restored for the shortcut's chain) instead of as a launch of its own: same operations on the same operands; bit 7 (tests) keeps the launch.
+ * Forward: the reference evaluates a down-sampling block's shortcut behind the main path (resnet.py:144-146); the engine computes it in front of
+ * the main path's last convolution, so that the residual add [+ ReLU] joins that convolution's epilogue like in every other block, and keeps the
+ * pooled shortcut inside its zero-padded form (a channel prefix is a storage prefix in CNHW: the padding is one fill, no copy).  The order of two
+ * independent branches changes no value; bit 8 (tests, A/B) keeps program order and the separate add. */
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable);
 
 /* Share one forward pass between consecutive calls on the same input (off by default).  While hold = 1, a run call

@@ -521,13 +521,14 @@ def test_epilogue_fusion_is_bit_identical(gpu_device, arch, mode):
     # (35) the default without the stream-interleaved tile order of the two-stream backward GEMMs
     # (67) the default with the down-sampling blocks' shortcut VJP as separate launches (no EW_AVGUP_IN head, scattering GEMM)
     # (131) the default with the main path's chain of a projection-shortcut block as its own launch (no side branch in the GEMM epilogue)
-    for fused in (1, 0, 3, 5, 11, 19, 35, 67, 131):
+    # (259) the default with the down-sampling blocks' shortcut computed in program order (behind the main path), their residual add as its own launch
+    for fused in (1, 0, 3, 5, 11, 19, 35, 67, 131, 259):
         eng.set_epilogue_fusion(fused)
         res[fused] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
                       wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone(),
                       wb.triplet_images_ebp_batch(x[:2], x[2:4], x[1:3]).clone())
     eng.set_epilogue_fusion(3)
-    for level in (0, 3, 5, 11, 19, 35, 67, 131):
+    for level in (0, 3, 5, 11, 19, 35, 67, 131, 259):
         for a, b in zip(res[1], res[level]):
             assert torch.equal(a, b), level
 

@@ -329,8 +329,9 @@ void launch_pool2_fwd(const float* in, float* out_sum, uint8_t* idx, float* out_
 // gin (+)= scatter of gout through the stored argmax; gradient batch SB vs forward batch B
 void launch_maxpool_bwd(const float* gout, const uint8_t* idx, float* gin, int accumulate, int C, int SB, int B,
                         int H, int W, int OH, int OW, int k, int stride, int pad, hipStream_t s);
+// zero_planes > 0: that many further planes behind the CN pooled ones are written as zeros (the pooled shortcut inside its channel-padded form)
 void launch_avgpool_fwd(const float* in, float* out, int CN, int H, int W, int OH, int OW, int k, int stride,
-                        int relu_in, hipStream_t s);
+                        int relu_in, hipStream_t s, int zero_planes = 0);
 void launch_avgpool_bwd(const float* gout, float* gin, int accumulate, int CN, int H, int W, int OH, int OW,
                         int k, int stride, hipStream_t s);
 // out[c] = max(in[c], in[c+Co]) ; optional relu on load

@@ -595,12 +595,15 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const float* __restrict
 }
 
 // AvgPool2d, no padding (resnet.py:186,211; resnet50_128.py pool5; lightcnn.py:237): mean over k*k
+// zero_planes: that many further output planes behind the CN pooled ones are written as zeros (ConcatChannels of a down-sampling shortcut)
 __global__ __launch_bounds__(NT) void avgpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int CN,
-                                                        int H, int W, int OH, int OW, int k, int stride, int relu_in)
+                                                        int H, int W, int OH, int OW, int k, int stride, int relu_in, int zero_planes)
 {
-    const long total = (long)CN * OH * OW;
+    const long pooled = (long)CN * OH * OW;
+    const long total = pooled + (long)zero_planes * OH * OW;
     const float inv = 1.0f / (float)(k * k);
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        if (i >= pooled) { out[i] = 0.f; continue; }
         const int cn = (int)(i / ((long)OH * OW));
         const int r = (int)(i - (long)cn * OH * OW);
         const int oh = r / OW, ow = r - oh * OW;
@@ -787,13 +790,14 @@ __global__ __launch_bounds__(NT) void avgpool_bwd_kernel_v4(const float* __restr
 // OW % 4 == 0: a thread owns four consecutive outputs of one row
 template <int KK, int SS>
 __global__ __launch_bounds__(NT) void avgpool_fwd_kernel_v4(const float* __restrict__ in, float4* __restrict__ out, int H, int W, int OH,
-                                                           int OW, int k_rt, int stride_rt, int relu_in)
+                                                           int OW, int k_rt, int stride_rt, int relu_in, int CN)
 {
     const int k = KK ? KK : k_rt, stride = SS ? SS : stride_rt;
     const int plane = blockIdx.y;
     const int OW4 = OW >> 2;
     const int q = blockIdx.x * NT + threadIdx.x;
     if (q >= OH * OW4) return;
+    if (plane >= CN) { out[(size_t)plane * OH * OW4 + q] = make_float4(0.f, 0.f, 0.f, 0.f); return; }     // zero planes behind the pooled ones
     const int oh = q / OW4, ow0 = (q - oh * OW4) * 4;
     const float* __restrict__ src = in + (size_t)plane * H * W + (size_t)(oh * stride) * W;
     const float inv = 1.0f / (float)(k * k);
@@ -1221,21 +1225,21 @@ void launch_maxpool_bwd(const float* gout, const uint8_t* idx, float* gin, int a
                        C, SB, B, H, W, OH, OW, k, stride, pad);
 }
 void launch_avgpool_fwd(const float* in, float* out, int CN, int H, int W, int OH, int OW, int k, int stride, int relu_in,
-                        hipStream_t s)
+                        hipStream_t s, int zero_planes)
 {
-    if (OH == 1 && OW == 1 && k == H && k == W && (size_t)GP * H * W * sizeof(float) <= 64 * 1024) {
+    if (zero_planes == 0 && OH == 1 && OW == 1 && k == H && k == W && (size_t)GP * H * W * sizeof(float) <= 64 * 1024) {
         hipLaunchKernelGGL(avgpool_global_fwd_kernel, dim3((CN + GP - 1) / GP), dim3(NT), (size_t)GP * H * W * sizeof(float), s, in, out, CN, H * W, relu_in);
         return;
     }
-    if ((OW & 3) == 0 && CN <= 65535) {
-        const dim3 g((OH * (OW / 4) + NT - 1) / NT, CN);
+    if ((OW & 3) == 0 && CN + zero_planes <= 65535) {
+        const dim3 g((OH * (OW / 4) + NT - 1) / NT, CN + zero_planes);
         float4* out4 = reinterpret_cast<float4*>(out);
-        if (k == 2 && stride == 2) hipLaunchKernelGGL((avgpool_fwd_kernel_v4<2, 2>), g, dim3(NT), 0, s, in, out4, H, W, OH, OW, k, stride, relu_in);
-        else hipLaunchKernelGGL((avgpool_fwd_kernel_v4<0, 0>), g, dim3(NT), 0, s, in, out4, H, W, OH, OW, k, stride, relu_in);
+        if (k == 2 && stride == 2) hipLaunchKernelGGL((avgpool_fwd_kernel_v4<2, 2>), g, dim3(NT), 0, s, in, out4, H, W, OH, OW, k, stride, relu_in, CN);
+        else hipLaunchKernelGGL((avgpool_fwd_kernel_v4<0, 0>), g, dim3(NT), 0, s, in, out4, H, W, OH, OW, k, stride, relu_in, CN);
         return;
     }
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)CN * OH * OW)), dim3(NT), 0, s, in, out, CN, H, W, OH, OW, k,
-                       stride, relu_in);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)(CN + zero_planes) * OH * OW)), dim3(NT), 0, s, in, out, CN, H, W, OH, OW, k,
+                       stride, relu_in, zero_planes);
 }
 void launch_avgpool_bwd(const float* gout, float* gin, int accumulate, int CN, int H, int W, int OH, int OW, int k, int stride,
                         hipStream_t s)

@@ -62,6 +62,7 @@ struct Tensor {
     bool nonneg = false;
     int pstate = PS_OTHER;
     int alias = -1;          // shares T storage with this tensor (in-place ReLU, Split)
+    int prefix_of = -1;      // T storage = the leading channels of this tensor's (the pooled shortcut inside its zero-padded form; layout_workspace)
     size_t t_off = 0, pv_off = 0, g_off = 0;   // offsets (floats) into the workspace
     bool need_pv = false;
     std::vector<Hook> hooks;
@@ -204,6 +205,8 @@ struct xfr_engine {
     bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue (STORE raw, [FORK positive
                                        // BatchNorm], affine, clamp).  Round 3, MI355X: +0.6 % maps/s on ResNet-101, +2.2 % on ResNet-50-128d, bit-identical
     bool fuse_fwd_only = true;         // forward-only runs: BatchNorm / residual add / ReLU in the GEMM epilogue
+    bool hoist_shortcut = true;        // down-sampling blocks: the shortcut (average pool, channel padding) is computed BEFORE the main path's last
+                                       // convolution, so that the residual add joins its epilogue like in every other block (bit 8 of the fusion mask)
     bool direct_stem = true;           // Light-CNN's 1-channel 5x5 first layer as a direct convolution (xfr_engine_set_epilogue_fusion bit 4 clear; tests set it)
     bool fuse_avgup = true;            // down-sampling blocks: slice copy + pooled hook + average-pool VJP + strided GEMM's read-modify-write as the head of the
                                        // hook chain that follows (EW_AVGUP_IN; xfr_engine_set_epilogue_fusion bit 6 clear)
@@ -479,10 +482,22 @@ xfr_status layout_workspace(xfr_engine* e)
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
     e->x_off = take(B * e->tens[0].per_n());
+    // ConcatChannels (resnet.py:210-213) pads the pooled shortcut with zero channels.  In CNHW a channel prefix is a storage prefix for every
+    // batch size, so the pooled tensor lives INSIDE the padded one: the average pool writes it there and the padding is one fill, no copy.
+    for (auto& o : e->ops) {
+        if (o.d.kind != XFR_OP_CONCAT) continue;
+        Tensor& in = e->tens[o.d.in0];
+        if (in.alias >= 0 || e->tens[o.d.out].alias >= 0 || in.consumers.size() != 1 || in.producer < 0 ||
+            e->ops[in.producer].d.kind != XFR_OP_AVGPOOL)
+            continue;
+        in.prefix_of = o.d.out;
+    }
     for (size_t t = 0; t < e->tens.size(); ++t) {
         Tensor& x = e->tens[t];
-        if (x.alias < 0) x.t_off = take(B * x.per_n());
+        if (x.alias < 0 && x.prefix_of < 0) x.t_off = take(B * x.per_n());
     }
+    for (auto& x : e->tens)
+        if (x.prefix_of >= 0) x.t_off = e->tens[x.prefix_of].t_off;
     e->t_region_floats = off;
     for (size_t t = 0; t < e->tens.size(); ++t) {
         Tensor& x = e->tens[t];
@@ -637,7 +652,39 @@ void conv_geometry(xfr_engine* e, int k, int NB, ConvParams& p)
 // Conv -> BatchNorm [-> Add with an already computed operand] [-> in-place ReLU] runs in the GEMM's chain epilogue
 // (per-channel affine, residual read as 16-byte pieces, clamp), same arithmetic in the same order as the stand-alone
 // kernels.
-void fuse_forward_only(xfr_engine* e, int k, int B, ConvParams& p)
+xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s);
+xfr_status pos_op(xfr_engine* e, int k, int B, hipStream_t s);
+
+// The reference evaluates a down-sampling block's shortcut BEHIND the main path (resnet.py:144-146: `residual = self.downsample(x)` after
+// bn3), so in program order the residual operand does not exist yet when the block's last convolution is launched and the add kept its own
+// kernel.  Nothing orders the two branches: when the operand is the end of a short chain of pooling / padding ops over tensors that exist,
+// run that chain now (true values and, in a probe forward, its positive values) and mark it done.  Returns true when tensor `t` exists afterwards.
+bool operand_ready(xfr_engine* e, int t, int k, int B, bool with_pos, hipStream_t s)
+{
+    if (e->tens[t].producer < k) return true;
+    if (!e->hoist_shortcut) return false;
+    int chain[4], n = 0;
+    for (int u = t; e->tens[u].producer >= k; u = e->ops[e->tens[u].producer].d.in0) {
+        const int kp = e->tens[u].producer;
+        if (e->fwd_done[kp]) break;                       // enqueued already (stream order makes it exist)
+        const xfr_op_desc& d = e->ops[kp].d;
+        if (kp > e->fwd_last_op || n == 4 || (d.kind != XFR_OP_AVGPOOL && d.kind != XFR_OP_CONCAT)) return false;
+        if (with_pos && e->tens[d.out].need_pv && d.kind != XFR_OP_AVGPOOL) return false;     // pos_op computes no padded positive value
+        chain[n++] = kp;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const int kp = chain[i];
+        if (!e->planning_only) {
+            if (!e->fwd_done[kp] && fwd_op(e, kp, B, with_pos, s) != XFR_OK) return false;
+            if (with_pos && e->tens[e->ops[kp].d.out].need_pv && !e->pos_done[kp] && pos_op(e, kp, B, s) != XFR_OK) return false;
+        }
+        e->fwd_done[kp] = 1;
+        e->pos_done[kp] = 1;
+    }
+    return true;
+}
+
+void fuse_forward_only(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t s)
 {
     const xfr_op_desc& d = e->ops[k].d;
     const Tensor& c = e->tens[d.out];
@@ -662,7 +709,7 @@ void fuse_forward_only(xfr_engine* e, int k, int B, ConvParams& p)
         const OpRec& ad = e->ops[k2];
         if (k2 <= e->fwd_last_op && (ad.d.kind == XFR_OP_ADD || ad.d.kind == XFR_OP_G_ADD)) {
             const int other = (ad.d.in0 == bn_out) ? ad.d.in1 : ad.d.in0;
-            if (other != bn_out && e->tens[other].producer < k) {          // the other operand is already computed
+            if (other != bn_out && operand_ready(e, other, k, B, false, s)) {          // the other operand is already computed (or is now)
                 push(EW_ADDP).p0 = e->T(other);
                 if (ad.fuse_relu) push(EW_RELU);
                 final_t = ad.d.out;
@@ -693,7 +740,7 @@ bool can_fuse_probe(xfr_engine* e, int k, int* k1_out)
     return true;
 }
 
-void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
+void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t s)
 {
     int k1 = -1;
     if (!can_fuse_probe(e, k, &k1)) return;
@@ -729,7 +776,7 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p)
         // (the positive pass of a functional add reads its inputs' POSITIVE values, never the true ones: only the Add module's does)
         if (k2 <= e->fwd_last_op && (ad.d.kind == XFR_OP_G_ADD || (ad.d.kind == XFR_OP_ADD && !e->tens[ad.d.out].need_pv))) {
             const int other = (ad.d.in0 == bn_out) ? ad.d.in1 : ad.d.in0;
-            if (other != bn_out && e->tens[other].producer < k) {
+            if (other != bn_out && operand_ready(e, other, k, B, true, s)) {
                 push(EW_ADDP).p0 = e->T(other);
                 if (ad.fuse_relu) push(EW_RELU);
                 final_t = ad.d.out;
@@ -900,8 +947,8 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
                 return XFR_OK;
             }
             if (o.pair && e->fuse_fwd_only && !dual && !p.relu_in && fuse_mfm_forward(e, k, B, want_pos, p)) { }
-            else if (!want_pos && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p);
-            else if (want_pos && e->fuse_probe_fwd && !p.relu_in) fuse_probe_forward(e, k, B, p);
+            else if (!want_pos && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p, s);
+            else if (want_pos && e->fuse_probe_fwd && !p.relu_in) fuse_probe_forward(e, k, B, p, s);
             return run_conv(e, p, s);
         }
         case XFR_OP_BATCHNORM:
@@ -916,16 +963,23 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
             if (fuse_pool2_forward(e, k, B, want_pos, s)) return XFR_OK;
             launch_maxpool_fwd(e->T(d.in0), e->T(d.out), e->t_bank ? nullptr : e->idx_base() + o.idx_off, a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, d.pad, s);
             return XFR_OK;
-        case XFR_OP_AVGPOOL:
+        case XFR_OP_AVGPOOL: {
             if (t.alias >= 0) return XFR_OK;
-            launch_avgpool_fwd(e->T(d.in0), e->T(d.out), a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, 0, s);
+            // the pooled shortcut lives inside its zero-padded form (layout_workspace): the pool writes the padding planes as well
+            int zero_planes = 0;
+            if (t.prefix_of >= 0 && e->hoist_shortcut && t.consumers[0] <= e->fwd_last_op) {
+                zero_planes = (e->tens[t.prefix_of].C - t.C) * B;
+                e->fwd_done[t.consumers[0]] = 1;
+            }
+            launch_avgpool_fwd(e->T(d.in0), e->T(d.out), a.C * B, a.H, a.W, t.H, t.W, d.kh, d.stride, 0, s, zero_planes);
             return XFR_OK;
+        }
         case XFR_OP_ADD:
         case XFR_OP_G_ADD:
             launch_add2(e->T(d.in0), e->T(d.in1), e->T(d.out), n_out, 0, 0, o.fuse_relu ? 1 : 0, s);
             return XFR_OK;
         case XFR_OP_CONCAT:
-            launch_copy_acc(e->T(d.in0), e->T(d.out), n_in, 0, s);
+            if (e->T(d.in0) != e->T(d.out)) launch_copy_acc(e->T(d.in0), e->T(d.out), n_in, 0, s);
             if (n_out > n_in) launch_fill(e->T(d.out) + n_in, n_out - n_in, 0.f, s);
             return XFR_OK;
         case XFR_OP_MULTIPLY:
@@ -2416,6 +2470,7 @@ xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
         e->fuse_branch = branch;
     }
     e->pair_tiles = (enable & 32) == 0;           // bit 5 (A/B measurements): tile order of the two-stream backward GEMMs as before round 4
+    e->hoist_shortcut = (enable & 256) == 0;      // bit 8 (tests, A/B): the down-sampling blocks' shortcut in program order, their residual add as its own launch
     e->direct_stem = (enable & 16) == 0;          // bit 4 (tests): the first layer of Light-CNN through the GEMM like every other convolution
     e->held_x = nullptr;
     return XFR_OK;
@@ -3069,7 +3124,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
         ConvParams p;
         conv_geometry(e, k, batch, p);
         p.out0 = e->T(d.out);
-        if (!fuse_mfm_forward(e, k, batch, false, p)) fuse_forward_only(e, k, batch, p);
+        if (!fuse_mfm_forward(e, k, batch, false, p)) fuse_forward_only(e, k, batch, p, nullptr);
         if (p.chain.n == 0) continue;
         EwLoads ld;
         ew_plan_loads(p.chain, p.out0, ld, EW_FWD_SLOTS_WIDE);
@@ -3087,7 +3142,7 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
         ConvParams p;
         conv_geometry(e, k, batch, p);
         p.out0 = e->T(d.out);
-        if (!fuse_mfm_forward(e, k, batch, true, p)) fuse_probe_forward(e, k, batch, p);
+        if (!fuse_mfm_forward(e, k, batch, true, p)) fuse_probe_forward(e, k, batch, p, nullptr);
         if (p.chain.n == 0) continue;
         EwLoads ld;
         ew_plan_loads(p.chain, p.out0, ld, EW_FWD_SLOTS_WIDE);
