@@ -110,6 +110,27 @@ def test_residual_blocks_leave_no_glue_launches():
     assert all('compiled=-1' not in ln for ln in lines67)
 
 
+def test_downsampling_blocks_take_their_add_into_the_convolution_epilogue():
+    """The reference computes a down-sampling block's shortcut behind the main path (resnet.py:144-146); the engine runs it first, so that all 33
+    residual adds of the STR-ResNet-101 -- not only the 29 of the ordinary blocks -- sit in the epilogue of the block's last convolution, in the
+    forward-only schedule and in the probe forward.  Epilogue-fusion bit 8 keeps program order and the four separate adds."""
+    prog = PROGRAMS['stresnet101']
+
+    def adds(lines, kind):
+        return sum(ln.startswith(kind + ' CONV') and ' 0bb9' in ln.split('SIG')[1] for ln in lines)     # 0bb9 / 13b9: EW_ADDP as step 1 / 2
+    def adds_probe(lines):
+        return sum(ln.startswith('probe CONV') and ' 13b9' in ln for ln in lines)
+    lines = prog.describe('affineonly_with_prior', prog.marks['encode']).splitlines()
+    assert adds(lines, 'fwd') == 33 and adds_probe(lines) == 33
+    os.environ['XFR_DESCRIBE_FUSION'] = '259'
+    try:
+        lines259 = prog.describe('affineonly_with_prior', prog.marks['encode']).splitlines()
+    finally:
+        del os.environ['XFR_DESCRIBE_FUSION']
+    assert adds(lines259, 'fwd') == 29 and adds_probe(lines259) == 29
+    assert all('compiled=-1' not in ln for ln in lines + lines259)
+
+
 def test_projection_shortcut_blocks_branch_in_the_gemm_epilogue():
     """ResNet-50-128d (projection shortcuts): the main path's hook chain of a stage's first block runs as a side branch of the Add-output GEMM's
     epilogue (EW_STORE actions 1 / 2, fuse_plan 3c): 60 backward launches, no stand-alone two-step chain, every chain compiled; with the switch
