@@ -649,9 +649,6 @@ void conv_geometry(xfr_engine* e, int k, int NB, ConvParams& p)
 }
 
 // Forward-only runs (encode, embeddings, the gallery of a triplet step) never need the raw convolution output:
-// Conv -> BatchNorm [-> Add with an already computed operand] [-> in-place ReLU] runs in the GEMM's chain epilogue
-// (per-channel affine, residual read as 16-byte pieces, clamp), same arithmetic in the same order as the stand-alone
-// kernels.
 xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s);
 xfr_status pos_op(xfr_engine* e, int k, int B, hipStream_t s);
 
@@ -684,6 +681,9 @@ bool operand_ready(xfr_engine* e, int t, int k, int B, bool with_pos, hipStream_
     return true;
 }
 
+// Conv -> BatchNorm [-> Add with an already computed operand] [-> in-place ReLU] runs in the GEMM's chain epilogue
+// (per-channel affine, residual read as 16-byte pieces, clamp), same arithmetic in the same order as the stand-alone
+// kernels.
 void fuse_forward_only(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t s)
 {
     const xfr_op_desc& d = e->ops[k].d;
