@@ -300,7 +300,9 @@ def make_workload(args, dev, rank, cpu_only=False):
             seed = torch.zeros((1, B, 80013), device=dev)
             seed[0, :, 0] = 1.0
             cls_t = prog.marks['classify']
-            W.pipeline = 2          # forward of step i+1 under the backward of step i; x is resident (inputs_ready below)
+            W.pipeline = 6          # forward of step i+1 under the backward of step i; x is resident (inputs_ready below).  Bit 2: THREE forward
+                                    # slots -- this schedule has one forward stream, which then runs up to two steps ahead: +1.8 % (the ResNets'
+                                    # three-stream step is level with it: profiles/r4/experiments/pipeline_slots_ab.txt)
 
             def step(ready=True):
                 _, pooled = eng.ebp(x, cls_t, seed, want_mwp=False, want_pooled=True, inputs_ready=ready)
@@ -368,6 +370,15 @@ def rank_report(eng, rank, local, world, binding=None):
     return allr
 
 
+def _pipe_level(level):
+    """XFR_PIPE_SLOTS=3 / 2 (tuning / A-B runs, tools/ab_env.sh): three / two forward slots whatever the workload chose (xfr_engine_set_pipeline bit 2)."""
+    if level and os.environ.get('XFR_PIPE_SLOTS') == '3':
+        return level | 4
+    if level and os.environ.get('XFR_PIPE_SLOTS') == '2':
+        return level & ~4
+    return level
+
+
 def timed_loop(W, steps, warmup, barrier, world, dev):
     """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; the checks on the last step's maps."""
     import torch
@@ -415,7 +426,7 @@ def run_secondary(model, dev, steps, warmup, chain_before):
     a = A()
     a.model, a.batch, a.mode = model, None, None
     W = make_workload(a, dev, 0)
-    W.eng.set_pipeline(W.pipeline)
+    W.eng.set_pipeline(_pipe_level(W.pipeline))
     r = timed_loop(W, steps, warmup, torch.cuda.synchronize, 1, dev)
     ms_step = 1e3 * r['dt'] / steps
     ok, row0 = r['ok'], None
@@ -508,7 +519,7 @@ def main():
     if args.persistent_gemm is not None:
         eng.set_persistent_gemm(args.persistent_gemm)
     if not args.no_pipeline and not args.serial:
-        eng.set_pipeline(W.pipeline)      # inputs are resident and never modified: the pipelining contract holds
+        eng.set_pipeline(_pipe_level(W.pipeline))      # inputs are resident and never modified: the pipelining contract holds
     step = W.step
     if args.serial:
         eng.set_profile(True)

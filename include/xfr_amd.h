@@ -208,7 +208,9 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
  * (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:200-215: independent jobs, inputs loaded ahead).
  * enable = 2 additionally pipelines xfr_ebp / xfr_contrastive / xfr_contrastive_raw: their forward overlaps the previous
  * call's sweep, and their x_dev must satisfy the inputs_ready contract of xfr_triplet_contrastive.
- * Costs one extra copy of the forward workspace.  Synchronises the device. */
+ * enable | 4: THREE forward slots instead of two -- the forwards may run two calls ahead of the sweep, which decouples a schedule whose forward is one
+ * stream from its sweep (Light-CNN-29v2 EBP, 128 images per call: +1.8 %; level for the three-stream triplet step of the ResNets).
+ * Costs one extra copy of the forward workspace per slot beyond the first.  Synchronises the device. */
 xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable);
 
 /* Pipeline level 2 only.  ready = 0 (default): the internal forward stream of xfr_ebp / xfr_contrastive /

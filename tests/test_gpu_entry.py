@@ -177,13 +177,14 @@ def test_fresh_inputs_are_safe_under_pipelining(gpu_device):
     gal = [torch.cat((x, x.flip(0)), dim=0) for x in xs]
     ref_t = [eng.triplet_contrastive(x, g, enc_t).clone() for x, g in zip(xs, gal)]
     torch.cuda.synchronize()
-    eng.set_pipeline(2)
-    for rep in range(3):
-        outs = [eng.contrastive(x, enc_t, sd_, inputs_ready=True) for x, sd_ in zip(xs, seeds)]
-        outs_t = [eng.triplet_contrastive(x, g, enc_t, inputs_ready=True) for x, g in zip(xs, gal)]
-        torch.cuda.synchronize()
-        for o, r in zip(outs + outs_t, ref + ref_t):
-            assert torch.equal(o, r)
+    for level in (2, 6):                        # 6: three forward slots (bit 2)
+        eng.set_pipeline(level)
+        for rep in range(3):
+            outs = [eng.contrastive(x, enc_t, sd_, inputs_ready=True) for x, sd_ in zip(xs, seeds)]
+            outs_t = [eng.triplet_contrastive(x, g, enc_t, inputs_ready=True) for x, g in zip(xs, gal)]
+            torch.cuda.synchronize()
+            for o, r in zip(outs + outs_t, ref + ref_t):
+                assert torch.equal(o, r)
     eng.close()
 
 

@@ -405,8 +405,10 @@ def test_triplet_step_equals_two_call_path(gpu_device):
         assert torch.equal(o, ref[i % len(batches)]), 'pipelined call %d differs' % i
 
 
-def test_pipelined_plain_calls(gpu_device):
-    """xfr_engine_set_pipeline(2): ebp / contrastive calls overlap across calls and still give the one-by-one results."""
+@pytest.mark.parametrize('level', [2, 6])
+def test_pipelined_plain_calls(gpu_device, level):
+    """xfr_engine_set_pipeline(2): ebp / contrastive calls overlap across calls and still give the one-by-one results; level 6 = the same with
+    three forward slots (bit 2: the forwards may run two calls ahead of the sweep)."""
     bb, sd = make_backbone('lightcnn29v2', seed=2, num_classes=7)
     subj = GC.engine_subject('lightcnn29v2', bb, 'affineonly_with_prior')
     subj.wb.debug_trace = False
@@ -419,7 +421,7 @@ def test_pipelined_plain_calls(gpu_device):
     ref = [eng.ebp(x, st, seed)[1].clone() for x in xs]
     enc = [eng.forward(x, wb.net._program.marks['encode']).clone() for x in xs]
     torch.cuda.synchronize()
-    eng.set_pipeline(2)
+    eng.set_pipeline(level)
     outs = [eng.ebp(x, st, seed)[1] for x in xs * 2]
     mid = eng.forward(xs[1], wb.net._program.marks['encode'])          # un-pipelined call in between
     outs2 = [eng.ebp(x, st, seed)[1] for x in xs]

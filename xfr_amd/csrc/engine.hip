@@ -240,14 +240,15 @@ struct xfr_engine {
     bool inputs_ready = false;     // xfr_engine_set_inputs_ready: the NEXT level-2 call may read x_dev without waiting for the caller's stream (one-shot)
     int cur_slot = 0;
     long seq = 0;
-    float* ws2 = nullptr;
-    uint8_t* idx_ws2 = nullptr;
+    float* ws2 = nullptr, *ws3 = nullptr;       // forward workspaces of pipeline slots 1 and 2
+    uint8_t* idx_ws2 = nullptr, *idx_ws3 = nullptr;
+    int n_slots = 2;               // xfr_engine_set_pipeline bit 2: three forward slots (the forwards may run two calls ahead of the sweep)
     size_t fwd_region_floats = 0;
-    float* seedbuf[2] = {nullptr, nullptr};
-    hipEvent_t ev_slot_done[2] = {nullptr, nullptr};
-    bool slot_pending[2] = {false, false};
-    float* fwd_base() { return cur_slot ? ws2 : ws; }
-    uint8_t* idx_base() { return cur_slot ? idx_ws2 : idx_ws; }
+    float* seedbuf[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_slot_done[3] = {nullptr, nullptr, nullptr};
+    bool slot_pending[3] = {false, false, false};
+    float* fwd_base() { return cur_slot == 0 ? ws : (cur_slot == 1 ? ws2 : ws3); }
+    uint8_t* idx_base() { return cur_slot == 0 ? idx_ws : (cur_slot == 1 ? idx_ws2 : idx_ws3); }
     float* T(int t) { const Tensor& x = tens[t]; return (t_bank ? t_bank : fwd_base()) + tens[x.alias >= 0 ? root(t) : t].t_off; }
     float* Pv(int t) { return fwd_base() + tens[t].pv_off; }
     float* misc() { return fwd_base() + misc_off; }
@@ -2021,7 +2022,7 @@ xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_te
     // overlaps the backward sweep of the previous call (which is still reading the other slot)
     const bool pipe = e->pipeline_all && !e->profile_on && e->s_b;
     hipStream_t sf = pipe ? e->s_b : s;
-    e->cur_slot = pipe ? (int)(e->seq++ & 1) : 0;
+    e->cur_slot = pipe ? (int)(e->seq++ % e->n_slots) : 0;
     const int slot = e->cur_slot;
     if (pipe && e->slot_pending[slot]) HIP_TRY(hipStreamWaitEvent(sf, e->ev_slot_done[slot], 0));
     // (the promise covers ONE call: a caller that forgets to renew it falls back to the safe ordering, never to a stale promise)
@@ -2093,6 +2094,7 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->ws_enc) (void)hipFree(e->ws_enc);
     for (int i = 0; i < e->n_tail_ws; ++i) (void)hipFree(e->tail_ws[i].ws);
     if (e->ws2) (void)hipFree(e->ws2);
+    if (e->ws3) (void)hipFree(e->ws3);
     if (e->cap_dev) (void)hipFree(e->cap_dev);
     if (e->tab_elem_d) (void)hipFree(e->tab_elem_d);
     if (e->tab_val_d) (void)hipFree(e->tab_val_d);
@@ -2106,7 +2108,8 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->stat_f2u) (void)hipFree(e->stat_f2u);
     if (e->store_dev) (void)hipFree(e->store_dev);
     if (e->idx_ws2) (void)hipFree(e->idx_ws2);
-    for (int i = 0; i < 2; ++i) { if (e->seedbuf[i]) (void)hipFree(e->seedbuf[i]); if (e->ev_slot_done[i]) (void)hipEventDestroy(e->ev_slot_done[i]); }
+    if (e->idx_ws3) (void)hipFree(e->idx_ws3);
+    for (int i = 0; i < 3; ++i) { if (e->seedbuf[i]) (void)hipFree(e->seedbuf[i]); if (e->ev_slot_done[i]) (void)hipEventDestroy(e->ev_slot_done[i]); }
     if (e->s_a) (void)hipStreamDestroy(e->s_a);
     if (e->s_b) (void)hipStreamDestroy(e->s_b);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -2402,7 +2405,7 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     hipStream_t sa = fork ? e->s_a : s, sb = fork ? e->s_b : s;
     // every exit path (errors included) leaves the engine on slot 0 / the main bank: the non-pipelined entry points assume it
     struct SlotGuard { xfr_engine* e; ~SlotGuard() { e->cur_slot = 0; e->t_bank = nullptr; } } slot_guard{e};
-    e->cur_slot = pipe ? (int)(e->seq++ & 1) : 0;
+    e->cur_slot = pipe ? (int)(e->seq++ % e->n_slots) : 0;
     const int slot = e->cur_slot;
     if (fork) {
         if (pipe && inputs_ready) {
@@ -2511,20 +2514,30 @@ xfr_status xfr_engine_set_pipeline(xfr_engine* e, int32_t enable)
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
+    const bool three = enable > 0 && (enable & 4) != 0;
+    size_t max_per_n = 0;
+    for (auto& x : e->tens) max_per_n = std::max(max_per_n, (size_t)x.per_n());
+    auto slot_state = [&](int i) -> xfr_status {
+        if (e->seedbuf[i]) return XFR_OK;
+        HIP_TRY(hipMalloc(&e->seedbuf[i], 2 * (size_t)e->max_batch * max_per_n * sizeof(float)));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_slot_done[i], hipEventDisableTiming));
+        return XFR_OK;
+    };
     if (enable && !e->ws2) {
         HIP_TRY(hipMalloc(&e->ws2, e->fwd_region_floats * sizeof(float)));
         HIP_TRY(hipMalloc(&e->idx_ws2, e->idx_bytes));
-        size_t max_per_n = 0;
-        for (auto& x : e->tens) max_per_n = std::max(max_per_n, (size_t)x.per_n());
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipMalloc(&e->seedbuf[i], 2 * (size_t)e->max_batch * max_per_n * sizeof(float)));
-            HIP_TRY(hipEventCreateWithFlags(&e->ev_slot_done[i], hipEventDisableTiming));
-        }
     }
+    if (three && !e->ws3) {
+        HIP_TRY(hipMalloc(&e->ws3, e->fwd_region_floats * sizeof(float)));
+        HIP_TRY(hipMalloc(&e->idx_ws3, e->idx_bytes));
+    }
+    if (enable)
+        for (int i = 0; i < (three ? 3 : 2); ++i) { xfr_status ss = slot_state(i); if (ss != XFR_OK) return ss; }
     if (enable) { xfr_status es = ensure_streams(e); if (es != XFR_OK) return es; }
     e->pipeline = enable != 0;
-    e->pipeline_all = enable >= 2;
-    e->slot_pending[0] = e->slot_pending[1] = false;
+    e->pipeline_all = enable > 0 && (enable & 2) != 0;
+    e->n_slots = three ? 3 : 2;
+    e->slot_pending[0] = e->slot_pending[1] = e->slot_pending[2] = false;
     e->seq = 0;
     return XFR_OK;
 }

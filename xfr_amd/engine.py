@@ -115,7 +115,7 @@ class Engine(object):
         """Pipeline level 2: tell the engine whether the NEXT ebp / contrastive call may read x without waiting for the
         caller's stream (xfr_engine_set_inputs_ready; the engine consumes the promise with that call, so ebp_capture /
         ebp_firing / layerwise, which never declare anything, always take the safe ordering)."""
-        if self._pipeline >= 2:
+        if self._pipeline & 2:
             _lib.check(self.lib.xfr_engine_set_inputs_ready(self._h, 1 if ready else 0))
 
     def forward(self, x, tensor_id):
@@ -188,7 +188,7 @@ class Engine(object):
 
     def set_pipeline(self, on):
         """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
-        _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call
+        _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call; | 4: three forward slots
         self._pipeline = int(on)
         self.options['pipeline'] = int(on)
 
