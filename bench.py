@@ -470,7 +470,6 @@ def main():
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 10 s sustained loop after the timed region')
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
-    ap.add_argument('--persistent-gemm', type=int, default=None, help='xfr_engine_set_persistent_gemm(level): 0 never (the default), 1 the image stems, 2 also the short-K 1x1 layers (A/B on one box)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
     ap.add_argument('--bind', action='store_true', help='pin every rank to its own CPU set (the GPU\'s NUMA node split among the ranks that share it): 8 launch threads of ~500 launches per step each do not migrate or share cores')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
@@ -516,8 +515,6 @@ def main():
 
     if args.fusion is not None:
         eng.set_epilogue_fusion(args.fusion)
-    if args.persistent_gemm is not None:
-        eng.set_persistent_gemm(args.persistent_gemm)
     if not args.no_pipeline and not args.serial:
         eng.set_pipeline(_pipe_level(W.pipeline))      # inputs are resident and never modified: the pipelining contract holds
     step = W.step

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define XFR_AMD_ABI_VERSION 3
+#define XFR_AMD_ABI_VERSION 4
 
 typedef enum {
     XFR_OK = 0,
@@ -266,14 +266,6 @@ xfr_status xfr_engine_hold_forward(xfr_engine* e, int32_t hold);
  * bits between batch sizes / positions.  enable = 0 restores batch-invariant arithmetic (every output element is
  * accumulated in one K order regardless of the batch). */
 xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable);
-
-/* The persistent wave-specialised GEMM kernel (xfr_amd/csrc/conv_ws.hip: workgroups that walk a list of tiles, four math waves behind a ring
- * that never drains, four epilogue waves).  level 0 (default): never.  level 1: the image stems (Cin <= 4; the 7x7 first layers of ResNet-101 /
- * ResNet-50-128d).  level 2: also the short-K 1x1 stride-1 layers (K <= 256, >= 1536 tiles).  Round 4 measured it: the
- * short-K layers +5..8 % in isolation, level in the engine's serial schedule, -1.7 % in the timed three-stream step; the stems level everywhere
- * (their gather, not their prologue, bounds them) -- hence off.  It sums K in the order of the kernel it replaces: switching changes no bit
- * (tests/test_gpu_parity.py).  ABI version 3. */
-xfr_status xfr_engine_set_persistent_gemm(xfr_engine* e, int32_t level);
 
 /* xfr_forward on batches of >= 32 images runs as two half batches on the engine's two internal streams and joins them on the caller's stream
  * (on by default; enable = 0: one forward on the caller's stream).  Images are independent; a sample's values can differ in the last fp32 bits

@@ -362,3 +362,14 @@ def test_image_mwp_of_every_backbone(gpu_device, arch, mode):
         got, want = subj.wb.P[k].cpu().numpy(), ow.P[k].numpy()
         assert got.shape == want.shape and np.abs(want).max() > 0
         assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max(), (arch, k)
+    # the on-demand P[-1] while plain calls are pipelined (levels 2 and 6: two / three forward slots): the gather must read the image of ITS call
+    ref = subj.wb.P[-1].clone()
+    eng = subj.wb._engine(1)
+    x2 = make_images(arch, 1, seed=10)
+    for level in (2, 6):
+        eng.set_pipeline(level)
+        for xi in (x2, x, x2, x):                # leaves the slot counter off 0 and another image in the other slots
+            subj.wb.ebp(xi, P2)
+        subj.wb.ebp(x, P2)
+        assert torch.equal(subj.wb.P[-1], ref), level
+    eng.set_pipeline(0)

@@ -535,35 +535,6 @@ def test_epilogue_fusion_is_bit_identical(gpu_device, arch, mode):
             assert torch.equal(a, b), level
 
 
-@pytest.mark.parametrize('arch,mode,n', [('stresnet101', 'affineonly_with_prior', 16), ('resnet50_128', 'norelu', 16), ('lightcnn29v2', 'affineonly', 32),
-                                         ('lightcnn29v2', 'all', 16)])
-def test_persistent_gemm_is_bit_identical(gpu_device, arch, mode, n):
-    """xfr_engine_set_persistent_gemm: the persistent wave-specialised kernel (conv_ws.hip: math waves + epilogue waves, tiles streamed
-    through one workgroup) sums K in the order of the one-tile-per-workgroup kernel it replaces and runs the same compiled epilogues --
-    identical bits for encodings and maps, with batches large enough that its launch rules (image stems; K <= 256, >= 1536 tiles) select it for
-    the 7x7 stems (gathered input, true and clamped), the forward 1x1 layers (BatchNorm / residual / ReLU, MaxFeatureMap epilogues), the dual
-    W / relu(W) launches and the backward chain GEMMs."""
-    bb, sd = make_backbone(arch, seed=6, num_classes=None if arch == 'resnet50_128' else 7)
-    subj = GC.engine_subject(arch, bb, mode)
-    wb = subj.wb
-    x = make_images(arch, n, seed=33, smooth=True).to(gpu_device)
-    D = emb_dim(arch)
-    xm = (synth.unit_rows(n, D, seed=3) / 2500).to(gpu_device)
-    xn = (synth.unit_rows(n, D, seed=4) / 2500).to(gpu_device)
-    subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
-    eng = wb._engine(2 * n)
-    res = {}
-    for level in (2, 1, 0):         # stems + short-K 1x1 layers | stems only | never (the default)
-        eng.set_persistent_gemm(level)
-        res[level] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
-                      wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone())
-    eng.set_persistent_gemm(0)      # the default
-    for level in (2, 1):
-        for a, b in zip(res[level], res[0]):
-            assert torch.isfinite(a).all()
-            assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize('mode', ['affineonly', 'affineonly_with_prior', 'all'])
 def test_maxfeaturemap_net_outside_the_signature_table(gpu_device, mode):
     """A Conv -> Split -> max network whose merged fan-out chain is NOT in chain_sigs.inc (a Multiply between two MaxFeatureMap layers: the

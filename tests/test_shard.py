@@ -70,6 +70,13 @@ def test_normalize_gpus_like_the_reference():
     assert shard.normalize_gpus([1], env={'CUDA_VISIBLE_DEVICES': '3,2'}) == [2]
     assert shard.normalize_gpus([1], env={'HIP_VISIBLE_DEVICES': '6,1', 'CUDA_VISIBLE_DEVICES': '3,2'}) == [1]
     assert shard.normalize_gpus([0], env={'ROCR_VISIBLE_DEVICES': 'GPU-abcdef'}) == ['GPU-abcdef']
+    # both levels set: HIP indices refer to the ROCR-filtered list
+    assert shard.normalize_gpus([0, 1], env={'ROCR_VISIBLE_DEVICES': '4,5,6,7', 'HIP_VISIBLE_DEVICES': '2,0'}) == [6, 4]
+    with pytest.raises(ValueError):
+        shard.normalize_gpus([0], env={'ROCR_VISIBLE_DEVICES': '4,5', 'HIP_VISIBLE_DEVICES': '3'})
+    # fewer CPUs than local ranks: a report, not an exception
+    rep = shard.bind_rank_cpus(0, 4, nodes=[None] * 4, allowed=[0, 1])
+    assert rep['cpus'] is None and rep['how'].startswith('not bound')
     # more GPUs than visible / index outside the range: ValueError (utils.py:528-529, 535-536)
     with pytest.raises(ValueError):
         shard.normalize_gpus([0, 1, 2], env={'HIP_VISIBLE_DEVICES': '0,1'})

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libxfr_amd.so')
 
 XFR_OK, XFR_INVALID_ARG, XFR_UNSUPPORTED_LAYER, XFR_OOM, XFR_HIP_ERROR, XFR_STATE_ERROR, XFR_RCCL_ERROR = range(7)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class TensorView(ctypes.Structure):
@@ -47,7 +47,6 @@ SYMBOLS = [
     ('xfr_engine_set_pipeline', _I, [_P, _I]),
     ('xfr_engine_set_inputs_ready', _I, [_P, _I]),
     ('xfr_engine_set_tail_balance', _I, [_P, _I]),
-    ('xfr_engine_set_persistent_gemm', _I, [_P, _I]),
     ('xfr_engine_set_forward_split', _I, [_P, _I]),
     ('xfr_engine_hold_forward', _I, [_P, _I]),
     ('xfr_engine_set_epilogue_fusion', _I, [_P, _I]),

@@ -232,14 +232,12 @@ struct ConvParams {
     int in_nb, out_nb;  // images per channel row of the input / output tensors (>= NB: a launch may cover a batch prefix)
     unsigned in_bytes;  // byte size of the input tensor (buffer descriptor range; < 2^31)
     int force_cfg;      // 0 = heuristic tile choice, else a configuration id (tuning / tests)
-    int ws_debug;       // tuning only (xfr_debug_conv cfg 18 / 19): 1 = the persistent kernel's epilogue waves store nothing
     int pair_m;         // > 0: the launch covers exactly TWO gradient streams of pair_m = B * OH * OW columns each (M = 2 * pair_m): where pair_m is a
                         // multiple of the tile width the m-tiles are walked stream-interleaved (tile 2j = stream 0's j-th, 2j + 1 = stream 1's j-th),
                         // so the forward-side operands of the epilogue chain -- the same for both streams -- are fetched from HBM once and hit L2 the
                         // second time.  Which workgroup computes which tile changes; no arithmetic does.
     int as_strided;     // a stride-2 1x1 backward-data GEMM whose result stays on its own (compact) grid (EW_AVGUP_IN): tile configuration -- hence K
                         // order -- of the scattering launch it replaces
-    int ws_level;       // the persistent wave-specialised kernel (conv_ws.hip): 0 = never, 1 = image stems (Cin <= 4), 2 = also the short-K 1x1 layers
     // tail balancing (conv_gemm.hip): the last tiles % CUs tiles of a small grid are cut along K into tail_s parts
     // each, so that every CU gets the same share of the final round; parts meet in tail_ws, the last arriver reduces.
     float* tail_ws;     // scratch for the parts' accumulators (nullptr: never balance); one per stream in flight
@@ -287,11 +285,6 @@ bool launch_conv_gemm(const ConvParams& p, hipStream_t s);
 int conv_gemm_cannot_launch(const ConvParams& p);
 const char* conv_gemm_refusal(int why);
 int conv_gemm_pick_cfg(const ConvParams& p);
-// conv_ws.hip: the persistent wave-specialised kernel for 1x1 stride-1 layers.  conv_ws_ok: the launch fits its scope (its chain, if any,
-// must also have a compiled epilogue); launch_conv_ws: q with the chain already planned (chain_sig, chain_ld), cfg 8 = (BK 16, 3 stages),
-// 9 = (16, 4)
-bool conv_ws_ok(const ConvParams& p);
-void launch_conv_ws(const ConvParams& q, int cfg, hipStream_t s);
 
 // g = src[idx]; run chain; dst[idx] = (accumulate ? dst[idx] : 0) + g.   Tensors are [C][SB][HW] for the gradient
 // and [C][B][HW] for the forward-side sources (sample b = sb % B).

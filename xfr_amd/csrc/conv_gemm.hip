@@ -1242,20 +1242,6 @@ int conv_gemm_pick_cfg(const ConvParams& p)
     // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.
     // K >= 512: the intra-workgroup split-K kernel (tools/conv_sweep.py, round 3: +6..13 % on the 3x3 layers and the K = 512 /
     // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
-    // Short-K 1x1 layers on grids of at least two tiles per resident workgroup: the persistent wave-specialised kernel (conv_ws.hip).  It sums K
-    // in conv_gemm_kernel's order, so choosing by the grid size (a property of the batch) changes no bit.
-    if (p.ws_level >= 2 && p.tap_major != 2 && p.K <= 256 && !p.as_strided && conv_ws_ok(p)) {
-        const long t = (long)((p.CoutTot + 63) / 64) * p.nhalves * ((p.M + 63) / 64);
-        if (t >= 1536) return 9;
-    }
-    // Image stems (Cin <= 4, 7x7) on the persistent kernel: the per-lane window arithmetic once per tile INSIDE a running ring, no prologue
-    // after the first tile; K order of conv_gemm_kernel, same bits.  Measured (round 4, tools/conv_sweep.py row 13): 0.2325 ms against 0.2304
-    // for conv_gemm_kernel once its tap mask is built separably (was 0.264-0.279), 0.212 with epilogue waves that store nothing -- the
-    // 4-byte gather loads bound the layer either way.  Not the default (ws_level 0).
-    if (p.ws_level >= 1 && p.tap_major == 2 && conv_ws_ok(p)) {
-        const long t = (long)((p.CoutTot + 63) / 64) * ((p.M + 63) / 64);
-        if (t >= 1536) return 9;
-    }
     // Channel counts that leave the last 64-row tile at most half full (Light-CNN: 96 = 64 + 32): the 32 x 128 block tile wastes no MFMA row.
     // A property of the layer; K order of the 64 x 64 tile, so the bits do not move where that one ran before.
     {
@@ -1355,20 +1341,6 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
             return r;
         }();
         if (p.force_cfg <= 0 && cfg >= 0 && cfg < 32) cfg = remap.v[cfg];
-    }
-    // cfg 8 / 9: the persistent wave-specialised kernel (conv_ws.hip) for 1x1 stride-1 layers whose chain, if any, is compiled
-    if ((cfg == 8 || cfg == 9 || cfg == 18 || cfg == 19) && conv_ws_ok(p)) {
-        ConvParams q = p;
-        q.ws_debug = cfg >= 18 ? 1 : 0;             // 18 / 19 (tuning only): 8 / 9 with epilogue waves that store nothing
-        q.tail_q = 0;
-        q.tail_s = 1;
-        bool ws = true;
-        if (q.chain.n > 0) {
-            if (plan_chain(q)) return false;
-            ws = q.chain_sig >= 0;               // an interpreted chain stays on conv_gemm_kernel
-            if (ws) g_chain_launches[0]++;
-        }
-        if (ws) { launch_conv_ws(q, cfg, s); return true; }
     }
     // cfg 6 / 7: the intra-workgroup split-K kernel, (BK, ring stages) = (8, 3): 48 KB of LDS, three workgroups per CU; (4, 4): 32 KB, five.
     // Round 3 sweep (tools/conv_sweep.py): (4, 5) and (4, 6) tie with (4, 4), (16, 3) -- one workgroup per CU -- loses 15 %.

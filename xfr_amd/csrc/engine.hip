@@ -199,7 +199,6 @@ struct xfr_engine {
     int n_tail_ws = 0;
     bool tail_balance = true;          // xfr_engine_set_tail_balance
     bool split_forward = true;         // xfr_engine_set_forward_split: forward-only batches of >= 32 images as two halves on the internal streams
-    int persistent_gemm = 0;           // xfr_engine_set_persistent_gemm: conv_ws.hip for 0 = nothing (default: round 4 measured no gain), 1 = the image stems, 2 = also the short-K 1x1 layers
     bool interpret_chains = false;     // xfr_engine_set_epilogue_fusion bit 2: fused chains run through the interpreted epilogue (tests)
     bool planning_only = false;        // xfr_plan_describe: list what the planner WOULD fuse, whatever the signature table holds
     bool fuse_probe_fwd = true;        // probe forward (with the positive pass): BatchNorm / ReLU in the (dual) GEMM's epilogue (STORE raw, [FORK positive
@@ -584,7 +583,6 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
     p.chain_interpret = e->interpret_chains ? 1 : 0;
-    p.ws_level = e->persistent_gemm;
     p.tail_force = 1;
     if (e->tail_balance) {
         p.tail_force = 0;
@@ -859,11 +857,19 @@ bool fuse_mfm_forward(xfr_engine* e, int k, int B, bool keep_raw, ConvParams& p)
             }
         }
     }
-    {
-        EwChain probe = ch;
-        EwLoads ld;
-        ew_plan_loads(probe, dst, ld, EW_FWD_SLOTS_WIDE);
-        if (!e->planning_only && ((((long)B * t.HW()) & 3) != 0 || conv_gemm_chain_sig(probe) < 0)) return false;
+    if (!e->planning_only) {
+        if ((((long)B * t.HW()) & 3) != 0) return false;
+        auto compiled = [&](const EwChain& c, const float* d) { EwChain probe = c; EwLoads ld; ew_plan_loads(probe, d, ld, EW_FWD_SLOTS_WIDE); return conv_gemm_chain_sig(probe) >= 0; };
+        if (!compiled(ch, dst)) {
+            // a network outside the signature table: without the resblock's Add the chain is [STORE raw,] MAXPAIR again (the Add keeps its kernel)
+            if (k3 < 0) return false;
+            ch.n = 0;
+            if (keep_raw) push(EW_STORE).pstore = e->T(o.d.out);
+            push(EW_MAXPAIR);
+            dst = e->T(e->ops[o.pair_max].d.out);
+            k3 = -1;
+            if (!compiled(ch, dst)) return false;
+        }
     }
     p.chain = ch;
     p.out0 = dst;
@@ -2262,18 +2268,24 @@ xfr_status xfr_forward(xfr_engine* e, const float* x_dev, int32_t n, int32_t ten
         HIP_TRY(hipEventRecord(e->ev_fork, s));          // after everything already on the caller's stream (inputs, earlier sweeps)
         HIP_TRY(hipStreamWaitEvent(e->s_a, e->ev_fork, 0));
         HIP_TRY(hipStreamWaitEvent(e->s_b, e->ev_fork, 0));
+        // whatever was enqueued on the internal streams (also by a half that then failed) is ordered before anything the caller puts on s next
+        auto join = [&]() -> xfr_status {
+            HIP_TRY(hipEventRecord(e->ev_a, e->s_a));
+            HIP_TRY(hipEventRecord(e->ev_b, e->s_b));
+            HIP_TRY(hipStreamWaitEvent(s, e->ev_a, 0));
+            HIP_TRY(hipStreamWaitEvent(s, e->ev_b, 0));
+            return XFR_OK;
+        };
         e->t_bank = e->ws_enc;
         st = forward_all(e, x_dev, n0, tensor_id, false, e->s_a);
-        if (st != XFR_OK) return st;
+        if (st != XFR_OK) { const std::string why = g_err; join(); g_err = why; return st; }
         launch_cnhw_to_nchw(e->T(tensor_id), out_dev, n0, t.C, t.HW(), e->s_a);
         e->t_bank = nullptr;
         st = forward_all(e, x_dev + (size_t)n0 * in_per_n, n - n0, tensor_id, false, e->s_b);
-        if (st != XFR_OK) return st;
+        if (st != XFR_OK) { const std::string why = g_err; join(); g_err = why; return st; }
         launch_cnhw_to_nchw(e->T(tensor_id), out_dev + (size_t)n0 * t.per_n(), n - n0, t.C, t.HW(), e->s_b);
-        HIP_TRY(hipEventRecord(e->ev_a, e->s_a));
-        HIP_TRY(hipEventRecord(e->ev_b, e->s_b));
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_a, 0));
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_b, 0));
+        st = join();
+        if (st != XFR_OK) return st;
         HIP_TRY(hipGetLastError());
         st = fence_slot0(e, s);
         if (st != XFR_OK) return st;
@@ -2498,14 +2510,6 @@ xfr_status xfr_engine_set_forward_split(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     e->split_forward = enable != 0;
-    return XFR_OK;
-}
-
-xfr_status xfr_engine_set_persistent_gemm(xfr_engine* e, int32_t enable)
-{
-    if (!e) return fail(XFR_INVALID_ARG, "null engine");
-    if (enable < 0 || enable > 2) return fail(XFR_INVALID_ARG, "xfr_engine_set_persistent_gemm: level must be 0, 1 or 2");
-    e->persistent_gemm = enable;
     return XFR_OK;
 }
 
@@ -2783,7 +2787,13 @@ xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, in
         if (!out_dev) return XFR_OK;
         e->rc_priors = e->rc_caps = false;
         e->store_slot = -1;
-        st = ebp_core(e, x_dev, n, 1, seed_tensor, seed_dev, s);
+        {
+            // un-pipelined on purpose: the gather below reads the image from forward slot 0 on the caller's stream; a pipelined call would have
+            // put it into slot seq % n_slots on an internal stream (and ebp_core resets cur_slot before it returns)
+            struct Unpipe { xfr_engine* e; bool was; ~Unpipe() { e->pipeline_all = was; } } unpipe{e, e->pipeline_all};
+            e->pipeline_all = false;
+            st = ebp_core(e, x_dev, n, 1, seed_tensor, seed_dev, s);
+        }
         if (st != XFR_OK) return st;
         const OpRec& o = e->ops[0];
         const xfr_op_desc& d = o.d;
@@ -2791,7 +2801,7 @@ xfr_status xfr_ebp_store_firing(xfr_engine* e, const float* x_dev, int32_t n, in
         launch_image_mwp(e->G(d.out), e->arena + o.w_pos, e->T(0), out_dev, e->in_c, n, e->in_h, e->in_w, d.cout, t1.H, t1.W, d.kh, d.kw, d.stride,
                          d.pad, o.ldw, o.tap4_fwd ? 2 : (o.tap_fwd ? 1 : 0), o.pair, s);
         HIP_TRY(hipGetLastError());
-        return XFR_OK;
+        return fence_slot0(e, s);           // the gather still reads slot 0: a later pipelined forward into it waits for THIS point
     }
     const Tensor& x = e->tens[plan->firing_tensor[firing]];
     if (c) *c = x.C;

@@ -215,19 +215,12 @@ class Engine(object):
         _lib.check(self.lib.xfr_engine_set_forward_split(self._h, int(bool(on))))
         self.options['forward_split'] = bool(on)
 
-    def set_persistent_gemm(self, level):
-        """The persistent wave-specialised kernel: 0 never (default), 1 the image stems, 2 also the short-K 1x1 layers (include/xfr_amd.h)."""
-        _lib.check(self.lib.xfr_engine_set_persistent_gemm(self._h, int(level)))
-        self.options['persistent_gemm'] = int(level)
-
     def apply_options(self, options):
         """Re-apply switches recorded by another Engine handle (WhiteboxNetwork.engine rebuilds engines that are too small)."""
         if 'tail_balance' in options:
             self.set_tail_balance(options['tail_balance'])
         if 'forward_split' in options:
             self.set_forward_split(options['forward_split'])
-        if 'persistent_gemm' in options:
-            self.set_persistent_gemm(options['persistent_gemm'])
         if 'epilogue_fusion' in options:
             self.set_epilogue_fusion(options['epilogue_fusion'])
         if options.get('pipeline'):

@@ -16,11 +16,13 @@ NET_SIDE = 224          # utils.py:189 imgScale
 
 
 def imread(fn):
-    """Decoded pixels of an image file as the decoder stores them: uint8, H x W (grey) or H x W x C."""
+    """Decoded pixels of an image file as the decoder stores them: uint8, H x W (grey) or H x W x C.  Supported: 8-bit grey, RGB and RGBA
+    files (PIL modes L / RGB / RGBA), for which PIL and the reference's imageio return the same array.  Anything else (palette, LA, 16-bit,
+    CMYK ...) raises: imageio would hand back the decoder's native dtype / channel count there and a silent conversion would diverge."""
     import PIL.Image
     with PIL.Image.open(fn) as im:
         if im.mode not in ('L', 'RGB', 'RGBA'):
-            im = im.convert('RGB')
+            raise ValueError('%s: unsupported image mode %r (8-bit grey / RGB / RGBA files only)' % (fn, im.mode))
         return np.asarray(im).copy()
 
 

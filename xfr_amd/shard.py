@@ -79,26 +79,30 @@ def gather_maps(local_maps, n_total):
 
 def normalize_gpus(gpus, env=None):
     """Logical GPU indices (command line, LOCAL_RANK) -> the ids the runtime was told to expose, like the reference's
-    `normalize_gpus` does with CUDA_VISIBLE_DEVICES (python/xfr/utils.py:515-540) -- here through HIP_VISIBLE_DEVICES, then
-    ROCR_VISIBLE_DEVICES, then CUDA_VISIBLE_DEVICES (ROCm honours all three).  No mask set: the list is returned unchanged.
-    Raises ValueError like the reference when an index lies outside the visible range."""
+    `normalize_gpus` does with CUDA_VISIBLE_DEVICES (python/xfr/utils.py:515-540).  ROCm composes its masks: ROCR_VISIBLE_DEVICES filters
+    the agents the HIP runtime sees, HIP_VISIBLE_DEVICES (or, when that is unset, CUDA_VISIBLE_DEVICES) then indexes the FILTERED list --
+    so a logical index goes through the HIP-level mask first and its result through the ROCR mask.  No mask set: the list is returned
+    unchanged.  Raises ValueError like the reference when an index lies outside a visible range."""
     env = os.environ if env is None else env
-    mask = None
-    for name in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
-        if env.get(name):
-            mask = env[name]
-            break
-    if not mask:
-        return list(gpus)
-    visible = [v.strip() for v in mask.split(',')]
-    if len(visible) < len(gpus):
-        raise ValueError('more GPUs requested than are visible through the *_VISIBLE_DEVICES mask')
-    out = []
-    for g in gpus:
-        if not 0 <= int(g) < len(visible):
-            raise ValueError('GPU %s is outside the visible range' % (g,))
-        v = visible[int(g)]
-        out.append(int(v) if v.lstrip('-').isdigit() else v)
+
+    def through(ids, mask, name):
+        visible = [v.strip() for v in mask.split(',')]
+        if len(visible) < len(ids):
+            raise ValueError('more GPUs requested than are visible through %s' % name)
+        out = []
+        for g in ids:
+            if not str(g).lstrip('-').isdigit() or not 0 <= int(g) < len(visible):
+                raise ValueError('GPU %s is outside the range visible through %s' % (g, name))
+            v = visible[int(g)]
+            out.append(int(v) if v.lstrip('-').isdigit() else v)
+        return out
+
+    out = list(gpus)
+    hip_name = 'HIP_VISIBLE_DEVICES' if env.get('HIP_VISIBLE_DEVICES') else 'CUDA_VISIBLE_DEVICES'
+    if env.get(hip_name):
+        out = through(out, env[hip_name], hip_name)
+    if env.get('ROCR_VISIBLE_DEVICES'):
+        out = through(out, env['ROCR_VISIBLE_DEVICES'], 'ROCR_VISIBLE_DEVICES')
     return out
 
 
@@ -152,7 +156,10 @@ def bind_rank_cpus(local, local_world, nodes=None, allowed=None):
         except Exception:
             mine = None
     if mine is None:
-        mine = cpu_slices(allowed, local_world)[local]
+        try:
+            mine = cpu_slices(allowed, local_world)[local]
+        except ValueError as ex:        # fewer allowed CPUs than local ranks: leave the affinity alone and say so
+            return {'cpus': None, 'n_cpus': len(allowed), 'numa_node': node, 'how': 'not bound (%s)' % (ex,)}
     try:
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(len(mine), torch.get_num_threads())))
