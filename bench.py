@@ -470,6 +470,7 @@ def main():
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 10 s sustained loop after the timed region')
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
+    ap.add_argument('--no-lean', action='store_true', help='xfr_engine_set_lean(0): the literal hook operands in every sweep (A/B against the default lean schedule)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
     ap.add_argument('--bind', action='store_true', help='pin every rank to its own CPU set (the GPU\'s NUMA node split among the ranks that share it): 8 launch threads of ~500 launches per step each do not migrate or share cores')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
@@ -515,6 +516,8 @@ def main():
 
     if args.fusion is not None:
         eng.set_epilogue_fusion(args.fusion)
+    if args.no_lean:
+        eng.set_lean(False)
     if not args.no_pipeline and not args.serial:
         eng.set_pipeline(_pipe_level(W.pipeline))      # inputs are resident and never modified: the pipelining contract holds
     step = W.step

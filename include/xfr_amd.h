@@ -267,6 +267,20 @@ xfr_status xfr_engine_hold_forward(xfr_engine* e, int32_t hold);
  * accumulated in one K order regardless of the batch). */
 xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable);
 
+/* The lean schedule (on by default; ABI version 4).  A sweep nobody observes (no trace, prior, capture or stored firing; batch % 4 == 0) does not
+ * need the literal operands a and x of whitebox.py:388-428 at every hook: the probe forward's W / relu(W) convolution forms the BatchNorm hook's
+ * a / (x + eps) in its epilogue (both accumulators in one workgroup) and stores that ONE tensor instead of the two, with the sign bit recording
+ * where the ReLU output behind it is zero; hooks whose x is their a (every Conv / Linear / pool / Add hook) become that one-bit gate.  Per hook the
+ * result differs from the literal expression by at most one ulp (for a >= 1.7e-9; identical at a = 0), so maps agree with the literal path to ~1e-6
+ * of their maximum -- far inside the stated tolerance against the reference -- but not bit for bit.  enable = 0: the literal operands everywhere
+ * (what every observing call -- traces, Whitebox.P[k], layerwise / weighted-subtree EBP -- runs regardless).  Batches that are not a multiple of four
+ * always run literal, so a sample's map can differ in its last digits between a batch of 32 and a batch of 1: callers that need batch-invariant
+ * arithmetic switch this off together with xfr_engine_set_tail_balance. */
+xfr_status xfr_engine_set_lean(xfr_engine* e, int32_t enable);
+/* Convolution launches that took the lean form so far (W and relu(W) accumulated by one workgroup, quotient stored): 0 on an engine whose calls
+ * all ran the literal schedule. */
+xfr_status xfr_engine_lean_stats(xfr_engine* e, int64_t* dual_launches);
+
 /* xfr_forward on batches of >= 32 images runs as two half batches on the engine's two internal streams and joins them on the caller's stream
  * (on by default; enable = 0: one forward on the caller's stream).  Images are independent; a sample's values can differ in the last fp32 bits
  * from the unsplit run exactly as they do between two batch sizes (tail balancing, see xfr_engine_set_tail_balance).  ABI version 3. */

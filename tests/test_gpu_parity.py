@@ -307,6 +307,9 @@ def test_resnet101_batch32_properties(gpu_device):
     probes = imgs
     for balanced, tol in ((False, 1e-5), (True, MAP_RTOL_CONTRAST)):
         wb._engine(B).set_tail_balance(balanced)       # one engine serves every batch size up to B
+        # batch-invariant arithmetic also needs ONE form of the hooks for every batch size: the lean schedule applies to batches that are a
+        # multiple of four (32 yes, 1 no), so the strict leg runs the literal schedule; the default leg compares lean (32) with literal (1)
+        wb._engine(B).set_lean(balanced)
         sal = wb.contrastive_triplet_ebp_batch(probes, em, en)
         assert tuple(sal.shape) == (B, 112, 112)
         assert bool(torch.isfinite(sal).all()) and float(sal.min()) >= 0.0
@@ -516,6 +519,7 @@ def test_epilogue_fusion_is_bit_identical(gpu_device, arch, mode):
     xn = (synth.unit_rows(n, D, seed=4) / 2500).to(gpu_device)
     subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
     eng = wb._engine(2 * n)
+    eng.set_lean(False)        # the fusion levels re-arrange the LITERAL arithmetic (the lean schedule only exists at level 3: test_lean_schedule_equals_literal)
     res = {}
     # default; everything un-fused; plus the probe forward's BatchNorm / ReLU (FORK / STORE chains); the interpreted epilogue
     # ... and (11) the default with Light-CNN's pool pairs as separate kernels / VJP launches (0 has them separate too, on the un-fused schedule)
@@ -530,6 +534,7 @@ def test_epilogue_fusion_is_bit_identical(gpu_device, arch, mode):
                       wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone(),
                       wb.triplet_images_ebp_batch(x[:2], x[2:4], x[1:3]).clone())
     eng.set_epilogue_fusion(3)
+    eng.set_lean(True)
     for level in (0, 3, 5, 11, 19, 35, 67, 131, 259):
         for a, b in zip(res[1], res[level]):
             assert torch.equal(a, b), level
@@ -581,3 +586,58 @@ def test_maxfeaturemap_net_outside_the_signature_table(gpu_device, mode):
         want = P[-2].sum(dim=1)[0].numpy()          # MWP at the first convolution's output, channel-pooled (whitebox.py:499)
         assert_map_close(got[i], want, 'out-of-table MaxFeatureMap net, sample %d, %s' % (i, mode))
     eng.close()
+
+
+@pytest.mark.parametrize('arch,mode,n', [('stresnet101', 'affineonly_with_prior', 8), ('stresnet101', 'norelu', 4), ('stresnet101', 'affineonly', 4),
+                                         ('resnet50_128', 'norelu', 8), ('resnet50_128', 'affineonly_with_prior', 4), ('resnet50_128', 'all', 4),
+                                         ('stresnet_mini', 'all', 4), ('lightcnn29v2', 'affineonly', 4)])
+def test_lean_schedule_equals_literal(gpu_device, arch, mode, n):
+    """xfr_engine_set_lean (the default): an un-observed sweep reads a stored quotient a / (x + eps) at the BatchNorm (and dividing ReLU) hooks
+    and a one-bit gate at every hook whose x is its a, instead of the literal operands of whitebox.py:388-428.  Per hook that is at most one ulp
+    away from the literal expression; here: encodings identical, contrastive / truncated / plain-EBP maps within 1e-5 of the map maximum of
+    the literal schedule (the golden suite runs lean and holds both to the reference at its stated tolerances).  The ResNets really take it
+    (dual-accumulator launches counted), a batch that is not a multiple of four and Light-CNN (no BatchNorm) stay literal."""
+    bb, sd = make_backbone(arch, seed=6, num_classes=None if arch == 'resnet50_128' else 7)
+    subj = GC.engine_subject(arch, bb, mode)
+    wb = subj.wb
+    x = make_images(arch, n, seed=33, smooth=True).to(gpu_device)
+    D = emb_dim(arch)
+    xm = (synth.unit_rows(n, D, seed=3) / 2500).to(gpu_device)
+    xn = (synth.unit_rows(n, D, seed=4) / 2500).to(gpu_device)
+    subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
+    eng = wb._engine(2 * n)
+    res, launches = {}, {}
+    for lean in (1, 0):
+        eng.set_lean(lean)
+        before = eng.lean_launches()
+        res[lean] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
+                     wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone(),
+                     torch.as_tensor(wb.contrastive_ebp(x, 0, 1)), torch.as_tensor(wb.ebp(x[:4], torch.tensor([[1.0, 0.0]]))))
+        launches[lean] = eng.lean_launches() - before
+    assert launches[0] == 0
+    assert (launches[1] > 0) == (arch != 'lightcnn29v2'), launches
+    assert torch.equal(res[1][0], res[0][0])
+    # Plain EBP maps: 1e-5 of the maximum.  Contrastive maps are a difference of two nearly equal normalised MWP tensors under these seeded
+    # weights -- a last-bit change of P shows at 1e-4 .. 1e-3 of the map (parity_utils: the reference moves its OWN map by 5e-4 when one classifier
+    # row moves by an ulp) -- so the lean and the literal sweep, one ulp apart per hook, are held to a fifth of the contrastive tolerance and to the
+    # cosine bar; the truncated map's percentile mask may flip a handful of pixels on top (robust criterion).
+    names = ('contrastive (triplet entry)', 'truncated (triplet entry)', 'contrastive_ebp', 'ebp')
+    for what, a, b in zip(names, res[1][1:], res[0][1:]):
+        a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+        for i in range(a.shape[0]):
+            tag = '%s/%s %s row %d' % (arch, mode, what, i)
+            if what == 'ebp':
+                assert_map_close(a[i], b[i], tag, rtol=1e-5)
+            elif what.startswith('truncated'):
+                assert_map_close_robust(a[i], b[i], tag, rtol=MAP_RTOL_CONTRAST / 5)
+            else:
+                assert_map_close(a[i], b[i], tag, rtol=MAP_RTOL_CONTRAST / 5)
+    # three probes: not a multiple of four -> the literal schedule, bit for bit the lean-off result
+    eng.set_lean(1)
+    before = eng.lean_launches()
+    odd = wb.contrastive_triplet_ebp_batch(x[:3], xm[:3], xn[:3]).clone()
+    assert eng.lean_launches() == before
+    eng.set_lean(0)
+    assert torch.equal(odd, wb.contrastive_triplet_ebp_batch(x[:3], xm[:3], xn[:3]))
+    eng.set_lean(1)
+

@@ -15,6 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODES = ('affineonly', 'affineonly_with_prior', 'norelu', 'all')
 
 
+
+def sig_code(op, s0=7, s1=7, store=0, step=0):
+    """One step of a chain signature (xfr_amd/csrc/common.h): op | s0 << 5 | s1 << 8 | store << 11 | step << 12."""
+    return op | (s0 << 5) | (s1 << 8) | (store << 11) | (step << 12)
+
+
 def _programs():
     return {'stresnet101': resnet.ResNet([3, 4, 23, 3], num_classes=65359).build_program(),
             'stresnet_mini': resnet.ResNet([1, 1, 1, 1], num_classes=5).build_program(),
@@ -87,7 +93,7 @@ def test_residual_blocks_leave_no_glue_launches():
     runs.append(cur)
     assert max(runs) >= 8, runs
     assert 'COPY' not in bwd, bwd
-    assert any(' 2bfd' in ln for ln in lines)          # store-back + fan-out chains behind a GEMM exist and ...
+    assert any(' %04x' % sig_code(13, step=5) in ln for ln in lines)          # store-back + fan-out chains behind a GEMM exist and ...
     assert all('compiled=-1' not in ln for ln in lines)    # ... every one of them has a compiled epilogue
     prog = PROGRAMS['stresnet101']
     lines = prog.describe('affineonly_with_prior', prog.marks['encode']).splitlines()
@@ -117,9 +123,9 @@ def test_downsampling_blocks_take_their_add_into_the_convolution_epilogue():
     prog = PROGRAMS['stresnet101']
 
     def adds(lines, kind):
-        return sum(ln.startswith(kind + ' CONV') and ' 0bb9' in ln.split('SIG')[1] for ln in lines)     # 0bb9 / 13b9: EW_ADDP as step 1 / 2
+        return sum(ln.startswith(kind + ' CONV') and ' %04x' % sig_code(9, s0=3, step=1) in ln.split('SIG')[1] for ln in lines)     # EW_ADDP (prefetch slot 3) as step 1 / 2
     def adds_probe(lines):
-        return sum(ln.startswith('probe CONV') and ' 13b9' in ln for ln in lines)
+        return sum(ln.startswith('probe CONV') and ' %04x' % sig_code(9, s0=3, step=2) in ln for ln in lines)
     lines = prog.describe('affineonly_with_prior', prog.marks['encode']).splitlines()
     assert adds(lines, 'fwd') == 33 and adds_probe(lines) == 33
     os.environ['XFR_DESCRIBE_FUSION'] = '259'

@@ -47,6 +47,8 @@ SYMBOLS = [
     ('xfr_engine_set_pipeline', _I, [_P, _I]),
     ('xfr_engine_set_inputs_ready', _I, [_P, _I]),
     ('xfr_engine_set_tail_balance', _I, [_P, _I]),
+    ('xfr_engine_set_lean', _I, [_P, _I]),
+    ('xfr_engine_lean_stats', _I, [_P, ctypes.POINTER(ctypes.c_int64)]),
     ('xfr_engine_set_forward_split', _I, [_P, _I]),
     ('xfr_engine_hold_forward', _I, [_P, _I]),
     ('xfr_engine_set_epilogue_fusion', _I, [_P, _I]),
@@ -84,6 +86,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError('xfr_amd: %s is missing -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           'or `make -C xfr_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
+    # torch first: PyTorch-ROCm ships its own libamdhip64; loaded after ours, the process would hold two HIP runtimes (ours resolved against
+    # /opt/rocm's) and the engine would see no device through the second one
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)      # AttributeError if the ABI symbol is absent

@@ -18,7 +18,7 @@
 // forward-side tensor with B images per channel row (sample b = sb % B).  For forward launches SB == B.
 enum {
     EW_HOOK = 0,      // tensor hook (whitebox.py:388-428): a = relu(p0[a]), x = relu(p1[a]) or a; p = a*relu(g); action
-    EW_MASK = 1,      // g = p0[a] > 0 ? g : 0                      (in-place ReLU VJP)
+    EW_MASK = 1,      // g = p0[a] > 0 ? g : 0                      (in-place ReLU VJP); action 1: the mask is the sign bit of a stored quotient (HOOK_GATE_SIGN)
     EW_SCALE_C = 2,   // g *= p0[c]                                 (BatchNorm VJP with relu(gamma)*invstd)
     EW_SCALE = 3,     // g *= f                                     (Multiply VJP)
     EW_STORE = 4,     // pstore[g] = g.  action 1: no store -- SAVE g (a branch point); action 2: pstore[g] = g, then g = the saved value: the steps
@@ -54,11 +54,24 @@ enum {
                       // not observed); prior_sb = W.  Same operands, same operations as the four launches: same bits.
                       // action = -2: no pooled source -- the tensor was a zero fill plus strided 1x1 GEMMs (projection shortcut + main path,
                       // resnet50_128.py): g = p2 on the even pixels, 0 elsewhere; the GEMMs accumulate on the compact grid.
+    // Lean probe forward (compiled epilogue of a ConvParams::dualacc launch only; g = W accumulator + bias, gp = relu(W) accumulator + bias):
+    EW_LEAN_Q = 16,   // FIRST step: q = relu(g) / (relu(gp) + eps) is kept in registers -- the BatchNorm hook's a / (x + eps) (whitebox.py:388-428); g unchanged
+    EW_LEAN_XR = 17,  // xr = relu(relu(g) * p0[c] + p1[c] [+ (action & 1 ? relu(p2[g]) : p2[g])]) is kept in registers: what EW_FORK_POSBN would have
+                      // stored, clamped -- the x of the ReLU hook behind the BatchNorm [and the functional add]; g unchanged
+    EW_LEAN_STORE = 18, // LAST steps.  action 0: pstore[g] = q with its sign bit set where the chain's final value g is <= 0 (the ReLU mask and every
+                      // x == a hook of that tensor read the sign, the BatchNorm hook the magnitude); action 1: pstore[g] = g / (xr + eps), the ReLU hook's quotient
     EW_MAXPAIR = 10   // GEMM epilogue only, last step: g = max(g, value of the partner row c ^ 1) -- MaxFeatureMap of a convolution
                       // whose output channels were packed interleaved (row 2c = channel c, row 2c+1 = channel c + Co); the even
                       // rows then store g as channel c of the Co-channel output
 };
-enum { HOOK_DIV = 0, HOOK_RELU = 1, HOOK_PASS = 2 };
+enum { HOOK_DIV = 0, HOOK_RELU = 1, HOOK_PASS = 2,
+       // The "lean" forms of a hook nobody observes (no P store, trace, prior or capture): the probe forward left, instead of the hook's literal
+       // operands a and x, what the sweep needs of them (ConvParams::dualacc; engine.hip lean_rewrite).  Within one ulp per hook of the
+       // literal expression for every a a real network produces -- gated by the golden tolerances, not bit for bit.
+       HOOK_Q = 3,          // g = relu(g) * |p0[a]|:  p0 holds q = a / (x + eps), computed once in the probe forward (BatchNorm and ReLU hooks)
+       HOOK_GATE = 4,       // g = p0[a] > 0 ? relu(g) : 0:  a hook whose x IS its a -- a * relu(g) / (a + eps) = relu(g) wherever a > 1.7e-9, 0 at a = 0
+       HOOK_GATE_SIGN = 5   // the same gate read from the SIGN bit of a stored quotient (set where the gated tensor is <= 0)
+     };
 enum { PRIOR_DIV = 0, PRIOR_PASS = 1, PRIOR_GATEZ = 2 };   // p/(x+eps) | gradient unchanged | (prior>0)*z
 
 struct EwStep {
@@ -145,11 +158,11 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld, int fwd_sl
         st.ls1 = -1;
         if (st.type == EW_MAXHALF_OUT) { fanned = true; continue; }
         if (fanned) {
-            if (st.type == EW_HOOK && !st.pstore && !st.trace && st.action != HOOK_DIV && !st.prior_elem && !st.prior_dense && !st.cap_dst) st.ls0 = -2;
+            if (st.type == EW_HOOK && !st.pstore && !st.trace && (st.action == HOOK_RELU || st.action == HOOK_PASS) && !st.prior_elem && !st.prior_dense && !st.cap_dst) st.ls0 = -2;
             continue;
         }
         if (st.type == EW_HOOK) {
-            if (!st.pstore && !st.trace && st.action != HOOK_DIV && !st.prior_elem && !st.prior_dense && !st.cap_dst) { st.ls0 = -2; continue; }
+            if (!st.pstore && !st.trace && (st.action == HOOK_RELU || st.action == HOOK_PASS) && !st.prior_elem && !st.prior_dense && !st.cap_dst) { st.ls0 = -2; continue; }
             st.ls0 = slot_for(st.p0, 0);
             if (st.action == HOOK_DIV && st.p1) st.ls1 = slot_for(st.p1, 0);
         } else if (st.type == EW_MASK) {
@@ -163,15 +176,16 @@ inline void ew_plan_loads(EwChain& ch, const float* dst, EwLoads& ld, int fwd_sl
 
 // Compile-time signature of a planned chain: one 16-bit code per step that does anything.  The GEMM epilogue is
 // specialised per signature (conv_gemm.hip: the table chain_sigs.inc lists the signatures the three backbones produce;
-// chains outside the table run through the interpreter).  Code = op | s0 << 4 | s1 << 7 | store << 10 | step << 11 with
-// s0 / s1 the prefetch slot of p0 / p1 (0..3), 4 = load in place, 7 = none (a hook whose x is its a).
+// chains outside the table run through the interpreter).  Code = op | s0 << 5 | s1 << 8 | store << 11 | step << 12 with
+// s0 / s1 the prefetch slot of p0 / p1 (0..3, 5, 6), 4 = load in place, 7 = none (a hook whose x is its a).
 enum { SIG_END = 0, SIG_HOOK_DIV = 1, SIG_HOOK_RELU = 2, SIG_HOOK_PASS = 3, SIG_RELU = 4, SIG_MASK = 5, SIG_SCALE_C = 6, SIG_SCALE = 7,
-       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11, SIG_MAXPAIR = 12, SIG_MAXHALF_OUT = 13, SIG_ADDP_CO = 14, SIG_FORK_POSADD = 15 };
-constexpr int sig_op(unsigned c) { return (int)(c & 15u); }
-constexpr int sig_s0(unsigned c) { return (int)((c >> 4) & 7u); }
-constexpr int sig_s1(unsigned c) { return (int)((c >> 7) & 7u); }
-constexpr bool sig_store(unsigned c) { return ((c >> 10) & 1u) != 0; }
-constexpr int sig_step(unsigned c) { return (int)((c >> 11) & 15u); }
+       SIG_STORE = 8, SIG_ADDP = 9, SIG_AFFINE_C = 10, SIG_FORK_POSBN = 11, SIG_MAXPAIR = 12, SIG_MAXHALF_OUT = 13, SIG_ADDP_CO = 14, SIG_FORK_POSADD = 15,
+       SIG_HOOK_Q = 16, SIG_GATE = 17, SIG_GATE_SIGN = 18, SIG_MASK_SIGN = 19, SIG_LEAN_Q = 20, SIG_LEAN_XR = 21, SIG_LEAN_STORE = 22 };
+constexpr int sig_op(unsigned c) { return (int)(c & 31u); }
+constexpr int sig_s0(unsigned c) { return (int)((c >> 5) & 7u); }
+constexpr int sig_s1(unsigned c) { return (int)((c >> 8) & 7u); }
+constexpr bool sig_store(unsigned c) { return ((c >> 11) & 1u) != 0; }
+constexpr int sig_step(unsigned c) { return (int)((c >> 12) & 15u); }
 constexpr bool sig_is_slot(int v) { return v != 4 && v != 7; }
 
 // codes[] of a chain whose prefetch slots are assigned (ew_plan_loads); returns the number of codes, or -1 if the chain
@@ -191,12 +205,13 @@ inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
                     op = SIG_RELU;
                     break;
                 }
-                op = st.action == HOOK_DIV ? SIG_HOOK_DIV : (st.action == HOOK_RELU ? SIG_HOOK_RELU : SIG_HOOK_PASS);
+                op = st.action == HOOK_DIV ? SIG_HOOK_DIV : st.action == HOOK_RELU ? SIG_HOOK_RELU : st.action == HOOK_PASS ? SIG_HOOK_PASS
+                     : st.action == HOOK_Q ? SIG_HOOK_Q : st.action == HOOK_GATE ? SIG_GATE : SIG_GATE_SIGN;
                 s0 = slot(st.ls0);
                 if (st.action == HOOK_DIV && st.p1) s1 = slot(st.ls1);
                 store = st.pstore ? 1u : 0u;
                 break;
-            case EW_MASK: op = SIG_MASK; s0 = slot(st.ls0); break;
+            case EW_MASK: op = st.action == 1 ? SIG_MASK_SIGN : SIG_MASK; s0 = slot(st.ls0); break;
             case EW_SCALE_C: op = SIG_SCALE_C; break;
             case EW_SCALE: op = SIG_SCALE; break;
             case EW_STORE: op = SIG_STORE; if (st.action == 1 || st.action == 2) s0 = (unsigned)st.action; break;     // s0: 7 plain, 1 save, 2 store + restore
@@ -208,9 +223,12 @@ inline int ew_chain_codes(const EwChain& ch, uint16_t codes[XFR_MAX_EW_STEPS])
             case EW_MAXHALF_OUT: op = SIG_MAXHALF_OUT; break;
             case EW_ADDP_CO: op = SIG_ADDP_CO; break;
             case EW_FORK_POSADD: op = SIG_FORK_POSADD; s0 = (unsigned)(st.action & 3); break;      // the two clamp flags are part of the signature
+            case EW_LEAN_Q: op = SIG_LEAN_Q; break;
+            case EW_LEAN_XR: op = SIG_LEAN_XR; if (st.p2) { store = 1; s1 = (unsigned)(st.action & 1); } break;     // like SIG_FORK_POSBN
+            case EW_LEAN_STORE: op = SIG_LEAN_STORE; s0 = (unsigned)(st.action & 1); break;                          // s0: which quotient
             default: return -1;
         }
-        codes[n++] = (uint16_t)(op | (s0 << 4) | (s1 << 7) | (store << 10) | ((unsigned)i << 11));
+        codes[n++] = (uint16_t)(op | (s0 << 5) | (s1 << 8) | (store << 11) | ((unsigned)i << 12));
     }
     return n;
 }
@@ -252,6 +270,8 @@ struct ConvParams {
     int OH, OW;
     int K, M;           // M = NB*OH*OW
     int CoutTot, nhalves, ldw;   // CoutTot = output channels per half
+    int dualacc;        // 1 (nhalves == 1): every workgroup accumulates W AND relu(W) -- taken from the W fragment in registers, no second pack is read -- over the
+                        // same staged input tile; the chain (compiled, first step EW_LEAN_Q) sees both.  The lean probe forward: bias_pos is the second bias
     int relu_in;        // clamp the gathered input at 0 (A = relu(input))
     int accumulate;     // out += result
     int out_H, out_W, out_stride;  // out_stride > 1: scatter the (OH,OW) grid into an (out_H,out_W) tensor

@@ -48,8 +48,10 @@ enum { MODE_VEC = 0, MODE_TAP = 1, MODE_GEN = 2, MODE_TAP4 = 3 };
 // groups hf, one float4 piece (channel hf*8 + lane/8, positions 4*(lane%8)..+3).  The operand loads of groups 0 and 1 are
 // issued first -- before the accumulators are turned through LDS -- and those of group hf+2 right after group hf's have been
 // consumed, so two groups' worth of HBM requests are in flight per lane instead of one dependent round trip per group.
+// Lean probe-forward signatures (sig_is_dual): accp is the wave's relu(W) accumulator tile of the same quadrant; it is turned through the same LDS
+// tile first and kept as four pieces (+ bias_pos) in registers.
 template <int SIG>
-__device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& acc, float* tile, int lane, int l31, int lhi,
+__device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& acc, const v16f* accp, float* tile, int lane, int l31, int lhi,
                                                int co_base, int m, float* __restrict__ osel, const float* __restrict__ bsel)
 {
     constexpr int LD = 36;
@@ -84,6 +86,19 @@ __device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& 
     // __syncthreads(): that one would first drain the operand loads just issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    float4 gpv[4];
+    if constexpr (sig_is_dual<SIG>()) {
+        // the tile is this wave's own: its LDS operations execute in order, the waits only keep the compiler from moving them
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = (*accp)[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int hf = 0; hf < 4; ++hf) {
+            gpv[hf] = *reinterpret_cast<const float4*>(tile + (hf * 8 + (lane >> 3)) * LD + mq);
+            if (p.bias_pos && ok[hf]) { const float b = p.bias_pos[cos[hf]]; gpv[hf].x += b; gpv[hf].y += b; gpv[hf].z += b; gpv[hf].w += b; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = acc[r];
     float4* out4 = reinterpret_cast<float4*>(osel);
@@ -92,6 +107,8 @@ __device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& 
         const int cl = hf * 8 + (lane >> 3);
         const float4 gv = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
         float g[4] = {gv.x, gv.y, gv.z, gv.w};
+        LeanRegs lr;
+        if constexpr (sig_is_dual<SIG>()) { lr.gp[0] = gpv[hf].x; lr.gp[1] = gpv[hf].y; lr.gp[2] = gpv[hf].z; lr.gp[3] = gpv[hf].w; }
         if (bsel && ok[hf]) { const float b = bsel[cos[hf]]; g[0] += b; g[1] += b; g[2] += b; g[3] += b; }
         if constexpr (sig_has_maxpair<SIG>()) {
             float4 w = *reinterpret_cast<const float4*>(tile + (cl ^ 1) * LD + mq);
@@ -102,7 +119,7 @@ __device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& 
         if constexpr (sig_has_fanout<SIG>()) { ops[hf].out4 = out4; ops[hf].row4 = row4; ops[hf].arow4 = arow4; }
         if (ok[hf]) {
             float sv[4] = {0.f, 0.f, 0.f, 0.f};
-            epi_steps<SIG, 0>(g, sv, ops[hf], p.chain, idx4[hf], aidx4[hf], p.chain_eps);
+            epi_steps<SIG, 0>(g, sv, lr, ops[hf], p.chain, idx4[hf], aidx4[hf], p.chain_eps);
             if constexpr (sig_has_fanout<SIG>()) {
                 // stored by the fan-out
             } else if constexpr (sig_has_maxpair<SIG>()) {
@@ -146,15 +163,19 @@ __device__ __forceinline__ void dense_epilogue(const ConvParams& p, const v16f& 
 // loads and a chain tail that runs twice) need ~10 registers more than the rest, and a kernel's register count -- hence how many
 // workgroups share a CU -- is the maximum over everything it contains.  MFM = false: every other signature (all ResNet chains).
 
-template <int SIG, bool MFM>
-__device__ __forceinline__ void chain_epilogue_dispatch(int sig, const ConvParams& p, const v16f& acc, float* tile, int lane, int l31,
+// ... FAM 2: the lean probe-forward signatures, which need the second accumulator tile (kernels compiled with CHAIN == 4)
+template <int SIG>
+constexpr int sig_family() { return sig_is_dual<SIG>() ? 2 : (sig_is_mfm<SIG>() ? 1 : 0); }
+
+template <int SIG, int FAM>
+__device__ __forceinline__ void chain_epilogue_dispatch(int sig, const ConvParams& p, const v16f& acc, const v16f* accp, float* tile, int lane, int l31,
                                                         int lhi, int co_base, int m, float* __restrict__ osel, const float* __restrict__ bsel)
 {
     if constexpr (SIG < kNumChainSigs) {
-        if constexpr (sig_is_mfm<SIG>() == MFM) {
-            if (sig == SIG) { chain_epilogue<SIG>(p, acc, tile, lane, l31, lhi, co_base, m, osel, bsel); return; }
+        if constexpr (sig_family<SIG>() == FAM) {
+            if (sig == SIG) { chain_epilogue<SIG>(p, acc, accp, tile, lane, l31, lhi, co_base, m, osel, bsel); return; }
         }
-        chain_epilogue_dispatch<SIG + 1, MFM>(sig, p, acc, tile, lane, l31, lhi, co_base, m, osel, bsel);
+        chain_epilogue_dispatch<SIG + 1, FAM>(sig, p, acc, accp, tile, lane, l31, lhi, co_base, m, osel, bsel);
     }
 }
 
@@ -165,7 +186,7 @@ __device__ __forceinline__ void chain_epilogue_dispatch(int sig, const ConvParam
 template <int CHAIN, bool LDS_OK, bool ROW = false>
 __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[1][1], float* smem, const int tid, const int lane, const int wave,
                                                const int co0, const int m0, const int half, const int tail_t, const int part, const int nparts,
-                                               float* __restrict__ osel, const float* __restrict__ bsel)
+                                               float* __restrict__ osel, const float* __restrict__ bsel, v16f* accp = nullptr)
 {
     constexpr int MI = 1, NJ = 1, TCO = 64, TM = 64;         // (TCO / 2, TM / 2 below = the 32 rows / columns of a wave's quadrant in both layouts)
     const int wrow = ROW ? 0 : wave >> 1, wcol = ROW ? wave : wave & 1;
@@ -174,8 +195,12 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
         // K-part of a tail tile: park the accumulators, count arrivals; the last part to arrive sums all parts in
         // part order (deterministic) and runs the normal epilogue.  Agent-scope stores / loads: the parts ran on
         // different XCDs, whose L2s are not coherent for plain accesses.
-        constexpr int TILE_FLOATS = TCO * TM;
+        constexpr int TILE_FLOATS = TCO * TM * (CHAIN == 4 ? 2 : 1);       // a dual-accumulator launch parks both tiles
         float* __restrict__ slab = p.tail_ws + (long)(tail_t * nparts + part) * TILE_FLOATS;
+        if constexpr (CHAIN == 4) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __hip_atomic_store(slab + (16 + r) * NT + tid, (*accp)[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -209,17 +234,31 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     acc[i][j][r] = sum;
                 }
+        if constexpr (CHAIN == 4) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sum = 0.f;
+                for (int q = 0; q < nparts; ++q)
+                    sum += __hip_atomic_load(base + (long)q * TILE_FLOATS + (16 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (*accp)[r] = sum;
+            }
+        }
     }
 
     // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
     // Optional fused micro-program (half 0 only): forward = bias -> [store raw] -> BatchNorm -> [+residual] -> ReLU;
     // backward = [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP -> next GEMM's input.
-    if constexpr (CHAIN == 1 || CHAIN == 3) {
+    if constexpr (CHAIN == 4) {
+        // lean probe forward: the wave holds the W and the relu(W) tile of its quadrant; the compiled chain stores what the sweep needs of them
+        if constexpr (MI == 1 && NJ == 1)
+            chain_epilogue_dispatch<0, 2>(p.chain_sig, p, acc[0][0], accp, smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
+                                          m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
+    } else if constexpr (CHAIN == 1 || CHAIN == 3) {
         // compiled chain epilogue (CHAIN 3: the MaxFeatureMap signatures); launch_one only selects this instantiation when the float4 layout conditions hold.  The chain
         // belongs to half 0; the relu(W) half of a dual launch (positive activations) leaves as plain dense rows.
         if constexpr (MI == 1 && NJ == 1) {
             if (half == 0)
-                chain_epilogue_dispatch<0, CHAIN == 3>(p.chain_sig, p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
+                chain_epilogue_dispatch<0, CHAIN == 3 ? 1 : 0>(p.chain_sig, p, acc[0][0], nullptr, smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
                                            m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
             else
                 dense_epilogue(p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32, m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
@@ -343,8 +382,14 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
 #pragma unroll
                             for (int e8 = 0; e8 < 4; ++e8) {
                                 if (!ok[e8]) continue;
-                                const float a = fmaxf(s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]], 0.f);
+                                const float a_raw = s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]];
+                                const float a = fmaxf(a_raw, 0.f);
                                 const float zh = fmaxf(g[e8], 0.f);
+                                if (st.action >= HOOK_Q) {      // lean hooks (common.h)
+                                    g[e8] = st.action == HOOK_Q ? zh * fabsf(a_raw)
+                                                                : (st.action == HOOK_GATE ? (a_raw > 0.f ? zh : 0.f) : ((__float_as_uint(a_raw) >> 31) ? 0.f : zh));
+                                    continue;
+                                }
                                 const float pp = a * zh;
                                 if (st.pstore) st.pstore[gi[e8]] = pp;
                                 if (st.action == HOOK_DIV) {
@@ -359,7 +404,7 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
                             for (int e8 = 0; e8 < 4; ++e8) {
                                 if (!ok[e8]) continue;
                                 const float t = s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]];
-                                g[e8] = t > 0.f ? g[e8] : 0.f;
+                                g[e8] = (st.action == 1 ? (__float_as_uint(t) >> 31) == 0u : t > 0.f) ? g[e8] : 0.f;
                             }
                         } else if (type == EW_SCALE_C) {
 #pragma unroll
@@ -443,14 +488,19 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
     }
 }
 
-// CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue (p.chain_sig), 2 = interpreted chain epilogue
+// CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue (p.chain_sig), 2 = interpreted chain epilogue, 3 = compiled, MaxFeatureMap family,
+// 4 = DUAL: compiled lean probe-forward epilogue over two accumulator tiles per wave -- W and relu(W), the latter multiplied from the clamped W
+// fragment (ConvParams::dualacc: one pack, one staged input tile, two MFMAs per fragment pair)
 // Waves per SIMD the MaxFeatureMap epilogue family (CHAIN 3) is compiled for: 6 (<= 80 registers) spills 8 registers of the epilogue into
 // 36 bytes of scratch, 5 (<= 96) does not.  Round 4 measured both on Light-CNN (profiles/r4/experiments/mfm_launch_bounds.txt).
 #ifndef XFR_MFM_WAVES
 #define XFR_MFM_WAVES 6
 #endif
+#ifndef XFR_DUAL_WAVES
+#define XFR_DUAL_WAVES 4          /* 5 (<= 96 registers) spills 4-8 registers of the lean epilogue */
+#endif
 template <int TCO, int TM, int BK, int NST, int MODE, bool RELU, int CHAIN>
-__global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVES)) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
+__global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : (CHAIN == 4 ? XFR_DUAL_WAVES : XFR_MFM_WAVES))) void conv_gemm_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     // TCO == 32 (with TM == 128): the four waves side by side along m -- a block tile for layers whose channel count leaves a 64-row tile half
     // empty (Light-CNN: 96 = 3 x 32).  Same K-steps, same accumulator order: same bits as the 64 x 64 tile.
@@ -684,13 +734,15 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
         }
     };
 
-    v16f acc[MI][NJ];
+    constexpr bool DUAL = CHAIN == 4;
+    static_assert(!DUAL || (MI == 1 && NJ == 1 && !RELU), "the dual-accumulator loop is written for one quadrant per wave");
+    v16f acc[MI][NJ], accp[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accp[i][j][r] = 0.f; }
 
     // prologue: fill NST-1 stages
 #pragma unroll
@@ -731,7 +783,10 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
+                {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+                    if constexpr (DUAL) accp[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(a_cur[i], 0.f), b_cur[j], accp[i][j], 0, 0, 0);
+                }
             if ((kk / 2) % (BK / 2 / NP) == 0) issue(kt + NST - 1, st_fill, (kk / 2) / (BK / 2 / NP));
             if (kk + 2 < BK) {
 #pragma unroll
@@ -746,7 +801,7 @@ __global__ __launch_bounds__(NT, CHAIN == 0 ? 1 : (CHAIN == 1 ? 7 : XFR_MFM_WAVE
     stamp(p, wave, lane, 2);
     stamp(p, wave, lane, 3);
 
-    block_epilogue<CHAIN, true, ROW>(p, acc, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel);      // the launcher allocates at least the four 32 x 36 tiles
+    block_epilogue<CHAIN, true, ROW>(p, acc, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel, DUAL ? &accp[0][0] : nullptr);      // the launcher allocates at least the four 32 x 36 tiles
     stamp(p, wave, lane, 4);
 }
 
@@ -813,8 +868,14 @@ __device__ __forceinline__ void ks_exchange(float* smem, const v16f (&acc)[2][2]
     }
 }
 
+// CHAIN == 4 (DUAL, ConvParams::dualacc): every wave carries EIGHT accumulators -- its 64x64 tile of W and of relu(W), the second multiplied from
+// the clamped W fragments: eight independent MFMAs per fragment pair on one private ring.  Two exchanges (W, then relu(W)) leave quadrant q of both
+// tiles with wave q, which is what the lean epilogue expects.
+#ifndef XFR_KS_DUAL_WAVES
+#define XFR_KS_DUAL_WAVES 2
+#endif
 template <int BK, int NST, int MODE, bool RELU, int CHAIN>
-__global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
+__global__ __launch_bounds__(NT, CHAIN == 4 ? XFR_KS_DUAL_WAVES : 5) void conv_gemm_ks_kernel(const ConvParams p, const int n_co_tiles, const int n_m_tiles)
 {
     static_assert(MODE == MODE_VEC || MODE == MODE_TAP, "the split-K kernel covers the 1x1 float4 path and the tap-major gather");
     constexpr int TCO = 64, TM = 64;
@@ -948,13 +1009,15 @@ __global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p,
         }
     };
 
-    v16f acc[2][2];
+    constexpr bool DUAL = CHAIN == 4;
+    static_assert(!DUAL || !RELU, "a dual-accumulator launch reads an input that is already clamped");
+    v16f acc[2][2], accp[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accp[i][j][r] = 0.f; }
 
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(w_lo + s, s, -1);
@@ -993,13 +1056,21 @@ __global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p,
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+            if constexpr (DUAL) {
+                const float ap0 = fmaxf(a_cur[0], 0.f), ap1 = fmaxf(a_cur[1], 0.f);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accp[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap0, b_cur[j], accp[0][j], 0, 0, 0);
+                    accp[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap1, b_cur[j], accp[1][j], 0, 0, 0);
+                }
+            }
             if (kk + 2 < BK) issue(kt + NST - 1, st_fill, kk / 2);
             // order within the k-pair: the next pair's fragment reads first (they then have four MFMAs to land), the global
             // loads between the MFMAs (issued while the pipe is busy)
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, (L + NP - 1) / NP, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, DUAL ? 7 : 3, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i) { a_cur[i] = a_nxt[i]; b_cur[i] = b_nxt[i]; }
         }
@@ -1016,9 +1087,17 @@ __global__ __launch_bounds__(NT, 5) void conv_gemm_ks_kernel(const ConvParams p,
     else if (wave == 1) ks_exchange<1, WAVE_LDS>(smem, acc, lane, accq[0][0]);
     else if (wave == 2) ks_exchange<2, WAVE_LDS>(smem, acc, lane, accq[0][0]);
     else ks_exchange<3, WAVE_LDS>(smem, acc, lane, accq[0][0]);
+    v16f accpq;
+    if constexpr (DUAL) {
+        __syncthreads();          // every wave has gathered its W quadrant: the rings may be overwritten with the relu(W) tiles
+        if (wave == 0) ks_exchange<0, WAVE_LDS>(smem, accp, lane, accpq);
+        else if (wave == 1) ks_exchange<1, WAVE_LDS>(smem, accp, lane, accpq);
+        else if (wave == 2) ks_exchange<2, WAVE_LDS>(smem, accp, lane, accpq);
+        else ks_exchange<3, WAVE_LDS>(smem, accp, lane, accpq);
+    }
     // the epilogues start with a workgroup barrier before they reuse the LDS (tail parts: before the arrival flag)
     stamp(p, wave, lane, 3);
-    block_epilogue<CHAIN, true>(p, accq, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel);
+    block_epilogue<CHAIN, true>(p, accq, smem, tid, lane, wave, co0, m0, half, tail_t, part, nparts, osel, bsel, DUAL ? &accpq : nullptr);
     stamp(p, wave, lane, 4);
 }
 
@@ -1081,6 +1160,7 @@ int plan_chain(ConvParams& q)
     q.chain_sig = (q.accumulate || !vec_ok || q.chain_interpret) ? -1 : conv_gemm_chain_sig(wide);
     if (q.chain_sig >= 0) { q.chain = wide; q.chain_ld = wide_ld; }
     if (q.nhalves == 2 && q.chain_sig < 0) return 1;      // a dual launch can only carry a compiled chain: the caller un-fuses
+    if ((q.dualacc != 0) != (q.chain_sig >= 0 && chain_sig_is_dual(q.chain_sig))) return 3;   // lean steps <=> two accumulator tiles
     for (int i = 0; i < q.chain.n && q.chain_sig < 0; ++i)
         if (q.chain.s[i].type == EW_MAXPAIR || q.chain.s[i].type == EW_MAXHALF_OUT) return 2;   // steps the interpreter does not have
     return 0;
@@ -1097,7 +1177,7 @@ bool launch_one(const ConvParams& p, hipStream_t s)
     q.tail_q = 0;
     q.tail_s = 1;
     {
-        const int S = pick_tail_split(p, n_co * n_m, (p.K + BK - 1) / BK, (size_t)TCO * TM * sizeof(float));
+        const int S = pick_tail_split(p, n_co * n_m, (p.K + BK - 1) / BK, (size_t)TCO * TM * sizeof(float) * (p.dualacc ? 2 : 1));
         if (S > 1) {
             const int r = (n_co * n_m) % num_cus();
             q.tail_q = n_co * n_m - r;
@@ -1105,10 +1185,18 @@ bool launch_one(const ConvParams& p, hipStream_t s)
             grid = q.tail_q + r * S;
         }
     }
+    if (p.dualacc && (q.chain.n == 0 || p.nhalves != 1 || p.relu_in)) return false;
     if constexpr ((TCO == 64 && TM == 64) || (TCO == 32 && TM == 128)) {
         if (q.chain.n > 0) {      // fused micro-program (no relu_in)
             if (plan_chain(q)) return false;
             g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
+            if constexpr (TCO == 64 && MODE != MODE_TAP4 && MODE != MODE_GEN) {
+                if (q.dualacc) {
+                    hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 4>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+                    return true;
+                }
+            }
+            if (q.dualacc) return false;
             if (q.chain_sig >= 0 && chain_sig_is_mfm(q.chain_sig))
                 hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 3>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
             else if (q.chain_sig >= 0)
@@ -1139,7 +1227,7 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
     q.tail_q = 0;
     q.tail_s = 1;
     {
-        const int S = pick_tail_split(p, n_co * n_m, (p.K + BK - 1) / BK, (size_t)TCO * TM * sizeof(float));
+        const int S = pick_tail_split(p, n_co * n_m, (p.K + BK - 1) / BK, (size_t)TCO * TM * sizeof(float) * (p.dualacc ? 2 : 1));
         if (S > 1) {
             const int r = (n_co * n_m) % num_cus();
             q.tail_q = n_co * n_m - r;
@@ -1147,9 +1235,14 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
             grid = q.tail_q + r * S;
         }
     }
+    if (p.dualacc && (q.chain.n == 0 || p.nhalves != 1 || p.relu_in)) return false;
     if (q.chain.n > 0) {
         if (plan_chain(q)) return false;
         g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
+        if (q.dualacc) {
+            hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 4>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
+            return true;
+        }
         if (q.chain_sig >= 0 && chain_sig_is_mfm(q.chain_sig))
             hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 3>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
         else if (q.chain_sig >= 0)
@@ -1186,8 +1279,12 @@ bool launch_cfg_ks(const ConvParams& p, hipStream_t s)
 }
 
 template <int TCO, int TM, int BK, int NST>
-bool launch_cfg(const ConvParams& p, hipStream_t s)
+bool launch_cfg(const ConvParams& p_in, hipStream_t s)
 {
+    ConvParams p = p_in;
+    // a strided 1x1 convolution on the dual-accumulator loop: the tap-major gather with its single tap (for one tap the two K orders are the same
+    // rows of the same pack) instead of the generic table gather, which has no dual-accumulator instantiation
+    if (p.dualacc && p.kh == 1 && p.kw == 1 && p.tap_major == 0 && (p.Cin % 16) == 0) p.tap_major = 1;
     const bool vec = (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && (p.M % 4) == 0 && p.OH == p.H && p.OW == p.W);
     if (vec) return launch_one<TCO, TM, BK, NST, MODE_VEC>(p, s);
     if (p.tap_major == 2) return launch_one<64, 64, 16, 4, MODE_TAP4>(p, s);
@@ -1224,6 +1321,7 @@ const char* conv_gemm_refusal(int why)
     switch (why) {
         case 0: return "the convolution launch was refused without a reason";
         case 1: return "a dual (W / relu(W)) convolution launch carries a fused chain without a compiled epilogue";
+        case 3: return "lean probe-forward steps and the dual-accumulator launch (ConvParams::dualacc) only exist together, behind a compiled epilogue";
         case 2: return "a fused chain with a MaxFeatureMap step (pair maximum / fan-out VJP) has no compiled epilogue and the interpreter does not run those steps";
         default: return "unknown convolution launch refusal";
     }
@@ -1235,8 +1333,12 @@ void conv_gemm_chain_launch_counts(long* compiled, long* interpreted)
     if (interpreted) *interpreted = g_chain_launches[1].load();
 }
 
-int conv_gemm_pick_cfg(const ConvParams& p)
+int conv_gemm_pick_cfg(const ConvParams& p_in)
 {
+    // A dual-accumulator launch does the work of the dual (W / relu(W)) launch of the same layer with half the workgroups, twice as long each: it
+    // takes the kernel that launch takes (the rules below see the dual launch's tile count), never the 32 x 128 tile.
+    ConvParams p = p_in;
+    if (p.dualacc) { p.nhalves = 2; p.dualacc = 0; const int c = conv_gemm_pick_cfg(p); return c == 12 ? 4 : c; }
     // Measured on MI355X over the ResNet-101 / ResNet-50 / Light-CNN GEMM shapes (M = 1.5k..400k, K = 64..4608,
     // Cout = 64..2048): the 64x64 tile wins or ties everywhere -- these grids are small (1-12 workgroups per CU), so
     // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.
@@ -1320,7 +1422,7 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     p.span = nullptr;
     if (g_log && (int)g_log_recs.size() < g_log_cap) {
         p.span = g_log + 8 * g_log_recs.size();
-        g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
+        g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.dualacc ? 2 : p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
     }
     int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
     {

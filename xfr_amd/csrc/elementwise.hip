@@ -79,7 +79,10 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
             const EwStep& st = ch.s[i];
             if (st.type == EW_HOOK) {
                 float p = 0.f;
-                if (ok) {
+                if (ok && st.action >= HOOK_Q) {       // lean hooks (common.h): never observed, no priors
+                    const float t = st.p0[aidx], z = fmaxf(g, 0.f);
+                    g = st.action == HOOK_Q ? z * fabsf(t) : (st.action == HOOK_GATE ? (t > 0.f ? z : 0.f) : ((__float_as_uint(t) >> 31) ? 0.f : z));
+                } else if (ok) {
                     const float a = fmaxf(st.p0[aidx], 0.f);
                     const float zh = fmaxf(g, 0.f);
                     p = a * zh;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(NT) void ew_chain_kernel(const float* __restrict__ 
                     }
                 }
             } else if (ok) {
-                if (st.type == EW_MASK) g = (st.p0[aidx] > 0.f) ? g : 0.f;
+                if (st.type == EW_MASK) g = (st.action == 1 ? (__float_as_uint(st.p0[aidx]) >> 31) == 0u : st.p0[aidx] > 0.f) ? g : 0.f;
                 else if (st.type == EW_SCALE_C) g = g * st.p0[c];
                 else if (st.type == EW_SCALE) g = g * st.f;
                 else if (st.type == EW_STORE) {

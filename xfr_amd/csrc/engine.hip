@@ -121,6 +121,12 @@ struct BwdPlan {
     std::vector<int> firing_ops;     // hooked module call (op index) per firing: Whitebox.P_layername is str(module) of these (whitebox.py:393)
     int n_firings = 0;
     int fan_ok = -1;                 // does every fan-out epilogue of fused_gemm have a compiled signature (-1: not checked yet; fanout_compiled)
+    // The lean schedule (xfr_engine_set_lean): the probe forward stores quotients instead of hook operands, the sweep reads them.
+    int lean_state = -1;             // -1 not prepared, 0 does not apply to this plan, 1 ready (lean_prepare)
+    std::vector<char> lean_q;        // per tensor: 1 = its T storage holds a / (x + eps) of the BatchNorm hook on it (sign bit: lean_final <= 0),
+                                     // 2 = its Pv storage holds a / (x + eps) of the in-place ReLU hook behind it
+    std::vector<int> lean_final;     // per tensor with lean_q 1: root of the tensor whose positivity the sign bit records (-1: none)
+    std::vector<BwdStep> fused_gemm_lean;
 };
 
 }  // namespace
@@ -211,6 +217,14 @@ struct xfr_engine {
                                        // hook chain that follows (EW_AVGUP_IN; xfr_engine_set_epilogue_fusion bit 6 clear)
     bool fuse_branch = true;           // projection-shortcut blocks: the main path's hook chain as a side branch of the Add-output GEMM's epilogue (EW_STORE actions
                                        // 1 / 2; xfr_engine_set_epilogue_fusion bit 7 clear)
+    bool lean = true;                  // xfr_engine_set_lean: plain sweeps (no trace / prior / capture / stored firing, batch % 4 == 0) take the lean schedule
+    const BwdPlan* lean_cur = nullptr; // the plan whose lean tables the running probe forward / sweep follow (null: literal)
+    bool lean_decide = false;          // lean_prepare's dry run of the probe forward: decide per convolution, record in lean_q_run / lean_final_run
+    bool dry_run = false;              // ... which launches nothing
+    bool lean_missing_sig = false;     // ... and found a lean epilogue without a compiled signature
+    long lean_launches = 0;            // dual-accumulator launches so far (xfr_engine_lean_stats)
+    std::vector<char> lean_q_run;
+    std::vector<int> lean_final_run;
     bool pair_tiles = true;            // backward chain GEMMs over two streams walk their m-tiles stream-interleaved (xfr_engine_set_epilogue_fusion bit 5 clear)
     bool fuse_pools = true;            // Light-CNN's maxpool + avgpool pair: one forward kernel (xfr_engine_set_epilogue_fusion bit 0 switches it with the rest)
     bool fuse_gemm_epilogue = true;    // hook chains that follow a backward GEMM run in its (vector) epilogue
@@ -670,7 +684,7 @@ bool operand_ready(xfr_engine* e, int t, int k, int B, bool with_pos, hipStream_
     }
     for (int i = n - 1; i >= 0; --i) {
         const int kp = chain[i];
-        if (!e->planning_only) {
+        if (!e->planning_only && !e->dry_run) {
             if (!e->fwd_done[kp] && fwd_op(e, kp, B, with_pos, s) != XFR_OK) return false;
             if (with_pos && e->tens[e->ops[kp].d.out].need_pv && !e->pos_done[kp] && pos_op(e, kp, B, s) != XFR_OK) return false;
         }
@@ -739,7 +753,11 @@ bool can_fuse_probe(xfr_engine* e, int k, int* k1_out)
     return true;
 }
 
-void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t s)
+// Lean variant (`dual` launches of a lean call, xfr_engine_set_lean): the W and relu(W) accumulators meet in ONE workgroup (ConvParams::dualacc), so
+// the BatchNorm hook's a / (x + eps) is formed there and stored in place of the raw output (EW_LEAN_Q ... EW_LEAN_STORE); where the in-place ReLU
+// behind the BatchNorm [+ functional add] has a dividing hook too, its quotient replaces the positive BatchNorm output (EW_LEAN_XR).  Two
+// tensors written per convolution instead of three or four, and the sweep reads one or two instead of three or four.
+void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t s, bool dual = false, bool lean_try = true)
 {
     int k1 = -1;
     if (!can_fuse_probe(e, k, &k1)) return;
@@ -749,7 +767,16 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t 
     EwChain& ch = p.chain;
     ch.n = 0;
     auto push = [&](int type) -> EwStep& { EwStep& q = ch.s[ch.n++]; memset(&q, 0, sizeof(q)); q.type = type; q.prior_sb = -1; return q; };
-    push(EW_STORE).pstore = e->T(d.out);
+    // lean: every hook on the raw output is the BatchNorm's (its a and x are the two accumulators), and the call asked for it
+    // (tuning: XFR_LEAN_MAX_K -- only convolutions with at most that many K rows go lean)
+    const int lean_max_k = [] { const char* v = getenv("XFR_LEAN_MAX_K"); return v ? atoi(v) : 512; }();
+    bool lean = lean_try && dual && d.out != 1 && e->ops[k].Kf <= lean_max_k && e->tens[d.out].need_pv &&
+                (e->lean_decide || (e->lean_cur && e->lean_cur->lean_q[d.out] == 1));
+    if (lean)
+        for (const Hook& h : e->tens[d.out].hooks)
+            if (h.op != k1 || h.a_tensor != d.out) lean = false;
+    if (lean) push(EW_LEAN_Q);
+    else push(EW_STORE).pstore = e->T(d.out);
     int fork_at = -1;
     if (e->tens[bn_out].need_pv) {
         fork_at = ch.n;
@@ -795,6 +822,25 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t 
         }
     }
     if (!fused_add && bn.fuse_relu) push(EW_RELU);
+    int lean_tq = -1;
+    if (lean) {
+        const bool ends_relu = fused_add ? e->ops[k2].fuse_relu : bn.fuse_relu;
+        // the ReLU hook's quotient: the fork's value has one reader, the x of the hook of the in-place ReLU that ends this chain
+        if (fork_at >= 0 && ends_relu) {
+            const int cand = pos_add >= 0 ? e->ops[pos_add].d.out : (fused_add ? -1 : bn_out);
+            if (cand >= 0 && e->tens[cand].consumers.size() == 1 && e->ops[e->tens[cand].consumers[0]].d.kind == XFR_OP_RELU &&
+                e->ops[e->tens[cand].consumers[0]].relu_fused_away && e->root(e->ops[e->tens[cand].consumers[0]].d.out) == e->root(final_t))
+                lean_tq = cand;
+        }
+        if (lean_tq >= 0) { ch.s[fork_at].type = EW_LEAN_XR; ch.s[fork_at].pstore = nullptr; }
+        { EwStep& q = push(EW_LEAN_STORE); q.action = 0; q.pstore = e->T(d.out); }
+        if (lean_tq >= 0) { EwStep& q = push(EW_LEAN_STORE); q.action = 1; q.pstore = e->Pv(lean_tq); }
+        if (e->lean_decide) {
+            e->lean_q_run[d.out] = 1;
+            e->lean_final_run[d.out] = ends_relu ? e->root(final_t) : -1;
+            if (lean_tq >= 0) e->lean_q_run[lean_tq] = 2;
+        }
+    }
     // a dual launch can only carry a chain through the compiled float4 epilogue (conv_gemm.hip): rows that are a multiple of 4
     // long and a signature that is in the table; otherwise the BatchNorm keeps its own kernel
     {
@@ -805,6 +851,12 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t 
         if (!e->planning_only && ((((long)B * t.HW()) & 3) != 0 || conv_gemm_chain_sig(probe) < 0)) {
             ch.n = 0;
             e->pos_done[k1] = 0;
+            if (pos_add >= 0) e->pos_done[pos_add] = 0;
+            if (lean) {     // no compiled lean epilogue: the plan as a whole stays literal (lean_prepare), this launch too
+                e->lean_missing_sig = true;
+                if (e->lean_decide) { e->lean_q_run[d.out] = 0; e->lean_final_run[d.out] = -1; if (lean_tq >= 0) e->lean_q_run[lean_tq] = 0; }
+                fuse_probe_forward(e, k, B, p, s, dual, false);
+            }
             return;
         }
     }
@@ -948,14 +1000,25 @@ xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s)
             // Light-CNN's first layer (one input channel, 5x5, MaxFeatureMap): a direct convolution instead of a 25-deep GEMM
             if (o.pair && e->fuse_fwd_only && e->direct_stem && !dual && !p.relu_in && a.C == 1 && d.kh == 5 && d.kw == 5 && d.stride == 1 && d.pad == 2 &&
                 !o.tap_fwd && !o.tap4_fwd && o.pair_max <= e->fwd_last_op && !e->interpret_chains && stem5_mfm_ok(e->T(d.in0), B, a.H, a.W)) {
-                launch_stem5_mfm(e->T(d.in0), p.w, o.ldw, p.bias, want_pos ? e->T(d.out) : nullptr, e->T(e->ops[o.pair_max].d.out), o.pair, B, a.H, a.W, s);
+                if (!e->dry_run) launch_stem5_mfm(e->T(d.in0), p.w, o.ldw, p.bias, want_pos ? e->T(d.out) : nullptr, e->T(e->ops[o.pair_max].d.out), o.pair, B, a.H, a.W, s);
                 e->fwd_done[o.pair_split] = 1;
                 e->fwd_done[o.pair_max] = 1;
                 return XFR_OK;
             }
             if (o.pair && e->fuse_fwd_only && !dual && !p.relu_in && fuse_mfm_forward(e, k, B, want_pos, p)) { }
             else if (!want_pos && e->fuse_fwd_only && !p.relu_in) fuse_forward_only(e, k, B, p, s);
-            else if (want_pos && e->fuse_probe_fwd && !p.relu_in) fuse_probe_forward(e, k, B, p, s);
+            else if (want_pos && e->fuse_probe_fwd && !p.relu_in) fuse_probe_forward(e, k, B, p, s, dual);
+            if (p.chain.n > 0 && p.chain.s[0].type == EW_LEAN_Q) {
+                // one workgroup per tile accumulates W and relu(W) (the latter from the clamped W fragment): no second pack, no second output
+                p.nhalves = 1;
+                p.dualacc = 1;
+                if (!e->dry_run) e->lean_launches++;
+                p.w_pos = nullptr;
+                p.out1 = nullptr;
+            } else if (e->lean_cur && !e->lean_decide && e->lean_cur->lean_q[d.out] == 1) {
+                return fail(XFR_STATE_ERROR, "lean schedule: convolution %d was planned with a lean epilogue and ran without one", k);
+            }
+            if (e->dry_run) return XFR_OK;
             return run_conv(e, p, s);
         }
         case XFR_OP_BATCHNORM:
@@ -1748,6 +1811,120 @@ xfr_status get_plan(xfr_engine* e, int seed_tensor, BwdPlan** out, bool plain = 
     return XFR_OK;
 }
 
+// ---- the lean schedule ------------------------------------------------------------------------------------------------------------
+// Every hook of a plain sweep (nothing observed: no trace, prior, capture or stored firing) needs less than its literal operands:
+//   * a hook whose x IS its a (every Conv / Linear / pool / Concat / Add hook): a * relu(g) / (a + eps) is relu(g) where a > 0
+//     and 0 where a = 0 -- one bit per element.  Where the tensor is the in-place ReLU output behind a lean BatchNorm, that bit is the sign bit of
+//     the BatchNorm hook's stored quotient (HOOK_GATE_SIGN), otherwise the tensor itself is compared with 0 (HOOK_GATE);
+//   * the BatchNorm hook (a = relu(W x + b), x = relu(relu(W) x + b)) and, in the modes that divide there, the in-place ReLU hook behind it: the
+//     probe forward stored a / (x + eps) (fuse_probe_forward), the hook is relu(g) * q (HOOK_Q);
+//   * ReLU masks and RELU-action hooks that the steps in front of them already imply are dropped.
+// lean_prepare decides per plan (dry run of the probe forward, then a rewrite of plan.fused_gemm); the literal schedules stay what every
+// observing call runs.
+void lean_rewrite_chain(xfr_engine* e, const BwdPlan& plan, std::vector<BwdStep::Sym>& chain)
+{
+    typedef BwdStep::Sym Sym;
+    std::vector<Sym> out;
+    // ReLU-output roots whose positivity some lean BatchNorm quotient read by THIS chain carries in its sign bit
+    auto sign_source = [&](int root) -> int {
+        for (const Sym& y : chain)
+            if (y.type == EW_HOOK && y.action == HOOK_DIV && !y.tap && y.x_t == y.t0 && y.t0 >= 0 && plan.lean_q[y.t0] == 1 && plan.lean_final[y.t0] == root) return y.t0;
+        return -1;
+    };
+    bool nonneg = false;           // g >= 0 is known here
+    int gated = -1;                // root r: g == 0 wherever T(r) <= 0 is known here
+    // a lean hook clamps g itself: a plain clamp right in front of it is dropped
+    auto drop_clamp = [&]() {
+        if (!out.empty() && (out.back().type == EW_RELU || (out.back().type == EW_HOOK && out.back().action == HOOK_RELU && !out.back().tap))) out.pop_back();
+    };
+    for (const Sym& y : chain) {
+        Sym z = y;
+        switch (y.type) {
+            case EW_HOOK: {
+                if (y.tap) { out.push_back(z); nonneg = false; gated = -1; break; }       // P[-2]: p is stored, literal
+                if (y.action == HOOK_DIV && y.x_t >= 0 && plan.lean_q[y.x_t] == 1 && y.x_t == y.t0) {
+                    z.action = HOOK_Q; z.x_t = -1;                                        // the quotient sits in T(t0)
+                    drop_clamp(); out.push_back(z); nonneg = true;
+                } else if (y.action == HOOK_DIV && y.x_t >= 0 && plan.lean_q[y.x_t] == 2 && e->root(y.x_t) == e->root(y.t0)) {
+                    z.action = HOOK_Q; z.t0 = y.x_t; z.x_t = y.x_t;                       // the quotient sits in Pv(x_t); zero exactly where the ReLU output is
+                    drop_clamp(); out.push_back(z); nonneg = true; gated = e->root(y.t0);
+                } else if (y.action == HOOK_DIV && y.x_t < 0) {
+                    const int r = e->root(y.t0);
+                    if (gated == r) { if (!nonneg) { z.type = EW_RELU; z.t0 = -1; out.push_back(z); nonneg = true; } break; }
+                    const int c = sign_source(r);
+                    if (c >= 0) { z.action = HOOK_GATE_SIGN; z.t0 = c; } else z.action = HOOK_GATE;
+                    drop_clamp(); out.push_back(z); nonneg = true; gated = r;
+                } else if (y.action == HOOK_RELU) {
+                    if (!nonneg) { out.push_back(z); nonneg = true; }
+                } else if (y.action == HOOK_PASS) {
+                    // nothing observed, nothing returned: no step
+                } else {
+                    out.push_back(z); nonneg = (y.action == HOOK_DIV); gated = -1;        // a literal dividing hook (x from another tensor): p / (x + eps) >= 0
+                }
+                break;
+            }
+            case EW_MASK: {
+                const int r = e->root(y.t0);
+                if (gated == r) break;
+                const int c = sign_source(r);
+                if (c >= 0) { z.action = 1; z.t0 = c; }
+                out.push_back(z); gated = r;
+                break;
+            }
+            case EW_RELU: if (!nonneg) { out.push_back(z); nonneg = true; } break;
+            case EW_SCALE_C: out.push_back(z); break;                                     // relu(gamma) * invstd >= 0: signs and zeros stay
+            case EW_SCALE: out.push_back(z); if (!(y.f > 0.f)) { nonneg = false; gated = -1; } break;
+            case EW_STORE: out.push_back(z); if (y.action == 2) { nonneg = false; gated = -1; } break;      // the restored value is the branch point's
+            default: out.push_back(z); nonneg = false; gated = -1; break;                 // ADDP, chain heads, fan-outs: anything may follow
+        }
+    }
+    chain.swap(out);
+}
+
+xfr_status fwd_op(xfr_engine* e, int k, int B, bool want_pos, hipStream_t s);
+void lean_prepare(xfr_engine* e, BwdPlan& plan, int B)
+{
+    if (plan.lean_state >= 0) return;
+    plan.lean_state = 0;
+    if (plan.plain || plan.fused_gemm.empty() || !e->fuse_probe_fwd || !e->fuse_gemm_epilogue || e->interpret_chains) return;
+    const int nt = (int)e->tens.size();
+    const int last_op = e->tens[plan.seed_tensor].producer;
+    // dry run of the probe forward: the same decisions the real one takes, nothing launched
+    e->lean_q_run.assign(nt, 0);
+    e->lean_final_run.assign(nt, -1);
+    e->lean_decide = true;
+    e->dry_run = true;
+    e->lean_missing_sig = false;
+    e->fwd_done.assign(e->ops.size(), 0);
+    e->pos_done.assign(e->ops.size(), 0);
+    e->fwd_last_op = last_op;
+    for (int k = 0; k <= last_op; ++k) {
+        const int kind = e->ops[k].d.kind;
+        if (e->fwd_done[k] || (kind != XFR_OP_CONV && kind != XFR_OP_LINEAR)) continue;
+        if (fwd_op(e, k, B, true, nullptr) != XFR_OK) e->lean_missing_sig = true;
+    }
+    e->lean_decide = false;
+    e->dry_run = false;
+    bool any = false;
+    for (int t = 0; t < nt; ++t) any = any || e->lean_q_run[t] == 1;
+    if (!any || e->lean_missing_sig) return;
+    plan.lean_q = e->lean_q_run;
+    plan.lean_final = e->lean_final_run;
+    plan.fused_gemm_lean = plan.fused_gemm;
+    for (BwdStep& b : plan.fused_gemm_lean)
+        if (!b.chain.empty()) lean_rewrite_chain(e, plan, b.chain);
+    plan.lean_state = 1;
+}
+
+// may this call take the lean schedule?  (B % 4: every lean epilogue is a float4 epilogue)
+bool lean_applies(xfr_engine* e, BwdPlan& plan, int B)
+{
+    if (!e->lean || (B & 3) != 0 || e->trace_on || e->rc_priors || e->rc_caps || e->store_slot >= 0 || e->hold_forward || plan.plain) return false;
+    if (!e->fuse_probe_fwd || !e->fuse_gemm_epilogue || e->interpret_chains) return false;
+    lean_prepare(e, plan, B);
+    return plan.lean_state == 1;
+}
+
 int prior_action_for(int mode, int kind)
 {   // what the hook returns for a sample whose p was overridden by a prior (whitebox.py:396-428 with p_prior set)
     switch (mode) {
@@ -1770,6 +1947,10 @@ void resolve_chain(xfr_engine* e, const std::vector<BwdStep::Sym>& syms, EwChain
         q.prior_sb = -1;
         switch (sy.type) {
             case EW_HOOK:
+                if (sy.action >= HOOK_Q) {        // lean hooks (lean_rewrite_chain): one source, nothing observed
+                    q.p0 = (sy.action == HOOK_Q && sy.x_t >= 0) ? e->Pv(sy.x_t) : e->T(sy.t0);
+                    break;
+                }
                 q.p0 = e->T(sy.t0);
                 q.p1 = sy.x_t >= 0 ? e->Pv(sy.x_t) : nullptr;
                 if (sy.tap) q.pstore = e->ws + e->tap_off;
@@ -1898,7 +2079,9 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
     int run_max = -1;
     const bool use_gemm_fusion = use_fused && e->fuse_gemm_epilogue && !special && !plan.fused_gemm.empty();
     const bool fanout = use_gemm_fusion && !e->interpret_chains && fanout_compiled(e, plan, B, SB);
-    for (const BwdStep& st : (use_gemm_fusion ? (fanout ? plan.fused_gemm : plan.fused_gemm_nofan) : use_fused ? plan.fused : plan.steps)) {
+    const bool lean = e->lean_cur == &plan && use_gemm_fusion && plan.lean_state == 1;
+    if (e->lean_cur == &plan && !lean) return fail(XFR_STATE_ERROR, "lean schedule: the probe forward ran lean and the sweep cannot");
+    for (const BwdStep& st : (lean ? plan.fused_gemm_lean : use_gemm_fusion ? (fanout ? plan.fused_gemm : plan.fused_gemm_nofan) : use_fused ? plan.fused : plan.steps)) {
         int SBa = SB;
         if (prefix) {
             for (const auto& sy : st.chain)
@@ -2038,6 +2221,8 @@ xfr_status ebp_core(xfr_engine* e, const float* x_dev, int n, int S, int seed_te
         HIP_TRY(hipEventRecord(e->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sf, e->ev_fork, 0));
     }
+    struct LeanGuard { xfr_engine* e; ~LeanGuard() { e->lean_cur = nullptr; } } lean_guard{e};
+    e->lean_cur = lean_applies(e, *plan, n) ? plan : nullptr;
     st = forward_all(e, x_dev, n, seed_tensor, true, sf);
     if (st != XFR_OK) { e->cur_slot = 0; return st; }
     if (pipe) {
@@ -2441,6 +2626,8 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     if (st == XFR_OK) launch_scale(e->T(encode_tensor), seed_dst, (long)sd.per_n() * 2 * n, scale, 0, sa);
     e->t_bank = nullptr;
     if (st != XFR_OK) return st;
+    struct LeanGuard { xfr_engine* e; ~LeanGuard() { e->lean_cur = nullptr; } } lean_guard{e};
+    e->lean_cur = lean_applies(e, *plan, n) ? plan : nullptr;
     st = forward_all(e, probes_dev, n, encode_tensor, true, sb);
     if (st != XFR_OK) return st;
     if (fork) {
@@ -2488,6 +2675,7 @@ xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)
     e->hoist_shortcut = (enable & 256) == 0;      // bit 8 (tests, A/B): the down-sampling blocks' shortcut in program order, their residual add as its own launch
     e->direct_stem = (enable & 16) == 0;          // bit 4 (tests): the first layer of Light-CNN through the GEMM like every other convolution
     e->held_x = nullptr;
+    for (auto& p : e->plans) p.lean_state = -1;   // the lean tables follow the probe forward's fusion decisions
     return XFR_OK;
 }
 
@@ -2503,6 +2691,21 @@ xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     e->tail_balance = enable != 0;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_set_lean(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->lean = enable != 0;
+    e->held_x = nullptr;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_lean_stats(xfr_engine* e, int64_t* dual_launches)
+{
+    if (!e || !dual_launches) return fail(XFR_INVALID_ARG, "null argument");
+    *dual_launches = e->lean_launches;
     return XFR_OK;
 }
 
@@ -3194,6 +3397,47 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
             }
         }
         out += "\n";
+    }
+    // the lean schedule of the same plan (xfr_engine_set_lean): probe-forward epilogues over two accumulator tiles, sweep chains on stored quotients
+    lean_prepare(e, *plan, batch);
+    if (plan->lean_state == 1) {
+        e->lean_cur = plan;
+        e->fwd_done.assign(e->ops.size(), 0);
+        e->pos_done.assign(e->ops.size(), 0);
+        int n_lean = 0;
+        for (int k = 0; k <= last_op; ++k) {
+            const xfr_op_desc& d = e->ops[k].d;
+            if (d.kind != XFR_OP_CONV && d.kind != XFR_OP_LINEAR) continue;
+            ConvParams p;
+            conv_geometry(e, k, batch, p);
+            p.out0 = e->T(d.out);
+            const bool dual = e->tens[d.out].need_pv && e->tens[d.in0].nonneg;
+            if (e->ops[k].pair || !dual) continue;
+            fuse_probe_forward(e, k, batch, p, nullptr, dual);
+            if (p.chain.n == 0 || p.chain.s[0].type != EW_LEAN_Q) continue;
+            EwLoads ld;
+            ew_plan_loads(p.chain, p.out0, ld, EW_FWD_SLOTS_WIDE);
+            snprintf(line, sizeof(line), "lean-probe CONV op %d [%d x %d x %d] K %d", k, e->tens[d.out].C, e->tens[d.out].H, e->tens[d.out].W, e->ops[k].K);
+            out += line;
+            emit_sig(p.chain);
+            out += "\n";
+            ++n_lean;
+        }
+        e->lean_cur = nullptr;
+        for (const BwdStep& b : plan->fused_gemm_lean) {
+            if (b.chain.empty()) continue;
+            EwChain ch;
+            EwLoads ld;
+            resolve_chain(e, b.chain, ch, nullptr, 2 * batch);
+            ew_plan_loads(ch, e->G(b.dst_t), ld, b.kind == ST_CONV_BWD ? EW_FWD_SLOTS_WIDE : EW_FWD_SLOTS_BASE);
+            snprintf(line, sizeof(line), "lean-bwd %s src %d dst %d", kn[b.kind], b.src_t, b.dst_t);
+            out += line;
+            if (b.kind == ST_CONV_BWD) emit_sig(ch);
+            else { snprintf(line, sizeof(line), " steps %d", ch.n); out += line; }
+            out += "\n";
+        }
+        snprintf(line, sizeof(line), "lean convolutions %d\n", n_lean);
+        out += line;
     }
     if (needed) *needed = out.size() + 1;
     if (buf && capacity > 0) {

@@ -74,6 +74,15 @@ __device__ __forceinline__ int ew_steps(int i0, float (&g)[4], long idx, long ai
                 continue;
             }
             const float4 av = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[aidx];
+            if (st.action >= HOOK_Q) {      // lean hooks (common.h): a stored quotient / a gate instead of the literal operands; never observed
+                const float t[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float z = fmaxf(g[q], 0.f);
+                    g[q] = st.action == HOOK_Q ? z * fabsf(t[q]) : (st.action == HOOK_GATE ? (t[q] > 0.f ? z : 0.f) : ((__float_as_uint(t[q]) >> 31) ? 0.f : z));
+                }
+                continue;
+            }
             const float a[4] = {fmaxf(av.x, 0.f), fmaxf(av.y, 0.f), fmaxf(av.z, 0.f), fmaxf(av.w, 0.f)};
             float p[4], zh[4];
 #pragma unroll
@@ -132,8 +141,13 @@ __device__ __forceinline__ int ew_steps(int i0, float (&g)[4], long idx, long ai
             }
         } else if (st.type == EW_MASK) {
             const float4 tv = s0 >= 0 ? pick_slot(v0, v1, v2, v3, s0) : reinterpret_cast<const float4*>(st.p0)[aidx];
-            g[0] = tv.x > 0.f ? g[0] : 0.f; g[1] = tv.y > 0.f ? g[1] : 0.f;
-            g[2] = tv.z > 0.f ? g[2] : 0.f; g[3] = tv.w > 0.f ? g[3] : 0.f;
+            if (st.action == 1) {       // the mask is the sign bit of a stored quotient
+                g[0] = (__float_as_uint(tv.x) >> 31) ? 0.f : g[0]; g[1] = (__float_as_uint(tv.y) >> 31) ? 0.f : g[1];
+                g[2] = (__float_as_uint(tv.z) >> 31) ? 0.f : g[2]; g[3] = (__float_as_uint(tv.w) >> 31) ? 0.f : g[3];
+            } else {
+                g[0] = tv.x > 0.f ? g[0] : 0.f; g[1] = tv.y > 0.f ? g[1] : 0.f;
+                g[2] = tv.z > 0.f ? g[2] : 0.f; g[3] = tv.w > 0.f ? g[3] : 0.f;
+            }
         } else if (st.type == EW_SCALE_C) {
             const float sc = st.p0[c];
 #pragma unroll

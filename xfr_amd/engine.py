@@ -215,12 +215,26 @@ class Engine(object):
         _lib.check(self.lib.xfr_engine_set_forward_split(self._h, int(bool(on))))
         self.options['forward_split'] = bool(on)
 
+    def set_lean(self, on):
+        """The lean schedule of un-observed sweeps (default on): stored hook quotients / one-bit gates instead of the literal hook operands;
+        off = the literal expressions of whitebox.py:388-428 everywhere (include/xfr_amd.h)."""
+        _lib.check(self.lib.xfr_engine_set_lean(self._h, int(bool(on))))
+        self.options['lean'] = bool(on)
+
+    def lean_launches(self):
+        """Convolution launches of this engine that took the lean (dual-accumulator) form so far."""
+        n = ctypes.c_int64(0)
+        _lib.check(self.lib.xfr_engine_lean_stats(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def apply_options(self, options):
         """Re-apply switches recorded by another Engine handle (WhiteboxNetwork.engine rebuilds engines that are too small)."""
         if 'tail_balance' in options:
             self.set_tail_balance(options['tail_balance'])
         if 'forward_split' in options:
             self.set_forward_split(options['forward_split'])
+        if 'lean' in options:
+            self.set_lean(options['lean'])
         if 'epilogue_fusion' in options:
             self.set_epilogue_fusion(options['epilogue_fusion'])
         if options.get('pipeline'):
