@@ -31,16 +31,21 @@ sys.path.insert(0, ROOT)
 
 F_FWD = {'resnet101': 14.419e9, 'resnet50_128': 7.712e9, 'lightcnn': 7.275e9}   # 2*MAC over conv+linear
 PEAK_F32_MFMA = 157.3e12         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
-ROW0_COS = 0.999                 # sample 0 against the map the reference computes for the same triplet (tests/golden/golden_bench.npz)
+ROW0_COS = 0.99999               # sample 0 against the map the reference computes for the same unit of work (tests/golden/golden_bench.npz, golden_synth.npz): the parity tests' cosine bar
 
 
 def fixture_cosine(sal0, key):
     """Cosine between the engine's map for sample 0 of rank 0's batch and the committed reference map of that triplet."""
     import numpy as np
-    f = os.path.join(ROOT, 'tests', 'golden', 'golden_bench.npz')
-    if not os.path.exists(f):
+    want = None
+    for name in ('golden_bench.npz', 'golden_synth.npz'):
+        f = os.path.join(ROOT, 'tests', 'golden', name)
+        if os.path.exists(f):
+            z = np.load(f)
+            if key + '/map' in z.files:
+                want = z[key + '/map'].astype(np.float64).ravel()
+    if want is None:
         return None
-    want = np.load(f)[key + '/map'].astype(np.float64).ravel()
     got = sal0.detach().cpu().numpy().astype(np.float64).ravel()
     return float(got @ want / max(np.linalg.norm(got) * np.linalg.norm(want), 1e-300))
 
@@ -215,7 +220,7 @@ class Workload(object):
     pass
 
 
-def make_workload(args, dev, rank, cpu_only=False):
+def make_workload(args, dev, rank, cpu_only=False, comm=None):
     """cpu_only: no engine, no device -- just the inputs and the CPU port's unit of work (the whole-host baseline's workers)."""
     import torch
     from xfr_amd import shard, synth
@@ -313,7 +318,7 @@ def make_workload(args, dev, rank, cpu_only=False):
         W.flop_per_unit = 3 * F_FWD['lightcnn']
         W.metric = 'EBP saliency maps/sec, Light-CNN-29v2 128x128 (80013-way hooked classifier)'
         W.work = 'Light-CNN-29v2 excitation backprop, batch=%d synthetic images per GPU, mode %s' % (B, W.mode)
-        W.fixture = None
+        W.fixture = 'bench/lcnn' if (B == 128 and W.mode == 'affineonly') else None     # image 0 through the real reference (tests/golden/make_golden_synth.py)
         W.pmc_tag = '_lcnn' if (B == 128 and W.mode == 'affineonly') else None
         W.cpu_what = 'Light-CNN-29v2 ebp call(s) over the 80013-way classifier'
 
@@ -339,16 +344,21 @@ def make_workload(args, dev, rank, cpu_only=False):
     if cpu_only:
         return W
     W.eng = eng
-    shard.load_and_broadcast(eng, make_sd, src=0)      # rank 0 packs, everybody receives the arena over RCCL
+    if comm is not None:
+        comm.load_weights(eng, make_sd, src=0)         # rank 0 packs, everybody receives the arena over RCCL (or, if that fails anywhere, packs locally)
+    else:
+        shard.load_and_broadcast(eng, make_sd, src=0)
     eng.set_mode(W.mode)
     return W
 
 
-def rank_report(eng, rank, local, world, binding=None):
+def rank_report(eng, comm, binding=None):
     """What proves N ranks and one broadcast in the driver's log: per rank the device, the checksum of the packed parameter arena it
-    ended up with (equal on all ranks) and the RCCL version; gathered on rank 0 for the JSON line, echoed on stderr by every rank."""
+    ended up with (equal on all ranks), how it got there (broadcast | local_pack_fallback) and the RCCL version; gathered on every rank
+    (through the store: no collective needed), echoed on stderr by every rank."""
     import torch
     import torch.distributed as dist
+    rank, local, world = comm.rank, comm.local, comm.world
     arena = eng.weight_arena()
     n8 = (arena.numel() // 8) * 8
     crc = int(arena[:n8].view(torch.int64).sum().item()) & 0xffffffffffff
@@ -359,15 +369,13 @@ def rank_report(eng, rank, local, world, binding=None):
     from xfr_amd import shard
     me = {'rank': rank, 'device': local, 'visible_device': shard.normalize_gpus([local])[0], 'device_name': torch.cuda.get_device_name(local),
           'arena_bytes': int(arena.numel()), 'arena_checksum48': '%012x' % crc, 'rccl': rccl,
-          'backend': dist.get_backend() if dist.is_initialized() else None}
+          'backend': dist.get_backend() if dist.is_initialized() else None, 'weights_via': comm.weights_via}
+    if comm.init_error:
+        me['collective_init_error'] = comm.init_error
     if binding is not None:
         me['cpu_binding'] = binding
     sys.stderr.write('bench.py rank %d/%d: %s\n' % (rank, world, json.dumps(me)))
-    allr = [me]
-    if world > 1:
-        allr = [None] * world
-        dist.all_gather_object(allr, me)
-    return allr
+    return comm.gather_objects(me, 'rank_report')
 
 
 def _pipe_level(level):
@@ -379,7 +387,7 @@ def _pipe_level(level):
     return level
 
 
-def timed_loop(W, steps, warmup, barrier, world, dev):
+def timed_loop(W, steps, warmup, barrier, world, dev, comm=None):
     """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; the checks on the last step's maps."""
     import torch
     import torch.distributed as dist
@@ -395,9 +403,7 @@ def timed_loop(W, steps, warmup, barrier, world, dev):
     dt = dt_rank = time.perf_counter() - t0
     cs = chain_stats()                        # process-wide counters right after the timed loop: nothing but product-path steps so far
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = comm.max_float(dt, dev)
     # every map of the last step: finite, non-negative, unit sum
     ok = bool(torch.isfinite(sal).all().item()) and float(sal.min().item()) >= 0.0 and \
         float((sal.sum(dim=(1, 2)) - 1.0).abs().max().item()) < 1e-3
@@ -414,6 +420,51 @@ def executed_flops(W, reps=2):
         ms, n, fl = eng.get_profile(); s_ms += ms; s_n += n; s_fl += fl
     eng.set_profile(False)
     return s_ms / reps, s_n / reps, s_fl / reps
+
+
+def roofline_object(W, step, ms_step, dev, reps=2, launch_log_out=None):
+    """The `roofline` object of one workload (the headline and every secondary get the same one): (1) the one-stream schedule with HIP events
+    around every GEMM launch -- what rocprofv3 --kernel-trace reproduces (profiles/rNN/kernel_stats_serial*.csv) -- and the executed GEMM FLOPs;
+    (2) the TIMED schedule from the launch log the kernels write themselves (streams overlapped as timed); (3) the shader clock held meanwhile;
+    (4) HBM bytes per launch from the committed PMC passes.  launch_log_out: keep the raw launch log of (2) as that CSV file
+    (profiles/frac_from_launch_log.py recomputes `frac` from it).  Returns (object, timeline analysis, FLOPs per step used)."""
+    from xfr_amd import tuning
+    B = W.B
+    peak = PEAK_F32_MFMA / 1e12
+    s_ms, s_n, s_fl = executed_flops(W, reps)
+    # the numerator of every fraction: never more than what the launches executed (ResNets: the stem's backward-data GEMM is --
+    # correctly -- never run, so executed < 6 F_fwd; Light-CNN 'affineonly' needs no relu(W) forward)
+    alg_step = min(W.flop_per_unit * B, s_fl)
+    for _ in range(3):
+        step()
+    csv = tuning.record_launch_log(step, 6, dev, csv_path=launch_log_out)
+    tl = tuning.analyse_launch_log(csv, 6, alg_step)
+    if launch_log_out is None:
+        os.remove(csv)
+    clk = tuning.shader_clock(step, 6, dev)
+    achieved = tl['achieved_over_union_TFLOPs']
+    roof = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+            'kernel': 'conv_gemm kernels (all GEMM launches of one step), timed multi-stream schedule',
+            'how': 'min(algorithmic, executed) FLOPs / union of the GEMM launches\' busy intervals (in-kernel s_memrealtime stamps, xfr_amd/tuning.py; '
+                   'profiles/frac_from_launch_log.py recomputes it from the committed launch log)',
+            'launches_per_step': tl['launches_per_step'], 'gemm_busy_ms_per_step': tl['gemm_union_busy_ms_per_step'],
+            'avg_launch_ms': tl['avg_launch_ms_in_union'], 'step_ms_while_logging': tl['ms_per_step'],
+            'concurrent_launches_ms_per_step': tl['concurrent_launches_ms_per_step'],
+            # the same FLOPs over the TIMED step (every non-GEMM kernel included)
+            'frac_timed': alg_step / (ms_step * 1e-3) / PEAK_F32_MFMA, 'achieved_timed': alg_step / (ms_step * 1e-3) / 1e12,
+            # one stream (the schedule rocprofv3 --kernel-trace sees): sum of the launch durations, HIP events
+            'frac_serial': alg_step / (s_ms * 1e-3) / PEAK_F32_MFMA, 'achieved_serial': alg_step / (s_ms * 1e-3) / 1e12,
+            'gemm_ms_per_step_serial': s_ms, 'avg_launch_ms_serial': s_ms / max(s_n, 1),
+            'executed_flop_per_step': s_fl, 'algorithmic_flop_per_step': W.flop_per_unit * B, 'flop_per_step_used': alg_step,
+            'mfma_util_source': 'profiles/rNN/pmc_mfma%s.txt (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024), serial schedule)' % (W.pmc_tag or '')}
+    if clk:
+        # 157.3 TFLOP/s is the peak at the nominal 2.4 GHz; what the chip can do at the clock it actually held
+        roof['shader_clock_GHz'] = clk
+        roof['peak_sustained'] = 64 * 1024 * clk['p50'] * 1e9 / 1e12
+        roof['frac_of_sustained'] = achieved / roof['peak_sustained']
+    if W.pmc_tag is not None:
+        roof.update(pmc_traffic(ROOT, W.pmc_tag))
+    return roof, tl, alg_step
 
 
 def run_secondary(model, dev, steps, warmup, chain_before):
@@ -435,14 +486,93 @@ def run_secondary(model, dev, steps, warmup, chain_before):
         ok = ok and row0 is not None and row0 >= ROW0_COS
     interp = r['chain'][1] - chain_before[1]
     ok = ok and interp == 0
-    _, n_launch, fl = executed_flops(W, 1)
-    alg_step = min(W.flop_per_unit * W.B, fl)
+    roof, _, alg_step = roofline_object(W, W.step, ms_step, dev, reps=1)
+    n_launch = roof['launches_per_step']
     out = {'model': model, 'metric': W.metric, 'workload': W.work, 'value': W.B * steps / r['dt'], 'unit': 'maps/s', 'ms_per_step': ms_step,
            'steps': steps, 'warmup': warmup, 'frac_timed': alg_step / (ms_step * 1e-3) / PEAK_F32_MFMA,
            'algorithmic_flop_per_step': alg_step, 'gemm_launches_per_step': n_launch,
-           'outputs_ok': ok, 'row0_cosine_vs_reference': row0, 'interpreted_chain_launches': interp}
+           'outputs_ok': ok, 'row0_cosine_vs_reference': row0, 'interpreted_chain_launches': interp, 'roofline': roof}
     W.eng.close()
     del W
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=65359):
+    """BASELINE.json configs[4] on ONE GPU: the job mix of the reference's inpainting-game generator on ResNet-101 (eval/
+    generate_inpaintinggame_wb_saliency_maps_multigpu.py:121-231; python/xfr/inpainting_game/generate_whitebox_saliency.py:79-214) -- per job meanEBP
+    over the 65359-way hooked classifier, contrastive and truncated-contrastive triplet EBP from `mates` averaged mate / non-mate encodings, and
+    weighted-subtree EBP top-32 ('norelu', whitebox.py:647-737) -- `group` jobs per batch through xfr_amd.inpainting_game.run_jobs_batched (what
+    tools/inpainting_game_workload.py --group 8 runs; that tool shards the jobs over ranks).  jobs/s over `jobs` jobs, ms per method (a second
+    pass, device synchronised between methods), and for the weighted subtree the GEMM FLOPs its launches executed per probe (in-kernel launch
+    log) over its wall time against the fp32 MFMA peak."""
+    import numpy as np
+    import torch
+    from xfr_amd import inpainting_game as IG, synth, tuning
+    from xfr_amd.engine import Engine
+    from xfr_amd.models import resnet, whitebox as WB
+    bb = resnet.ResNet([3, 4, 23, 3], num_classes=num_classes)
+    bb.to(dev)
+    wbn = WB.WhiteboxSTResnet(bb)
+    wb = WB.Whitebox(wbn, ebp_subtree_mode='norelu')            # eval/create_wbnet.py:51-52 default for resnetv4/v6
+    wbn._program = bb.build_program()
+    wbn._engine = Engine(wbn._program, max(32, 16 * group), dev)
+    wbn._engine_key = (str(bb.device), id(bb))
+    wbn._engine.load_weights(synth.synth_state_dict(bb, seed=0))
+    wbn._engine.loaded_version = bb.version
+    k = mates
+    pool = [synth.synth_smooth_images(2 * k + 1, (3, 224, 224), seed=10000 + j, mean=resnet.MEAN_RGB).to(dev) for j in range(8)]
+
+    def batch(g0):
+        return [(list(pool[j % 8][1:1 + k]), list(pool[j % 8][1 + k:]), pool[j % 8][0]) for j in range(g0, min(jobs, g0 + group))]
+
+    def run_all(timings=None, methods=None):
+        ok = True
+        for g0 in range(0, jobs, group):
+            res = IG.run_jobs_batched(wb, batch(g0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, timings=timings, methods=methods)
+            for maps in res.values():
+                for m in maps:
+                    m = np.asarray(m)
+                    ok = ok and m.shape == (112, 112) and bool(np.isfinite(m).all()) and abs(float(m.sum()) - 1.0) < 1e-3
+        return ok
+    run_all()                                                   # warm: plans, scratch, lazy code objects
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ok = run_all()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    phase = {}
+    run_all(timings=phase)
+    # the weighted subtree alone: wall time and executed GEMM FLOPs of one group
+    ws = ('weighted-subtree',)
+    IG.run_jobs_batched(wb, batch(0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, methods=ws)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        IG.run_jobs_batched(wb, batch(0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, methods=ws)
+    torch.cuda.synchronize()
+    t_ws = (time.perf_counter() - t1) / 3
+    csv = tuning.record_launch_log(lambda: IG.run_jobs_batched(wb, batch(0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, methods=ws), 0, dev,
+                                   launches_per_step_cap=40000)
+    fl, n_launch, busy = 0.0, 0, 0
+    for ln in list(open(csv))[1:]:
+        r = ln.strip().split(',')
+        if int(r[9]) > 0 and int(r[10]) > int(r[9]):
+            fl += 2.0 * int(r[4]) * int(r[5]) * int(r[2]) * int(r[3])
+            busy += int(r[10]) - int(r[9])
+            n_launch += 1
+    os.remove(csv)
+    fl, n_launch, busy_ms = fl / 2, n_launch / 2, busy * 1e-5 / 2           # the log holds two calls
+    out = {'model': 'resnet101 inpainting-game job mix', 'metric': 'inpainting-game whitebox saliency jobs/sec, ResNet-101 (4 methods per job), 1 GPU',
+           'workload': 'BASELINE.json configs[4] shape on one GPU: %d synthetic jobs, %d mates + %d non-mates per job, %d-way hooked classifier for meanEBP, '
+                       'weighted subtree top-%d, mode norelu, %d jobs per batch' % (jobs, k, k, num_classes, topk, group),
+           'value': jobs / dt, 'unit': 'jobs/s', 'seconds': dt, 'jobs': jobs, 'outputs_ok': bool(ok),
+           'ms_per_job_by_method': {kk: round(1e3 * v / jobs, 3) for kk, v in phase.items()},
+           'weighted_subtree': {'ms_per_probe': 1e3 * t_ws / group, 'probes_per_call': group, 'gemm_launches_per_call': n_launch,
+                                'executed_gemm_gflop_per_probe': fl / group / 1e9, 'sum_of_gemm_launch_ms_per_call': busy_ms,
+                                'frac_of_peak_over_wall': fl / t_ws / PEAK_F32_MFMA, 'frac_of_peak_while_a_gemm_runs': fl / (busy_ms * 1e-3) / PEAK_F32_MFMA},
+           'reference': '~36 h for 541 ResNet-101 jobs on one Titan X (README.md:166) = ~240 s per job'}
+    wbn._engine.close()
     torch.cuda.empty_cache()
     return out
 
@@ -466,10 +596,12 @@ def main():
     ap.add_argument('--no-pipeline', action='store_true', help='do not overlap step i+1 forwards with step i backward')
     ap.add_argument('--profile-csv', default=None, help='with --serial: append one record per GEMM launch to this file (profiles/layer_table.py)')
     ap.add_argument('--launch-log-csv', default=None, help='with --serial: after the timed loop, record 3 more steps with the in-kernel launch log on (one stream) and write it here: per-launch durations from the kernels\' own s_memrealtime stamps (profiles/layer_table.py reads it) -- HIP events misread the first GEMM after an idle queue')
+    ap.add_argument('--launch-log-out', default=None, help='keep the raw in-kernel launch log of the TIMED schedule (the one roofline.frac is computed from) as this CSV file; profiles/frac_from_launch_log.py recomputes frac from it')
     ap.add_argument('--timeline-json', default=None, help='write the launch-log analysis of the timed schedule (roofline.timeline) to this file')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 10 s sustained loop after the timed region')
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
+    ap.add_argument('--inpainting-game', action='store_true', help='only the BASELINE.json configs[4] job mix (one GPU): print its object and exit')
     ap.add_argument('--no-lean', action='store_true', help='xfr_engine_set_lean(0): the literal hook operands in every sweep (A/B against the default lean schedule)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
     ap.add_argument('--bind', action='store_true', help='pin every rank to its own CPU set (the GPU\'s NUMA node split among the ranks that share it): 8 launch threads of ~500 launches per step each do not migrate or share cores')
@@ -484,34 +616,63 @@ def main():
     import torch.distributed as dist
     from xfr_amd import shard, tuning
 
-    rank, world, local = shard.init_process_group()
+    # rendezvous with a bounded wait; a collective backend that does not come up is a reported condition, not a crash (shard.Comm)
+    comm = shard.Comm()
+    rank, world, local = comm.rank, comm.world, comm.local
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)\n' % (args.gpus, world))
         if args.gpus != 1 or world != 1:
             sys.exit(2)
+    try:
+        run(args, comm)
+    except SystemExit:
+        raise
+    except BaseException:          # noqa: BLE001 -- every rank's exception text reaches rank 0's output, whatever it was
+        import traceback
+        text = traceback.format_exc()
+        comm.report_error(text)
+        sys.stderr.write('bench.py rank %d/%d FAILED:\n%s' % (rank, world, text))
+        if rank == 0:
+            errs = comm.collect_errors(2.0)
+            errs[0] = text
+            print(json.dumps({'error': text.strip().splitlines()[-1], 'n_gpus': world, 'rank_errors': {str(k): v for k, v in sorted(errs.items())}}))
+        sys.stdout.flush()
+        os._exit(4)                # no clean shutdown of a process group whose peers may be gone
+
+
+def run(args, comm):
+    import torch
+    from xfr_amd import shard, tuning
+    rank, world, local = comm.rank, comm.world, comm.local
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    if os.environ.get('XFR_TEST_RAISE_RANK') == str(rank):
+        raise RuntimeError('XFR_TEST_RAISE_RANK: simulated failure of rank %d' % rank)
+    if args.inpainting_game:
+        if rank == 0:
+            print(json.dumps(run_inpainting_game(dev)))
+        comm.close()
+        return
     binding = shard.bind_rank_cpus(local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))) if args.bind else None
-    W = make_workload(args, dev, rank)
+    W = make_workload(args, dev, rank, comm=comm)
     eng, B = W.eng, W.B
-    ranks = rank_report(eng, rank, local, world, binding)
-    if rank == 0 and len({r['arena_checksum48'] for r in ranks}) != 1:
+    ranks = rank_report(eng, comm, binding)
+    if rank == 0 and len({r.get('arena_checksum48') for r in ranks}) != 1:
         sys.stderr.write('bench.py: the ranks hold different parameter arenas after the broadcast\n')
         sys.exit(3)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
 
     if args.dry_run:
         sal = W.step(False)
         barrier()
         if rank == 0:
-            print(json.dumps({'dry_run': True, 'n_gpus': world, 'ranks': ranks, 'outputs_finite': bool(torch.isfinite(sal).all().item())}))
-        if world > 1:
-            dist.destroy_process_group()
+            print(json.dumps({'dry_run': True, 'n_gpus': world, 'weights_via': comm.weights_via, 'collective_backend_ok': comm.collective_ok or world == 1,
+                              'ranks': ranks, 'outputs_finite': bool(torch.isfinite(sal).all().item())}))
+        comm.close()
         return
 
     if args.fusion is not None:
@@ -525,13 +686,13 @@ def main():
         eng.set_profile(True)
         if args.profile_csv:
             eng.profile_csv(args.profile_csv)
-    r = timed_loop(W, args.steps, args.warmup, barrier, world, dev)
+    r = timed_loop(W, args.steps, args.warmup, barrier, world, dev, comm)
     dt, t_enqueue, sal, ok = r['dt'], r['t_enqueue'], r['sal'], r['ok']
     chain_timed = r['chain']              # (compiled, interpreted, signatures) through the end of the timed loop
     # the product path runs compiled epilogues only: an interpreted launch inside the timed region fails the line
     ok = ok and (chain_timed[1] == 0 or args.fusion is not None)
     # per-rank rates: a straggler shows up as `spread` (the whole-job value below uses the MAX-over-ranks time)
-    rank_rates = shard.gather_rank_rates(B * args.steps / r['dt_rank'], dev)
+    rank_rates = shard.gather_rank_rates(B * args.steps / r['dt_rank'], dev, comm)
     row0 = None
     if rank == 0 and W.fixture:
         row0 = fixture_cosine(sal[0], W.fixture)
@@ -568,42 +729,8 @@ def main():
     unfused_leg = None
     ms_step = 1e3 * dt / args.steps
     if not args.no_profile and rank == 0:
-        peak = PEAK_F32_MFMA / 1e12
-        # (1) one stream, HIP events around every GEMM launch on the launch stream: what rocprofv3 --kernel-trace can reproduce
-        #     (profiles/rNN/kernel_stats_serial*.csv); the executed FLOPs tell how much of the algorithmic count the mode needs
         reps = 2
-        s_ms, s_n, s_fl = executed_flops(W, reps)
-        # the numerator of every fraction: never more than what the launches executed (ResNets: the stem's backward-data GEMM is --
-        # correctly -- never run, so executed < 6 F_fwd; Light-CNN 'affineonly' needs no relu(W) forward)
-        alg_step = min(W.flop_per_unit * B, s_fl)
-        # (2) the timed schedule itself: launch log written by the kernels, streams overlapped as timed
-        for _ in range(3):
-            step()
-        csv = tuning.record_launch_log(step, 6, dev)
-        tl = tuning.analyse_launch_log(csv, 6, alg_step)
-        os.remove(csv)
-        # (3) the clock the chip sustained meanwhile
-        clk = tuning.shader_clock(step, 6, dev)
-        achieved = tl['achieved_over_union_TFLOPs']
-        roof = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
-                'kernel': 'conv_gemm kernels (all GEMM launches of one step), timed three-stream schedule',
-                'how': 'min(algorithmic, executed) FLOPs / union of the GEMM launches\' busy intervals (in-kernel s_memrealtime stamps, xfr_amd/tuning.py)',
-                'launches_per_step': tl['launches_per_step'], 'gemm_busy_ms_per_step': tl['gemm_union_busy_ms_per_step'],
-                'avg_launch_ms': tl['avg_launch_ms_in_union'], 'step_ms_while_logging': tl['ms_per_step'],
-                'concurrent_launches_ms_per_step': tl['concurrent_launches_ms_per_step'],
-                # the same FLOPs over the TIMED step (every non-GEMM kernel included)
-                'frac_timed': alg_step / (ms_step * 1e-3) / PEAK_F32_MFMA, 'achieved_timed': alg_step / (ms_step * 1e-3) / 1e12,
-                # one stream (the schedule rocprofv3 --kernel-trace sees): sum of the launch durations, HIP events
-                'frac_serial': alg_step / (s_ms * 1e-3) / PEAK_F32_MFMA, 'achieved_serial': alg_step / (s_ms * 1e-3) / 1e12,
-                'gemm_ms_per_step_serial': s_ms, 'avg_launch_ms_serial': s_ms / max(s_n, 1),
-                'executed_flop_per_step': s_fl, 'algorithmic_flop_per_step': W.flop_per_unit * B, 'flop_per_step_used': alg_step}
-        if clk:
-            # 157.3 TFLOP/s is the peak at the nominal 2.4 GHz; what the chip can do at the clock it actually held
-            roof['shader_clock_GHz'] = clk
-            roof['peak_sustained'] = 64 * 1024 * clk['p50'] * 1e9 / 1e12
-            roof['frac_of_sustained'] = achieved / roof['peak_sustained']
-        if W.pmc_tag is not None:
-            roof.update(pmc_traffic(ROOT, W.pmc_tag))
+        roof, tl, alg_step = roofline_object(W, step, ms_step, dev, reps=reps, launch_log_out=args.launch_log_out)
         if args.timeline_json:
             json.dump(tl, open(args.timeline_json, 'w'), indent=1)
         # the same launches with the elementwise epilogues un-fused (convolution work only): reference figure for the MFMA
@@ -638,6 +765,10 @@ def main():
                 secondary.append(run_secondary(m, dev, args.secondary_steps, 3, chain_stats()))
             except Exception as ex:      # the headline must still be printed
                 secondary.append({'model': m, 'error': repr(ex), 'outputs_ok': False})
+        try:
+            secondary.append(run_inpainting_game(dev))
+        except Exception as ex:
+            secondary.append({'model': 'resnet101 inpainting-game job mix', 'error': repr(ex), 'outputs_ok': False})
         del chain_main
 
     if rank == 0:
@@ -653,7 +784,15 @@ def main():
             'host_enqueue_ms_per_step': 1e3 * t_enqueue / args.steps, 'host_enqueue_idle_ms': host_idle_ms,
             'rank_maps_s': rank_rates,
             'ranks': ranks,
+            # how the parameters reached the ranks: 'broadcast' (one RCCL broadcast of the packed arena), 'local_pack_fallback' (the collective
+            # backend or the broadcast failed somewhere: every rank packed from the seed; the checksums above still agree), 'local_pack' (N = 1)
+            'weights_via': comm.weights_via, 'collective_backend_ok': bool(comm.collective_ok or world == 1),
         }
+        errs = comm.collect_errors()
+        if errs:
+            line['rank_errors'] = {str(k): v for k, v in sorted(errs.items())}
+        if world > 1:
+            line['scaling_note'] = 'N > 1 has only ever run with several ranks on ONE GPU here (gloo); no multi-GPU node was available to the builder'
         if sustained is not None:
             line['sustained_maps_s'] = world * sustained['maps_s']
             line['sustained'] = sustained
@@ -667,9 +806,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = W.cpu_baseline(20.0, not args.no_whole_host)
         print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    comm.close()
 
 
 if __name__ == '__main__':

@@ -5,7 +5,7 @@
  * python/xfr/models/whitebox.py:506-527, does through its hooks).  Without a device it prints the planner's schedule
  * (xfr_plan_describe needs none) and the engine's loud refusal to run on the CPU.
  *
- *   gcc -std=c99 -Iinclude examples/c_host.c -Lxfr_amd/csrc -lxfr_amd -Wl,-rpath,$PWD/xfr_amd/csrc -lm -o c_host && ./c_host
+ *   gcc -std=c99 -Iinclude -Iexamples examples/c_host.c -Lxfr_amd/csrc -lxfr_amd -Wl,-rpath,$PWD/xfr_amd/csrc -lm -o c_host && ./c_host
  *
  * Device memory is allocated with hipMalloc / hipMemcpy resolved from libamdhip64 at run time (dlopen), so that this file
  * needs no HIP headers: the ABI takes raw device pointers, whoever allocated them.
@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "xfr_amd.h"
+#include "c_host_ref.h"      /* what the real reference computes for this very network and these images (tests/golden/make_golden_chost.py) */
 
 #define IMG 16
 #define C1 8
@@ -80,6 +81,8 @@ int main(void)
     if (xfr_forward(e, d_img, 2, encode_tensor, d_enc, NULL) != XFR_OK) { fprintf(stderr, "%s\n", xfr_last_error()); return 1; }
     hipDeviceSynchronize_();
     hipMemcpy_(enc, d_enc, sizeof(enc), 2 /* device to host */);
+    double enc_err = 0.0;
+    for (int i = 0; i < 2 * D; ++i) enc_err = fmax(enc_err, fabs((double)enc[i] - (double)c_host_ref_enc[i]));
     for (int i = 0; i < 2 * D; ++i) enc[i] *= 1.0f / 2500.0f;                      /* demo/test_whitebox.py:129 */
     hipMemcpy_(d_seed, enc, sizeof(enc), 1);                                        /* 2 streams x 1 probe x D: one_hot(k) @ W_cls */
     if (xfr_contrastive(e, d_img + 2 * IMG * IMG, 1, encode_tensor, d_seed, -1.0f, d_sal, NULL) != XFR_OK) { fprintf(stderr, "%s\n", xfr_last_error()); return 1; }
@@ -88,6 +91,15 @@ int main(void)
     double sum = 0.0; float mx = 0.f; int arg = 0;
     for (int i = 0; i < IMG * IMG; ++i) { sum += sal[i]; if (sal[i] > mx) { mx = sal[i]; arg = i; } }
     printf("-- contrastive EBP saliency map %dx%d: sum %.6f, max %.5f at (%d, %d)\n", IMG, IMG, sum, mx, arg / IMG, arg % IMG);
+    /* against the reference's own map of the same triplet: max|d| / max and cosine (the parity tests' criterion, tests/parity_utils.py) */
+    double dmax = 0.0, rmax = 0.0, dot = 0.0, na = 0.0, nb = 0.0;
+    for (int i = 0; i < IMG * IMG; ++i) {
+        const double a = sal[i], b = c_host_ref_map[i];
+        dmax = fmax(dmax, fabs(a - b)); rmax = fmax(rmax, fabs(b));
+        dot += a * b; na += a * a; nb += b * b;
+    }
+    const double rel = dmax / rmax, cosine = dot / sqrt(na * nb);
+    printf("-- against the reference: encodings max|d| %.2e, map max|d|/max %.3e, cosine %.8f\n", enc_err, rel, cosine);
     xfr_engine_destroy(e);
-    return (fabs(sum - 1.0) < 1e-3 || sum == 0.0) ? 0 : 1;
+    return (fabs(sum - 1.0) < 1e-3 && enc_err < 1e-5 && rel <= 1e-3 && cosine >= 0.99999) ? 0 : 1;
 }

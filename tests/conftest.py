@@ -19,3 +19,17 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.fail('test marked gpu but no HIP device is visible')
     return torch.device('cuda', 0)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """-m gpu sessions: the measured margin of every golden case that ran (max|d|/max, cosine, per-firing trace error) as
+    gpurun_out/parity_report.json, so the distance to each tolerance is visible (a copy is committed under profiles/rNN/)."""
+    mod = sys.modules.get('test_gpu_parity')
+    rep = getattr(mod, 'PARITY_REPORT', None) if mod else None
+    if not rep:
+        return
+    import json
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'parity_report.json'), 'w') as f:
+        json.dump({'cases': len(rep), 'schedule': 'default (lean where it applies)', 'results': dict(sorted(rep.items()))}, f, indent=1)

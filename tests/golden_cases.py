@@ -88,7 +88,28 @@ def oracle_subject(arch, sd, mode, num_classes=None):
     return Subject(ow, ow.encode, ow.set_triplet_classifier, trace)
 
 
-def engine_subject(arch, bb, mode, device='cuda:0'):
+class _Replicated(object):
+    """Whitebox proxy for the golden replay: contrastive calls run on FOUR copies of the probe and return row 0, so that the batch is a
+    multiple of four and the sweep takes the engine's lean schedule (xfr_engine_set_lean) -- the golden vectors then pin that schedule to the
+    reference too, not only the literal one a batch of one runs.  Everything else passes through."""
+
+    def __init__(self, wb):
+        object.__setattr__(self, '_wb', wb)
+
+    def __getattr__(self, name):
+        return getattr(self._wb, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._wb, name, value)
+
+    def contrastive_ebp(self, x, kp, kn):
+        return self._wb.contrastive_ebp(x.repeat(4, 1, 1, 1), kp, kn)[0]
+
+    def truncated_contrastive_ebp(self, x, kp, kn, percentile=20):
+        return self._wb.truncated_contrastive_ebp(x.repeat(4, 1, 1, 1), kp, kn, percentile)[0]
+
+
+def engine_subject(arch, bb, mode, device='cuda:0', replicate=False):
     from xfr_amd.models import whitebox as WB
     bb.to(device)
     if arch == 'resnet50_128':
@@ -104,7 +125,7 @@ def engine_subject(arch, bb, mode, device='cuda:0'):
         if not getattr(wb, 'P_layername', None):
             return None
         return (np.asarray(wb.P_trace)[:, 0], list(wb.P_layername))
-    return Subject(wb, wbn.encode, wbn.set_triplet_classifier, trace, gold_enc=True)
+    return Subject(_Replicated(wb) if replicate else wb, wbn.encode, wbn.set_triplet_classifier, trace, gold_enc=True)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -194,6 +215,17 @@ def lcnn_cases(mode, which=None):
                   (pre + 'triplet/contrastive', lambda s: s.wb.contrastive_ebp(x_probe, 0, 1)),
                   (pre + 'triplet/truncated', lambda s: s.wb.truncated_contrastive_ebp(x_probe, 0, 1, 20))]
     return _filter(cases, which)
+
+
+def synth_cases(arch, tag, mode):
+    """tests/golden/make_golden_synth.py: a smooth synthetic probe against two independent random classifier rows -- a WELL-CONDITIONED contrast."""
+    from parity_utils import emb_dim
+    x = make_images(arch, 1, seed=77, smooth=True)
+    D = emb_dim(arch)
+    pre = '%s/%s/synthetic/' % (tag, mode)
+    return [('__set__', lambda s: s.set_cls(synth.unit_rows(1, D, seed=1) / 2500, synth.unit_rows(1, D, seed=2) / 2500)),
+            (pre + 'contrastive', lambda s: s.wb.contrastive_ebp(x, 0, 1)),
+            (pre + 'truncated', lambda s: s.wb.truncated_contrastive_ebp(x, 0, 1, 20))]
 
 
 def _filter(cases, which):

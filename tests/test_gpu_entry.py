@@ -308,6 +308,47 @@ def test_bench_dry_run_and_rank_report(gpu_device):
     assert all(r['arena_bytes'] > 0 and r['rccl'] for r in j['ranks'])
 
 
+def test_bench_survives_a_failed_weight_broadcast(gpu_device):
+    """The weight broadcast fails on rank 1 (XFR_TEST_FAIL_BROADCAST): every rank packs from the seed locally, the arena checksums still agree,
+    the line says "weights_via": "local_pack_fallback" -- not rc != 0 (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:101-118: the
+    reference's workers survive a failing job too)."""
+    outs = _run_ranks(['bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '4', '--no-cpu-baseline', '--no-sustained', '--no-profile'],
+                      2, 29681, extra_env={'XFR_TEST_FAIL_BROADCAST': '1', 'XFR_DIST_TIMEOUT': '60'})
+    j = json.loads([ln for ln in outs[0].splitlines() if ln.startswith('{')][0])
+    assert j['n_gpus'] == 2 and j['outputs_ok'] is True and j['weights_via'] == 'local_pack_fallback' and j['collective_backend_ok'] is False
+    assert len({r['arena_checksum48'] for r in j['ranks']}) == 1 and all(r['weights_via'] == 'local_pack_fallback' for r in j['ranks'])
+
+
+def test_bench_surfaces_a_failing_rank(gpu_device):
+    """Rank 1 raises (XFR_TEST_RAISE_RANK): rank 0 neither hangs nor dies silently -- it prints ONE JSON line with every rank's exception text
+    and both exit with code 4."""
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29687', WORLD_SIZE='2', RANK=str(r), LOCAL_RANK=str(r), XFR_DIST_BACKEND='gloo',
+                   XFR_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0', XFR_TEST_RAISE_RANK='1', XFR_DIST_TIMEOUT='60')
+        procs.append(subprocess.Popen([sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '4', '--no-cpu-baseline',
+                                       '--no-sustained', '--no-profile'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [4, 4], [o[1][-1500:] for o in outs]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert 'simulated failure of rank 1' in j['rank_errors']['1'] and 'rank(s) [1] failed' in j['rank_errors']['0']
+
+
+@pytest.mark.parametrize('bind', [False, True])
+def test_bench_eight_ranks_on_one_gpu(gpu_device, bind):
+    """Eight ranks (the driver's 8-GPU launch shape) as eight processes on this one GPU, four triplets each: eight launch threads fit the
+    host's CPU quota with and without --bind, one line, eight equal arena checksums, one broadcast."""
+    cmd = ['bench.py', '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '4', '--no-cpu-baseline', '--no-sustained', '--no-profile']
+    outs = _run_ranks(cmd + (['--bind'] if bind else []), 8, 29691 + int(bind) * 40, extra_env={'XFR_DIST_TIMEOUT': '300'}, timeout=1500)
+    j = json.loads([ln for ln in outs[0].splitlines() if ln.startswith('{')][0])
+    assert j['n_gpus'] == 8 and j['outputs_ok'] is True and j['weights_via'] == 'broadcast' and len(j['ranks']) == 8
+    assert len({r['arena_checksum48'] for r in j['ranks']}) == 1 and len(j['rank_maps_s']['per_rank']) == 8
+    if bind:
+        assert all('cpu_binding' in r for r in j['ranks'])
+
+
 def test_rccl_entry_points_world_size_1(gpu_device):
     """xfr_comm_unique_id / xfr_comm_init / xfr_broadcast_weights / xfr_comm_destroy through librccl (one rank: the
     communicator is real, the broadcast degenerates to a self-copy); the receiving side's bookkeeping is checked on a second

@@ -8,27 +8,44 @@ import pytest
 import torch
 
 import golden_cases as GC
-from parity_utils import (MAP_RTOL_CONTRAST, assert_map_close, assert_map_close_robust, assert_trace_close, emb_dim, make_backbone,
+from parity_utils import (MAP_RTOL, MAP_RTOL_CONTRAST, assert_map_close, assert_map_close_robust, assert_trace_close, emb_dim, make_backbone,
                           make_images, map_metrics)
 from xfr_amd import synth
 
 pytestmark = pytest.mark.gpu
 
 
+PARITY_REPORT = {}          # key -> measured margins of every golden case this session (tests/conftest.py writes parity_report.json)
+
+
 def _check_factory():
     def check(key, res, trace, gold):
         want = gold[key + '/map']
         # Every golden case of every backbone is held to the STRICT criterion (measured on MI355X in round 2: all pass); only the
-        # final maps of *truncated* calls ride on the percentile mask, a discontinuous step (see parity_utils docstring)
+        # final maps of *truncated* calls ride on the percentile mask, a discontinuous step (see parity_utils docstring).
+        # Contrastive maps whose classifier rows are two face encodings (cosine 0.9998 under seeded weights) get MAP_RTOL_CONTRAST; the
+        # WELL-CONDITIONED ones (`synthetic/...`: independent random rows) are held to SURVEY.md section 8c's 1e-3.
+        well = '/synthetic/' in key
+        rel, cos = map_metrics(res, want)
+        rec = {'max_abs_diff_over_max': float(rel), 'cosine': float(cos)}
         if key.endswith('truncated'):
-            assert_map_close_robust(res, want, key, rtol=MAP_RTOL_CONTRAST)
+            rec['criterion'] = 'robust %.0e' % (MAP_RTOL if well else MAP_RTOL_CONTRAST)
+            PARITY_REPORT[key] = rec
+            assert_map_close_robust(res, want, key, rtol=MAP_RTOL if well else MAP_RTOL_CONTRAST)
         elif key.endswith('contrastive'):
-            assert_map_close(res, want, key, rtol=MAP_RTOL_CONTRAST)
+            rec['criterion'] = 'strict %.0e' % (MAP_RTOL if well else MAP_RTOL_CONTRAST)
+            PARITY_REPORT[key] = rec
+            assert_map_close(res, want, key, rtol=MAP_RTOL if well else MAP_RTOL_CONTRAST)
         else:
+            rec['criterion'] = 'strict %.0e' % MAP_RTOL
+            PARITY_REPORT[key] = rec
             assert_map_close(res, want, key)
         if trace is not None and key.endswith('/ebp'):
             sums, names = trace
             assert_trace_close(sums, names, gold[key + '/trace'], gold[key + '/names'], key)
+            g = np.asarray(gold[key + '/trace'], dtype=np.float64)
+            n = min(len(g), len(sums))
+            rec['trace_max_rel_err'] = float((np.abs(np.asarray(sums[:n], dtype=np.float64) - g[:n]) / np.maximum(np.abs(g[:n]), 1e-300)).max())
     return check
 
 
@@ -186,6 +203,49 @@ def test_lightcnn_golden(gpu_device, mode):
     bb, sd = make_backbone('lightcnn29v2', seed=0, num_classes=80013)
     assert synth.state_checksum(sd) == str(gold['lcnn/wsum'])
     GC.replay(GC.engine_subject('lightcnn29v2', bb, mode), GC.lcnn_cases(mode), gold, _check_factory())
+
+
+@pytest.mark.parametrize('arch,tag,mode,nc', [('resnet50_128', 'r50', 'norelu', None), ('resnet50_128', 'r50', 'affineonly_with_prior', None),
+                                               ('lightcnn29v2', 'lcnn', 'affineonly_with_prior', 7), ('lightcnn29v2', 'lcnn', 'all', 7)])
+def test_well_conditioned_contrastive_golden(gpu_device, arch, tag, mode, nc):
+    """Contrastive / truncated maps under two INDEPENDENT random classifier rows (tests/golden/make_golden_synth.py, the real reference): the
+    contrast does not cancel, and the engine is held to 1e-3 of the map maximum instead of the 5e-3 the
+    nearly-parallel face encodings of the demo cases need.  ResNet-101's case of the same kind is `r101/.../synthetic/contrastive`."""
+    gold = GC.golden('golden_synth')
+    bb, sd = make_backbone(arch, seed=0, num_classes=nc)
+    assert synth.state_checksum(sd) == str(gold[tag + '/wsum'])
+    GC.replay(GC.engine_subject(arch, bb, mode), GC.synth_cases(arch, tag, mode), gold, _check_factory())
+
+
+@pytest.mark.parametrize('arch,mode', [('stresnet101', 'affineonly_with_prior'), ('stresnet101', 'norelu'), ('resnet50_128', 'norelu'),
+                                       ('resnet50_128', 'affineonly_with_prior'), ('stresnet_mini', 'all')])
+def test_golden_contrastive_cases_on_the_lean_schedule(gpu_device, arch, mode):
+    """The contrastive / truncated golden cases of the BatchNorm backbones once more, as a batch of four copies of the probe: a multiple of four takes
+    the lean schedule (stored hook quotients, one-bit gates; the replay above runs batches of one, i.e. the literal operands).  Same golden
+    vectors, same tolerances; the dual-accumulator launches are counted."""
+    which = ['contrastive', 'truncated']
+    if arch == 'stresnet101':
+        gold, cases = GC.golden('golden_r101'), GC.r101_cases(mode, which=which)
+        bb, sd = make_backbone(arch, seed=0, num_classes=65359)
+    elif arch == 'resnet50_128':
+        gold = GC.golden('golden_r50')
+        bb, sd = make_backbone(arch, seed=0)
+        cases = GC.r50_cases(mode, which=which)
+    else:
+        gold, cases = GC.golden('golden_mini'), GC.mini_cases('mild', mode)
+        cases = [c for c in cases if c[0] == '__set__' or c[0].endswith('contrastive') or c[0].endswith('truncated')]
+        bb, sd = make_backbone(arch, seed=3, recipe='mild', num_classes=5)
+    subj = GC.engine_subject(arch, bb, mode, replicate=True)
+    inner = _check_factory()
+
+    def check(key, res, trace, g):
+        inner(key, res, None, g)
+        PARITY_REPORT[key + ' [lean, batch of 4]'] = PARITY_REPORT.pop(key)
+    GC.replay(subj, cases, gold, check)
+    if arch == 'resnet50_128':
+        gs = GC.golden('golden_synth')
+        GC.replay(subj, GC.synth_cases(arch, 'r50', mode), gs, check)
+    assert subj.wb._engine(4).lean_launches() > 0
 
 
 # ---- oracle on fresh seeded inputs, batched ----------------------------------------------------------------------------

@@ -88,3 +88,14 @@ def test_weighted_subtree_and_layerwise_mini():
         got = ow.layerwise_ebp(x, k_layer=k, mode='argmax', k_poschannel=0, mwp=True)
         want = g['mini/norelu/layerwise_argmax_%d' % k]
         assert np.abs(got - want).max() <= ORACLE_TOL * max(np.abs(want).max(), 1e-30)
+
+
+
+@pytest.mark.parametrize('arch,tag,mode,nc', [('resnet50_128', 'r50', 'norelu', None), ('lightcnn29v2', 'lcnn', 'all', 7)])
+def test_well_conditioned_contrastive(arch, tag, mode, nc):
+    """tests/golden/make_golden_synth.py: independent random classifier rows (the contrast does not cancel)."""
+    torch.set_num_threads(8)
+    gold = GC.golden('golden_synth')
+    bb, sd = make_backbone(arch, seed=0, num_classes=nc)
+    assert synth.state_checksum(sd) == str(gold[tag + '/wsum'])
+    GC.replay(GC.oracle_subject(arch, sd, mode), GC.synth_cases(arch, tag, mode), gold, check)

@@ -104,3 +104,82 @@ def test_cpu_binding_slices():
             os.sched_setaffinity(0, before)
         assert got0 + got1 == allowed and not set(got0) & set(got1)
         assert b0['n_cpus'] == len(got0) and b1['n_cpus'] == len(got1) and 'even split' in b0['how']
+
+
+class _FakeEngine(object):
+    """load_weights packs deterministically from the state dict; weight_arena is the packed tensor (the engine's contract, on the CPU)."""
+
+    def __init__(self):
+        self.arena = torch.zeros(1024, dtype=torch.uint8)
+        self.packed = self.marked = 0
+
+    def load_weights(self, sd):
+        self.arena.copy_(sd['w'])
+        self.packed += 1
+
+    def weight_arena(self):
+        return self.arena
+
+    def mark_weights_loaded(self):
+        self.marked += 1
+
+
+def _comm_worker(rank, world, port, q, scenario):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      XFR_DIST_BACKEND='gloo', XFR_DIST_TIMEOUT='30')
+    if scenario == 'fail_broadcast':
+        os.environ['XFR_TEST_FAIL_BROADCAST'] = '1'
+    if scenario == 'fail_init':
+        os.environ['XFR_TEST_FAIL_INIT'] = '1' if rank == 1 else '0'
+    comm = shard.Comm()
+    eng = _FakeEngine()
+    want = (torch.arange(1024) % 251).to(torch.uint8)
+    comm.load_weights(eng, lambda: {'w': want})
+    out = {'rank': rank, 'via': comm.weights_via, 'arena_ok': bool((eng.arena == want).all()), 'packed': eng.packed, 'collective_ok': comm.collective_ok}
+    out['reports'] = comm.gather_objects({'r': rank}, 'rep')
+    out['max'] = comm.max_float(10.0 + rank)
+    comm.barrier()
+    if scenario == 'raise':
+        # rank 1 fails between two barriers: rank 0's next barrier raises with rank 1's text instead of hanging
+        if rank == 1:
+            comm.report_error('Traceback ...\nRuntimeError: boom on rank 1')
+            q.put(out)
+            return
+        try:
+            comm.barrier()
+            out['barrier_raised'] = None
+        except RuntimeError as ex:
+            out['barrier_raised'] = str(ex)
+        out['errors'] = comm.collect_errors()
+        q.put(out)
+        return
+    q.put(out)
+    comm.close()
+
+
+@pytest.mark.parametrize('scenario', ['healthy', 'fail_broadcast', 'fail_init', 'raise'])
+def test_comm_survives_a_failing_collective_backend(scenario):
+    """shard.Comm (what bench.py --gpus N runs on): healthy -> ONE broadcast, rank 1 never packs; a broadcast that fails on one rank or a
+    collective backend that does not come up on one rank -> EVERY rank packs locally ('local_pack_fallback'), reports / max / barrier go through
+    the store; a rank that dies between barriers turns the others' next barrier into an error that carries its text."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 200) + {'healthy': 0, 'fail_broadcast': 211, 'fail_init': 422, 'raise': 633}[scenario]
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r['rank'])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r['arena_ok'] for r in res)
+    assert all(r['reports'] == [{'r': 0}, {'r': 1}] and r['max'] == 11.0 for r in res)
+    if scenario in ('healthy', 'raise'):
+        assert [r['via'] for r in res] == ['broadcast', 'broadcast'] and [r['packed'] for r in res] == [1, 0]
+    else:
+        assert [r['via'] for r in res] == ['local_pack_fallback'] * 2 and all(r['packed'] >= 1 for r in res)
+    if scenario == 'fail_init':
+        assert not any(r['collective_ok'] for r in res)
+    if scenario == 'raise':
+        assert 'boom on rank 1' in res[0]['barrier_raised'] and 1 in res[0]['errors'] or '1' in res[0]['errors']
+

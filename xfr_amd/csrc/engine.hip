@@ -166,6 +166,7 @@ struct xfr_engine {
     const float* held_x = nullptr;
     int held_B = 0, held_last = -1;
     hipStream_t held_stream = nullptr;
+    bool lazy_zero = false;                           // prefix sweeps: run_backward zeroes un-written gradient rows on demand (xfr_layerwise_ebp)
     std::vector<int> rc_active;                       // layerwise sweeps in ascending firing order: stream j (all its samples) is identically zero before firing rc_active[j]
     int rc_n = 1;                                     // samples per stream of the current layerwise batch
     size_t g_begin = 0, g_end = 0;                    // the gradient region of the workspace (floats)
@@ -2081,6 +2082,21 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
     const bool fanout = use_gemm_fusion && !e->interpret_chains && fanout_compiled(e, plan, B, SB);
     const bool lean = e->lean_cur == &plan && use_gemm_fusion && plan.lean_state == 1;
     if (e->lean_cur == &plan && !lean) return fail(XFR_STATE_ERROR, "lean schedule: the probe forward ran lean and the sweep cannot");
+    // On-demand zeroing of the prefix sweeps (e->lazy_zero): wr[t] = leading rows of G(t) that hold defined values.  A launch that reads rows
+    // [0, r) first gets the rows [wr[t], r) zeroed (one 2-D memset over the channels); launches that walk whole tensors or use another layout
+    // (pool / copy VJPs, scattering and compact strided GEMMs, chain heads that expand a pooled gradient) get whole tensors.
+    const bool lazy = prefix && e->lazy_zero;
+    std::vector<int> wr;
+    if (lazy) { wr.assign(e->tens.size(), 0); wr[plan.seed_tensor] = SB; }
+    auto need = [&](int t, int rows) -> xfr_status {
+        if (!lazy || t < 0 || wr[t] >= rows) return XFR_OK;
+        const Tensor& x = e->tens[t];
+        const size_t hw = (size_t)x.HW();
+        HIP_TRY(hipMemset2DAsync(e->G(t) + (size_t)wr[t] * hw, (size_t)SB * hw * sizeof(float), 0, (size_t)(rows - wr[t]) * hw * sizeof(float), (size_t)x.C, s));
+        wr[t] = rows;
+        return XFR_OK;
+    };
+    auto wrote = [&](int t, int rows) { if (lazy && t >= 0 && wr[t] < rows) wr[t] = rows; };
     for (const BwdStep& st : (lean ? plan.fused_gemm_lean : use_gemm_fusion ? (fanout ? plan.fused_gemm : plan.fused_gemm_nofan) : use_fused ? plan.fused : plan.steps)) {
         int SBa = SB;
         if (prefix) {
@@ -2088,6 +2104,27 @@ xfr_status run_backward(xfr_engine* e, BwdPlan& plan, int B, int S, hipStream_t 
                 if (sy.type == EW_HOOK && sy.slot > run_max) run_max = sy.slot;
             SBa = (int)(std::upper_bound(e->rc_active.begin(), e->rc_active.end(), run_max) - e->rc_active.begin()) * e->rc_n;
             if (SBa == 0) continue;
+        }
+        if (lazy) {
+            bool irregular = st.compact || !(st.kind == ST_EW || st.kind == ST_CONV_BWD);
+            if (st.kind == ST_CONV_BWD && e->ops[st.op].d.stride != 1) irregular = true;
+            for (const auto& sy : st.chain)
+                if (sy.type == EW_AVGUP_IN || sy.type == EW_POOL2_IN || sy.type == EW_MAXHALF_IN || sy.type == EW_MAXHALF_OUT) irregular = true;
+            const int ew_hw = st.kind == ST_EW ? e->tens[st.ew_t].HW() : 4;
+            // rows this launch covers: the float4 chain kernel and the GEMMs honour the prefix, the scalar chain kernels walk every row
+            const int rows = (irregular || st.kind == ST_ZERO || (st.kind == ST_EW && ((ew_hw & 3) != 0 || st.accumulate))) ? SB : SBa;
+            xfr_status zs = XFR_OK;
+            if (st.kind != ST_ZERO && zs == XFR_OK) zs = need(st.src_t, rows);
+            if ((st.accumulate || irregular) && zs == XFR_OK) zs = need(st.dst_t, rows);
+            for (const auto& sy : st.chain) {
+                if (zs != XFR_OK) break;
+                if (sy.type == EW_ADDP) zs = need(sy.t0, rows);
+                else if (sy.type == EW_AVGUP_IN && sy.slot >= 0) zs = need(sy.slot, SB);
+            }
+            if (zs != XFR_OK) return zs;
+            wrote(st.dst_t, rows);
+            for (const auto& sy : st.chain)
+                if (sy.type == EW_STORE && sy.action != 1) wrote(sy.t0, rows);
         }
         switch (st.kind) {
             case ST_EW: {
@@ -2953,11 +2990,19 @@ xfr_status xfr_layerwise_ebp(xfr_engine* e, const float* x_dev, int32_t n, int32
     st = forward_all(e, x_dev, n, seed_tensor, true, s);
     if (st == XFR_OK) {
         const Tensor& sd = e->tens[seed_tensor];
-        if (!e->rc_active.empty()) HIP_TRY(hipMemsetAsync(e->ws + e->g_begin, 0, (e->g_end - e->g_begin) * sizeof(float), s));
+        // Rows of a gradient tensor that no launch has written must read as zero (a sweep joins at its own firing).  The whole gradient region
+        // used to be zero-filled here -- 30 GB at 256 rows, a third of a round; now run_backward zeroes exactly the rows a launch is about to
+        // read and nobody has written (XFR_EAGER_ZERO=1: the old fill, for A/B runs; XFR_POISON_G=1, tests: NaN-fill first, so that a row the
+        // bookkeeping misses shows up in the maps)
+        static const bool eager = getenv("XFR_EAGER_ZERO") != nullptr, poison = getenv("XFR_POISON_G") != nullptr;
+        e->lazy_zero = !e->rc_active.empty() && !eager;
+        if (!e->rc_active.empty() && (eager || poison))
+            HIP_TRY(hipMemsetAsync(e->ws + e->g_begin, eager ? 0 : 0xFF, (e->g_end - e->g_begin) * sizeof(float), s));
         launch_fill(e->G(seed_tensor), (long)sd.per_n() * rows, 0.f, s);
         st = run_backward(e, *plan, n, n_sweeps, s);
     }
     e->rc_active.clear();
+    e->lazy_zero = false;
     e->rc_priors = false;
     e->rc_prior_dense = nullptr;
     e->rc_dense_slot = -1;
@@ -3396,6 +3441,19 @@ xfr_status xfr_plan_describe(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
                 for (const auto& y : b.chain) { snprintf(line, sizeof(line), " %d:%d:%d", y.type, y.action, y.t0); out += line; }
             }
         }
+        out += "\n";
+    }
+    // the schedule of the OBSERVING calls (priors / captures / stored firings: layerwise and weighted-subtree EBP): chains stay in their own launches there,
+    // but copy forwarding leaves short hook-free chains (fan-in adds, store-backs) behind some GEMMs -- listed so that they get compiled epilogues too
+    for (const BwdStep& b : plan->fused) {
+        if (b.kind != ST_CONV_BWD || b.chain.empty()) continue;
+        EwChain ch;
+        EwLoads ld;
+        resolve_chain(e, b.chain, ch, nullptr, 2 * batch);
+        ew_plan_loads(ch, e->G(b.dst_t), ld, EW_FWD_SLOTS_WIDE);
+        snprintf(line, sizeof(line), "observed-bwd CONV_BWD src %d dst %d acc %d", b.src_t, b.dst_t, b.accumulate);
+        out += line;
+        emit_sig(ch);
         out += "\n";
     }
     // the lean schedule of the same plan (xfr_engine_set_lean): probe-forward epilogues over two accumulator tiles, sweep chains on stored quotients

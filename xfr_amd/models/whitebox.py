@@ -300,7 +300,8 @@ class Whitebox(object):
         squeeze = (t.dim() == 2)
         if squeeze:
             t = t.unsqueeze(0)
-        out = eng.mwp_to_saliency(t).cpu().numpy()
+        cap = max(1, 2 * eng.max_batch)            # the engine's blur scratch holds 2 x max_batch maps
+        out = torch.cat([eng.mwp_to_saliency(t[i:i + cap]) for i in range(0, t.shape[0], cap)], dim=0).cpu().numpy()
         return out[0] if squeeze else out
 
     def _layernames(self, seed_tensor):
@@ -531,10 +532,30 @@ class Whitebox(object):
                     for k in ks:
                         if alive[row[k], b] and len(valid[b]) < topk:
                             valid[b].append((k, maps[row[k], b]))
-            valid = [[(k, P.cpu().numpy().astype(np.float32)) for k, P in vb] for vb in valid]
+            # ONE device-to-host copy for every valid map of every probe (was: one synchronising copy per map)
+            flat = [P for vb in valid for _, P in vb]
+            host = torch.stack(flat).cpu().numpy().astype(np.float32) if flat else np.zeros((0,) + tuple(eng.tensor_shape(1)[1:]), np.float32)
+            o, vh = 0, []
+            for vb in valid:
+                vh.append([(k, host[o + i]) for i, (k, _) in enumerate(vb)])
+                o += len(vb)
+            valid = vh
         finally:
             eng.hold_forward(False)
-        return [self._merge_subtrees(valid[b][::-1], [float(v) for v in w[:, b]], do_max_subtree, do_mwp_to_saliency) for b in range(n)]
+        batched = do_mwp_to_saliency and not self.convert_saliency_uint8
+        res = [self._merge_subtrees(valid[b][::-1], [float(v) for v in w[:, b]], do_max_subtree, do_mwp_to_saliency and not batched) for b in range(n)]
+        if batched and n > 0:
+            # ... and ONE saliency conversion (blur, clamp, normalise: whitebox.py:456-459) for the merged map and the top-k maps of every probe
+            # instead of topk + 1 device round trips per probe; the conversion is per map, so batching it changes nothing
+            stack = np.stack([m for r in res for m in [r[0]] + list(r[1])])
+            conv = self._mwp_to_saliency(stack)
+            o, out = 0, []
+            for r in res:
+                k = len(r[1])
+                out.append((conv[o], [conv[o + 1 + i] for i in range(k)], r[2], r[3]))
+                o += 1 + k
+            res = out
+        return res
 
     def _merge_subtrees(self, valid, P_subtree, do_max_subtree, do_mwp_to_saliency):
         """whitebox.py:706-737 on the valid subtrees (ascending weight, like the reference's [-topk:])."""

@@ -35,6 +35,187 @@ def init_process_group(backend=None, force=False):
     return rank, world, local
 
 
+class Comm(object):
+    """What bench.py --gpus N needs between its ranks, made to survive a collective backend that does not come up.
+
+    Two channels.  (1) A TCPStore of its own (MASTER_PORT + 17, rank 0 serves), created BEFORE torch.distributed is initialised and used for
+    everything that is small: per-rank reports, exception texts, agreement flags, and -- when the collective backend is unusable -- barriers and
+    the max-over-ranks time.  It does not depend on RCCL.  (2) torch.distributed (backend "nccl" = RCCL over xGMI; gloo in the tests) for the one
+    payload that matters, the packed parameter arena, and for the barriers around the timed region while it is healthy.  Rendezvous and
+    every wait are bounded (XFR_DIST_TIMEOUT seconds, default 180): a rank that never shows up becomes an error text on rank 0, not a hang.
+    The reference's pool does the same per job (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:101-118: try / except around every
+    job, failed jobs listed at the end, :193-224)."""
+
+    def __init__(self, backend=None, timeout_s=None):
+        import datetime
+        self.rank, self.world, self.local = dist_env()
+        self.timeout_s = float(timeout_s if timeout_s is not None else os.environ.get('XFR_DIST_TIMEOUT', '180'))
+        self.store = None
+        self.collective_ok = False
+        self.init_error = None
+        self.notes = []                  # non-fatal conditions worth printing (a failed broadcast that the fallback absorbed)
+        self.weights_via = 'local_pack' if self.world == 1 else None
+        self._seq = 0
+        if self.world == 1:
+            return
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        td = datetime.timedelta(seconds=self.timeout_s)
+        self.store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']) + 17, self.world, self.rank == 0, timeout=td)
+        try:
+            if os.environ.get('XFR_TEST_FAIL_INIT') == '1':
+                raise RuntimeError('XFR_TEST_FAIL_INIT: simulated rendezvous failure')
+            if backend is None:
+                backend = os.environ.get('XFR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            if backend == 'nccl':
+                torch.cuda.set_device(self.local)
+            if not dist.is_initialized():
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, timeout=td)
+            self.collective_ok = True
+        except Exception as ex:        # noqa: BLE001 -- whatever the backend throws: the ranks go on over the store
+            self.init_error = repr(ex)
+        # one decision for all ranks: a collective backend is only used if EVERY rank has it
+        self.collective_ok = self.agree(self.collective_ok)
+
+    # -- the store channel ---------------------------------------------------------------------------------------------------
+    def gather_objects(self, obj, tag, fail_fast=True):
+        """[obj of rank 0, ..., obj of rank world-1] on every rank (JSON through the store); a missing rank yields {'missing_rank': r}."""
+        import json
+        if self.world == 1:
+            return [obj]
+        import datetime
+        import time
+        self.store.set('%s/%d' % (tag, self.rank), json.dumps(obj))
+        out = []
+        for r in range(self.world):
+            key, t0, val = '%s/%d' % (tag, r), time.time(), None
+            while val is None:
+                try:
+                    self.store.wait([key], datetime.timedelta(milliseconds=100))
+                    val = json.loads(self.store.get(key).decode())
+                except Exception as ex:    # noqa: BLE001 -- not there yet: has that rank reported an exception instead?
+                    if fail_fast and r != self.rank and self.store.check(['error/%d' % r]):
+                        raise RuntimeError('rank(s) [%d] failed: %s' % (r, self.store.get('error/%d' % r).decode().strip().splitlines()[-1]))
+                    if time.time() - t0 > self.timeout_s:
+                        val = {'missing_rank': r, 'error': repr(ex)}
+            out.append(val)
+        return out
+
+    def agree(self, flag):
+        """True iff every rank passed True (a rank that never answers counts as False)."""
+        if self.world == 1:
+            return bool(flag)
+        self._seq += 1
+        votes = self.gather_objects(bool(flag), 'agree%d' % self._seq)
+        return all(v is True for v in votes)
+
+    def barrier(self):
+        """A store barrier, followed by torch.distributed's while the collective backend is healthy."""
+        if self.world == 1:
+            return
+        # the store barrier comes first either way: it can see a rank that has reported an exception (and then raises here instead of waiting
+        # for a collective that rank will never join)
+        self._seq += 1
+        key = 'barrier%d' % self._seq
+        self.store.add(key, 1)
+        import time
+        t0 = tc = time.time()
+        while int(self.store.add(key, 0)) < self.world:
+            now = time.time()
+            if now - tc > 0.05:
+                tc = now
+                errs = self.collect_errors()
+                errs.pop(self.rank, None)
+                if errs:
+                    raise RuntimeError('rank(s) %s failed: %s' % (sorted(errs), '; '.join(e.strip().splitlines()[-1] for e in errs.values())))
+            if now - t0 > self.timeout_s:
+                raise RuntimeError('barrier timed out after %.0f s' % self.timeout_s)
+            time.sleep(0.0002)
+        if self.collective_ok:
+            dist.barrier()
+
+    def max_float(self, x, device=None):
+        if self.world == 1:
+            return float(x)
+        if self.collective_ok:
+            t = torch.tensor([float(x)], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        self._seq += 1
+        return max(float(v) for v in self.gather_objects(float(x), 'max%d' % self._seq) if not isinstance(v, dict))
+
+    def report_error(self, text):
+        if self.store is not None:
+            try:
+                self.store.set('error/%d' % self.rank, text)
+            except Exception:          # noqa: BLE001
+                pass
+
+    def collect_errors(self, wait_s=0.0):
+        """{rank: exception text} of the ranks that reported one (rank 0 calls this before it prints its line)."""
+        import time
+        errs = {}
+        if self.store is None:
+            return errs
+        t0 = time.time()
+        while True:
+            for r in range(self.world):
+                try:
+                    if r not in errs and self.store.check(['error/%d' % r]):
+                        errs[r] = self.store.get('error/%d' % r).decode()
+                except Exception:      # noqa: BLE001
+                    pass
+            if time.time() - t0 >= wait_s:
+                return errs
+            time.sleep(0.05)
+
+    # -- the payload ---------------------------------------------------------------------------------------------------------
+    def load_weights(self, engine, state_dict_fn, src=0):
+        """Rank `src` packs, the arena travels with ONE broadcast; if the collective backend is down or the broadcast fails on any rank, EVERY rank
+        packs from the seed locally (the pack is deterministic: the arena checksums of the per-rank report must still agree).  Sets
+        self.weights_via: 'local_pack' (one rank), 'broadcast', or 'local_pack_fallback'."""
+        if self.world == 1:
+            engine.load_weights(state_dict_fn())
+            return engine
+        ok = self.collective_ok
+        err = None
+        if ok:
+            try:
+                if os.environ.get('XFR_TEST_FAIL_BROADCAST') == '1' and self.rank != src:
+                    raise RuntimeError('XFR_TEST_FAIL_BROADCAST: simulated broadcast failure')
+                if self.rank == src:
+                    engine.load_weights(state_dict_fn())
+                arena = engine.weight_arena()
+                work = dist.broadcast(arena, src=src, async_op=True)
+                import datetime
+                work.wait(datetime.timedelta(seconds=self.timeout_s))
+                if arena.is_cuda:
+                    torch.cuda.synchronize()
+            except Exception as ex:    # noqa: BLE001
+                ok, err = False, repr(ex)
+        if self.agree(ok):
+            if self.rank != src:
+                engine.mark_weights_loaded()
+            self.weights_via = 'broadcast'
+            return engine
+        if err:
+            sys_note = 'weight broadcast failed on rank %d: %s' % (self.rank, err)
+            self.notes.append(sys_note)
+        self.collective_ok = False          # a collective that failed half way leaves the backend in an unknown state: the store from here on
+        engine.load_weights(state_dict_fn())
+        self.weights_via = 'local_pack_fallback'
+        return engine
+
+    def close(self):
+        if self.world > 1 and dist.is_initialized():
+            try:
+                if self.collective_ok:
+                    dist.barrier()
+                dist.destroy_process_group()
+            except Exception:          # noqa: BLE001
+                pass
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of n_items for `rank` (sizes differ by at most one)."""
     q, r = divmod(int(n_items), int(world))
@@ -169,11 +350,14 @@ def bind_rank_cpus(local, local_world, nodes=None, allowed=None):
             'n_cpus': len(mine), 'numa_node': node, 'how': how}
 
 
-def gather_rank_rates(rate, device=None):
+def gather_rank_rates(rate, device=None, comm=None):
     """Every rank's own rate (units/s over ITS time for the timed steps) -> {'per_rank', 'min', 'max', 'spread'} on every rank;
-    spread = (max - min) / max: a straggler that the whole-job figure (max-over-ranks time) hides shows up here."""
+    spread = (max - min) / max: a straggler that the whole-job figure (max-over-ranks time) hides shows up here.  `comm` (a Comm): through its
+    store, so that the figure exists even when the collective backend does not."""
     rates = [float(rate)]
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if comm is not None and comm.world > 1:
+        rates = [float(v) if not isinstance(v, dict) else float('nan') for v in comm.gather_objects(float(rate), 'rank_rate')]
+    elif dist.is_initialized() and dist.get_world_size() > 1:
         t = torch.tensor([float(rate)], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
         dist.all_gather(outs, t)
