@@ -220,6 +220,22 @@ class Workload(object):
     pass
 
 
+def make_u8_step(eng, imgs, mean, B, enc_t, pct, dev):
+    """The same triplet step fed the way a caller holding decoded crops would feed it (xfr_triplet_contrastive_u8): the 3B images as uint8 H x W x 3
+    in PINNED host memory, the host-to-device copy and the on-device preprocessing inside the step.  imgs: the bench's fp32 images (mean
+    subtracted); their uint8 versions are round(img + mean)."""
+    import torch
+    m = torch.tensor(mean, dtype=torch.float32).reshape(1, 3, 1, 1)
+    u8 = (imgs + m).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().pin_memory()
+    eng.set_u8_preprocess('sub_mean', 3, tuple(float(v) for v in mean), None)
+    dev_buf = torch.empty_like(u8, device=dev)
+
+    def step():
+        dev_buf.copy_(u8, non_blocking=True)
+        return eng.triplet_contrastive_u8(dev_buf[2 * B:], dev_buf[:2 * B], enc_t, 1.0 / 2500.0, pct, inputs_ready=False)
+    return step
+
+
 def make_workload(args, dev, rank, cpu_only=False, comm=None):
     """cpu_only: no engine, no device -- just the inputs and the CPU port's unit of work (the whole-host baseline's workers)."""
     import torch
@@ -244,6 +260,7 @@ def make_workload(args, dev, rank, cpu_only=False, comm=None):
             enc_t = prog.marks['encode']
             W.pipeline = 1
             W.step = lambda ready=True: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, None, inputs_ready=ready)   # noqa: E731
+            W.u8_step = make_u8_step(eng, imgs, resnet.MEAN_RGB, B, enc_t, None, dev)
         W.flop_per_unit = 6 * F_FWD['resnet101']           # 2 encodes + true fwd + relu(W) fwd + 2 backward-data sweeps = 86.51 GFLOP
         W.metric = 'triplet-contrastive-EBP saliency maps/sec, ResNet-101 224x224'
         W.work = ('ResNet-101 triplet contrastive EBP, batch=%d synthetic 224x224 triplets per GPU (2 encodes + contrastive_ebp per '
@@ -275,6 +292,7 @@ def make_workload(args, dev, rank, cpu_only=False, comm=None):
             enc_t = prog.marks['encode']
             W.pipeline = 1
             W.step = lambda ready=True: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, 20.0, inputs_ready=ready)   # noqa: E731
+            W.u8_step = make_u8_step(eng, imgs, (131.0912, 103.8827, 91.4953), B, enc_t, 20.0, dev)
         W.flop_per_unit = 6 * F_FWD['resnet50_128']
         W.metric = 'triplet truncated-contrastive-EBP (20 %) saliency maps/sec, VGGFace2 ResNet-50-128d 224x224'
         W.work = 'ResNet-50-128d truncated contrastive EBP, batch=%d synthetic triplets per GPU, mode %s' % (B, W.mode)
@@ -616,6 +634,9 @@ def main():
     import torch.distributed as dist
     from xfr_amd import shard, tuning
 
+    if os.environ.get('XFR_FAULT_DUMP_S'):       # debugging aid: every thread's Python stack on stderr after that many seconds (and again, repeatedly)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['XFR_FAULT_DUMP_S']), repeat=True)
     # rendezvous with a bounded wait; a collective backend that does not come up is a reported condition, not a crash (shard.Comm)
     comm = shard.Comm()
     rank, world, local = comm.rank, comm.world, comm.local
@@ -647,6 +668,11 @@ def run(args, comm):
     rank, world, local = comm.rank, comm.world, comm.local
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    if world > 1:
+        # N ranks share the host's CPUs: the default of one intra-op thread per LOGICAL CPU (256 on these boxes, under a cgroup quota of 16) times N
+        # ranks stalls every rank's host-side tensor code for minutes (measured: eight ranks, > 100 s in the input synthesis); give each rank its share
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+        torch.set_num_threads(max(1, host_cpu_budget()['usable'] // max(1, local_world)))
     if os.environ.get('XFR_TEST_RAISE_RANK') == str(rank):
         raise RuntimeError('XFR_TEST_RAISE_RANK: simulated failure of rank %d' % rank)
     if args.inpainting_game:
@@ -659,7 +685,7 @@ def run(args, comm):
     eng, B = W.eng, W.B
     ranks = rank_report(eng, comm, binding)
     if rank == 0 and len({r.get('arena_checksum48') for r in ranks}) != 1:
-        sys.stderr.write('bench.py: the ranks hold different parameter arenas after the broadcast\n')
+        sys.stderr.write('bench.py: the ranks hold different parameter arenas after the broadcast: %s\n' % json.dumps(ranks))
         sys.exit(3)
 
     def barrier():
@@ -725,6 +751,22 @@ def run(args, comm):
             n_sus += 20
         sustained = {'maps_s': n_sus * B / (time.perf_counter() - t1), 'seconds': time.perf_counter() - t1, 'steps': n_sus}
 
+    # the same step with uint8 inputs arriving from pinned host memory: H2D copy and preprocessing inside the timed region (never `value`)
+    u8_e2e = None
+    if rank == 0 and world == 1 and getattr(W, 'u8_step', None) is not None and not args.serial:
+        for _ in range(3):
+            s8 = W.u8_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n8 = max(5, args.steps // 2)
+        for _ in range(n8):
+            s8 = W.u8_step()
+        torch.cuda.synchronize()
+        d8 = time.perf_counter() - t1
+        ok8 = bool(torch.isfinite(s8).all().item()) and float((s8.sum(dim=(1, 2)) - 1.0).abs().max().item()) < 1e-3
+        u8_e2e = {'maps_s': B * n8 / d8, 'ms_per_step': 1e3 * d8 / n8, 'steps': n8, 'outputs_ok': ok8,
+                  'what': 'xfr_triplet_contrastive_u8: the %d uint8 224x224x3 images of a step copied from pinned host memory (%.1f MB instead of %.1f MB as fp32) and '
+                          'preprocessed on the device, both inside the timed region' % (3 * B, 3 * B * 150528 / 1e6, 3 * B * 602112 / 1e6)}
     roof = None
     unfused_leg = None
     ms_step = 1e3 * dt / args.steps
@@ -793,6 +835,8 @@ def run(args, comm):
             line['rank_errors'] = {str(k): v for k, v in sorted(errs.items())}
         if world > 1:
             line['scaling_note'] = 'N > 1 has only ever run with several ranks on ONE GPU here (gloo); no multi-GPU node was available to the builder'
+        if u8_e2e is not None:
+            line['u8_end_to_end'] = u8_e2e
         if sustained is not None:
             line['sustained_maps_s'] = world * sustained['maps_s']
             line['sustained'] = sustained

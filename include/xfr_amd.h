@@ -267,6 +267,27 @@ xfr_status xfr_engine_hold_forward(xfr_engine* e, int32_t hold);
  * accumulated in one K order regardless of the batch). */
 xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable);
 
+/* uint8 entry points (ABI version 4).  The reference's callers hold decoded uint8 H x W x C crops and turn every one into a float tensor on the
+ * host (resnet.py:25-37 convert_resnet101v4_image, whitebox.py:235-258 Whitebox_resnet50_128.preprocess, lightcnn.py:19-25
+ * prepare_lightCNN_image) before it is copied to the device as fp32.  Here the uint8 images go to the device as they are -- a quarter of the bytes --
+ * and the layout kernel in front of the first convolution does that arithmetic, in float64 like numpy does, bit for bit the reference's tensor
+ * (tests/test_gpu_entry.py on the four bundled JPEGs): kind SUB_MEAN: out[c] = (float)((double)u8[c] - mean[c]); kind LUMINANCE (3-channel image,
+ * 1-channel network): (float)((r / 255) w[0] + (g / 255) w[1] + (b / 255) w[2]).  Resizing / cropping stays with the caller, as in the reference.
+ * x_u8_dev: n images, each in_h x in_w x channels, contiguous.  Everything else is xfr_forward / xfr_triplet_contrastive. */
+enum { XFR_U8_SUB_MEAN = 0, XFR_U8_LUMINANCE = 1 };
+typedef struct xfr_u8_preprocess {
+    int32_t kind;       /* XFR_U8_* */
+    int32_t channels;   /* of the uint8 images */
+    double mean[4];     /* SUB_MEAN: per image channel */
+    double weight[4];   /* LUMINANCE: per image channel */
+} xfr_u8_preprocess;
+xfr_status xfr_engine_set_u8_preprocess(xfr_engine* e, const xfr_u8_preprocess* p);
+xfr_status xfr_forward_u8(xfr_engine* e, const uint8_t* x_u8_dev, int32_t n, int32_t tensor_id, float* out_dev, void* stream);
+xfr_status xfr_triplet_contrastive_u8(xfr_engine* e, const uint8_t* probes_u8_dev, const uint8_t* gallery_u8_dev, int32_t n, int32_t encode_tensor,
+                                      float scale, float percentile, float* sal_dev, void* stream, int32_t inputs_ready);
+/* parity hook: the fp32 network input (n x C x H x W) the uint8 path builds from x_u8_dev */
+xfr_status xfr_debug_u8_preprocess(xfr_engine* e, const uint8_t* x_u8_dev, int32_t n, float* out_nchw_dev, void* stream);
+
 /* The lean schedule (on by default; ABI version 4).  A sweep nobody observes (no trace, prior, capture or stored firing; batch % 4 == 0) does not
  * need the literal operands a and x of whitebox.py:388-428 at every hook: the probe forward's W / relu(W) convolution forms the BatchNorm hook's
  * a / (x + eps) in its epilogue (both accumulators in one workgroup) and stores that ONE tensor instead of the two, with the sign bit recording
@@ -363,8 +384,8 @@ xfr_status xfr_debug_conv_stamps(void* stamps_dev, int32_t capacity_workgroups);
  * started and its last one ended (s_memrealtime, 10 ns ticks) and the library notes its shape, stream and tile configuration.  A
  * call with dump_path != NULL first writes what has been recorded so far as CSV (synchronise the device before); log_dev = NULL
  * stops recording.  tools/gemm_timeline.py reads the file.
- * xfr_debug_conv_stamps and xfr_debug_conv_log are PROCESS-GLOBAL and NOT thread-safe: set, dump and clear them from the one host thread
- * that also issues the engine calls being measured; no engine may be launching from another thread meanwhile.  A dump after
+ * xfr_debug_conv_stamps and xfr_debug_conv_log are PROCESS-GLOBAL (every engine of the process records into them) and mutex-guarded: engines
+ * may launch from other host threads while they are set, dumped or cleared; launches only touch the lock while a hook is on.  A dump after
  * log_dev = NULL writes nothing and returns XFR_OK. */
 xfr_status xfr_debug_conv_log(void* log_dev, int32_t capacity, const char* dump_path);
 

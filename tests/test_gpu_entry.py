@@ -190,24 +190,33 @@ def test_fresh_inputs_are_safe_under_pipelining(gpu_device):
 
 # ---- multi-rank --------------------------------------------------------------------------------------------------------
 def _run_ranks(cmd, world, port, extra_env=None, timeout=900):
-    """world processes on ONE GPU (gloo rendezvous on 127.0.0.1): the multi-process code path of the tools without an 8-GPU node."""
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r),
-                   XFR_DIST_BACKEND='gloo', XFR_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
-        env.update(extra_env or {})
-        procs.append(subprocess.Popen([sys.executable] + cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
+    """world processes on ONE GPU (gloo rendezvous on 127.0.0.1): the multi-process code path of the tools without an 8-GPU node.  Every rank's
+    stdout / stderr go to files (a rank blocked on a full pipe would block its peers at the next barrier)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        procs, files = [], []
+        for r in range(world):
+            env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r),
+                       XFR_DIST_BACKEND='gloo', XFR_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+            env.update(extra_env or {})
+            fo, fe = open(os.path.join(d, 'out%d' % r), 'w+'), open(os.path.join(d, 'err%d' % r), 'w+')
+            files.append((fo, fe))
+            procs.append(subprocess.Popen([sys.executable] + cmd, cwd=ROOT, env=env, stdout=fo, stderr=fe, text=True))
+        outs = []
         try:
-            o, e = p.communicate(timeout=timeout)
+            for p in procs:
+                p.wait(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
             raise
-        assert p.returncode == 0, 'rank failed:\n%s\n%s' % (o[-2000:], e[-4000:])
-        outs.append(o)
-    return outs
+        for p, (fo, fe) in zip(procs, files):
+            fo.seek(0)
+            fe.seek(0)
+            o, e = fo.read(), fe.read()
+            assert p.returncode == 0, 'rank failed:\n%s\n%s' % (o[-2000:], e[-4000:])
+            outs.append(o)
+        return outs
 
 
 def test_two_ranks_shard_the_inpainting_game_workload(gpu_device, tmp_path):
@@ -313,7 +322,7 @@ def test_bench_survives_a_failed_weight_broadcast(gpu_device):
     the line says "weights_via": "local_pack_fallback" -- not rc != 0 (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:101-118: the
     reference's workers survive a failing job too)."""
     outs = _run_ranks(['bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '4', '--no-cpu-baseline', '--no-sustained', '--no-profile'],
-                      2, 29681, extra_env={'XFR_TEST_FAIL_BROADCAST': '1', 'XFR_DIST_TIMEOUT': '60'})
+                      2, 29681, extra_env={'XFR_TEST_FAIL_BROADCAST': '1', 'XFR_DIST_TIMEOUT': '45'})
     j = json.loads([ln for ln in outs[0].splitlines() if ln.startswith('{')][0])
     assert j['n_gpus'] == 2 and j['outputs_ok'] is True and j['weights_via'] == 'local_pack_fallback' and j['collective_backend_ok'] is False
     assert len({r['arena_checksum48'] for r in j['ranks']}) == 1 and all(r['weights_via'] == 'local_pack_fallback' for r in j['ranks'])
@@ -322,13 +331,23 @@ def test_bench_survives_a_failed_weight_broadcast(gpu_device):
 def test_bench_surfaces_a_failing_rank(gpu_device):
     """Rank 1 raises (XFR_TEST_RAISE_RANK): rank 0 neither hangs nor dies silently -- it prints ONE JSON line with every rank's exception text
     and both exit with code 4."""
-    procs = []
+    import tempfile
+    procs, files = [], []
+    tmp = tempfile.mkdtemp()
     for r in range(2):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29687', WORLD_SIZE='2', RANK=str(r), LOCAL_RANK=str(r), XFR_DIST_BACKEND='gloo',
                    XFR_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0', XFR_TEST_RAISE_RANK='1', XFR_DIST_TIMEOUT='60')
+        fo, fe = open(os.path.join(tmp, 'o%d' % r), 'w+'), open(os.path.join(tmp, 'e%d' % r), 'w+')
+        files.append((fo, fe))
         procs.append(subprocess.Popen([sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '4', '--no-cpu-baseline',
-                                       '--no-sustained', '--no-profile'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+                                       '--no-sustained', '--no-profile'], cwd=ROOT, env=env, stdout=fo, stderr=fe, text=True))
+    for p in procs:
+        p.wait(timeout=600)
+    outs = []
+    for fo, fe in files:
+        fo.seek(0)
+        fe.seek(0)
+        outs.append((fo.read(), fe.read()))
     assert [p.returncode for p in procs] == [4, 4], [o[1][-1500:] for o in outs]
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith('{')]
     assert len(lines) == 1
@@ -341,7 +360,7 @@ def test_bench_eight_ranks_on_one_gpu(gpu_device, bind):
     """Eight ranks (the driver's 8-GPU launch shape) as eight processes on this one GPU, four triplets each: eight launch threads fit the
     host's CPU quota with and without --bind, one line, eight equal arena checksums, one broadcast."""
     cmd = ['bench.py', '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '4', '--no-cpu-baseline', '--no-sustained', '--no-profile']
-    outs = _run_ranks(cmd + (['--bind'] if bind else []), 8, 29691 + int(bind) * 40, extra_env={'XFR_DIST_TIMEOUT': '300'}, timeout=1500)
+    outs = _run_ranks(cmd + (['--bind'] if bind else []), 8, 29691 + int(bind) * 40, extra_env={'XFR_DIST_TIMEOUT': '240'}, timeout=900)
     j = json.loads([ln for ln in outs[0].splitlines() if ln.startswith('{')][0])
     assert j['n_gpus'] == 8 and j['outputs_ok'] is True and j['weights_via'] == 'broadcast' and len(j['ranks']) == 8
     assert len({r['arena_checksum48'] for r in j['ranks']}) == 1 and len(j['rank_maps_s']['per_rank']) == 8
@@ -414,3 +433,40 @@ def test_image_mwp_of_every_backbone(gpu_device, arch, mode):
         subj.wb.ebp(x, P2)
         assert torch.equal(subj.wb.P[-1], ref), level
     eng.set_pipeline(0)
+
+
+@pytest.mark.parametrize('arch', ['stresnet101', 'resnet50_128', 'lightcnn29v2'])
+def test_uint8_entry_points_match_the_reference_preprocessing(gpu_device, arch):
+    """xfr_forward_u8 / xfr_triplet_contrastive_u8: uint8 H x W x C crops go to the device as they are and the engine does the pixel arithmetic of
+    convert_resnet101v4_image (resnet.py:25-37), Whitebox_resnet50_128.preprocess (whitebox.py:235-258) and prepare_lightCNN_image
+    (lightcnn.py:19-25).  On the four bundled JPEGs: the fp32 network input it builds equals the host function's tensor BIT FOR BIT, hence
+    encodings and triplet maps from uint8 equal those from the preprocessed float tensors bit for bit."""
+    import PIL.Image
+    import golden_cases as GC
+    from xfr_amd.models import whitebox as WB
+    bb, sd = make_backbone(arch if arch != 'stresnet101' else 'stresnet_mini', seed=2, num_classes=None if arch == 'resnet50_128' else 5)
+    bb.to(gpu_device)
+    wbn = {'stresnet101': WB.WhiteboxSTResnet, 'resnet50_128': WB.Whitebox_resnet50_128, 'lightcnn29v2': WB.WhiteboxLightCNN}[arch](bb)
+    wb = WB.Whitebox(wbn, ebp_subtree_mode='affineonly_with_prior')
+    pics = [GC.jpegs()[f] for f in GC.JPEGS]                                   # 224 x 224 x 3 uint8
+    if arch == 'lightcnn29v2':                                                 # Resize(144) + CenterCrop(128) stay on the host, like in the reference
+        crops = []
+        for a in pics:
+            im = PIL.Image.fromarray(a).resize((144, 144), PIL.Image.BILINEAR).crop((8, 8, 136, 136))
+            crops.append(np.asarray(im).copy())
+        host = torch.cat([WB.lightcnn_preprocess.__globals__['prepare_lightCNN_image'](PIL.Image.fromarray(c)) for c in crops])
+    elif arch == 'resnet50_128':
+        crops = pics
+        host = torch.cat([wbn.preprocess(PIL.Image.fromarray(c)) for c in crops])        # 224 x 224 in: its resize / crop are the identity
+    else:
+        crops = pics
+        host = torch.cat([wbn.preprocess(PIL.Image.fromarray(c)) for c in crops])
+    u8 = torch.from_numpy(np.stack(crops))
+    eng = wb._engine(8)
+    dev_in = eng.preprocess_u8(u8).cpu()
+    assert dev_in.shape == host.shape and torch.equal(dev_in, host.float())
+    assert torch.equal(wbn.encode_u8(u8), wbn.encode(host.to(gpu_device)))
+    a = wb.triplet_images_ebp_batch_u8(u8, u8[[1, 2, 3, 0]], u8[[2, 3, 0, 1]])
+    b = wb.triplet_images_ebp_batch(host.to(gpu_device), host[[1, 2, 3, 0]].to(gpu_device), host[[2, 3, 0, 1]].to(gpu_device))
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+

@@ -239,8 +239,11 @@ def test_golden_contrastive_cases_on_the_lean_schedule(gpu_device, arch, mode):
     inner = _check_factory()
 
     def check(key, res, trace, g):
+        prev = PARITY_REPORT.get(key)            # the literal replay's entry of the same case, if that test ran before
         inner(key, res, None, g)
         PARITY_REPORT[key + ' [lean, batch of 4]'] = PARITY_REPORT.pop(key)
+        if prev is not None:
+            PARITY_REPORT[key] = prev
     GC.replay(subj, cases, gold, check)
     if arch == 'resnet50_128':
         gs = GC.golden('golden_synth')

@@ -205,3 +205,52 @@ def test_comm_entry_points_check_arguments():
     assert lib.xfr_comm_init(0, 0, None, 0, ctypes.byref(h)) == _lib.XFR_INVALID_ARG
     assert lib.xfr_broadcast_weights(None, None, 0, None) == _lib.XFR_INVALID_ARG
     assert lib.xfr_comm_destroy(None) == _lib.XFR_OK
+
+
+# (backbone, subtree mode, xfr_engine_set_epilogue_fusion level or None = default) -> firings, launches of the fused sweep, launches of the un-fused one,
+# backward GEMMs, stand-alone chain launches, gradient copies left, lean convolutions.  One row per fusion pass that can be switched: 67 = without the
+# average-pool shortcut rewrite (pass 2b), 131 = without the projection-shortcut side branch (3c), 259 = the shortcut in program order (forward side
+# only: the sweep is the default's), 0 = no fusion into GEMM epilogues at all (copy forwarding, the pool pair and chain -> chain merges remain).
+FUSION_TABLE = [
+    ('stresnet101', 'affineonly_with_prior', None, 377, 110, 321, 100, 7, 0, 41),
+    ('stresnet101', 'norelu', None, 377, 110, 321, 100, 7, 0, 41),
+    ('resnet50_128', 'affineonly_with_prior', None, 157, 60, 161, 53, 5, 0, 27),
+    ('resnet50_128', 'norelu', None, 157, 60, 161, 53, 5, 0, 27),
+    ('lightcnn29v2', 'affineonly_with_prior', None, 86, 33, 166, 29, 4, 0, 0),
+    ('lightcnn29v2', 'norelu', None, 86, 33, 166, 29, 4, 0, 0),
+    ('stresnet101', 'affineonly_with_prior', 67, 377, 120, 321, 100, 10, 4, 41),
+    ('resnet50_128', 'norelu', 67, 157, 63, 161, 53, 5, 0, 27),
+    ('stresnet101', 'norelu', 131, 377, 114, 321, 100, 11, 0, 41),
+    ('resnet50_128', 'norelu', 131, 157, 64, 161, 53, 9, 0, 27),
+    ('stresnet101', 'affineonly_with_prior', 259, 377, 110, 321, 100, 7, 0, 41),
+    ('stresnet101', 'affineonly_with_prior', 0, 377, 124, 321, 100, 14, 4, 0),
+    ('resnet50_128', 'norelu', 0, 157, 67, 161, 53, 9, 0, 0),
+    ('lightcnn29v2', 'affineonly_with_prior', 0, 86, 45, 166, 29, 8, 0, 0),
+]
+
+
+@pytest.mark.parametrize('row', FUSION_TABLE, ids=lambda r: '%s-%s-%s' % (r[0], r[1], r[2]))
+def test_fusion_passes_table(row):
+    """The planner's fusion passes (engine.hip: fuse_copy_forwarding, fuse_pool_pair, fuse_downsample_avgpool / _projection, fuse_stage_head_relu /
+    _branch, fuse_merge_to_fixed_point; lean_prepare), one table row per backbone / mode / switchable pass: what each pass removes is pinned as a
+    launch count, so a change to one pass shows up as the row it moves."""
+    import re
+    from xfr_amd.models import lightcnn, resnet, resnet50_128
+    arch, mode, fusion, firings, launches, unfused, gemms, chains, copies, lean = row
+    prog = {'stresnet101': lambda: resnet.ResNet([3, 4, 23, 3], num_classes=65359), 'resnet50_128': resnet50_128.Resnet50_128,
+            'lightcnn29v2': lambda: lightcnn.LightCNN_29Layers_v2(num_classes=80013)}[arch]().build_program()
+    if fusion is not None:
+        os.environ['XFR_DESCRIBE_FUSION'] = str(fusion)
+    try:
+        text = prog.describe(mode, prog.marks['encode'])
+    finally:
+        os.environ.pop('XFR_DESCRIBE_FUSION', None)
+    m = re.search(r'firings (\d+) launches (\d+) \(unfused (\d+)\)', text)
+    kinds = {}
+    for ln in text.splitlines():
+        if ln.startswith('bwd '):
+            kinds[ln.split()[1]] = kinds.get(ln.split()[1], 0) + 1
+    ml = re.search(r'lean convolutions (\d+)', text)
+    got = (int(m.group(1)), int(m.group(2)), int(m.group(3)), kinds.get('CONV_BWD', 0), kinds.get('EW', 0), kinds.get('COPY', 0), int(ml.group(1)) if ml else 0)
+    assert got == (firings, launches, unfused, gemms, chains, copies, lean)
+

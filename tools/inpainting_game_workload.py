@@ -46,6 +46,8 @@ def main():
     from xfr_amd.models import resnet, whitebox as WB
 
     rank, world, local = shard.init_process_group()
+    if world > 1:      # N ranks share the host's CPUs (see bench.py): one intra-op thread per logical CPU per rank stalls all of them
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16)) // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     bb = resnet.ResNet([3, 4, 23, 3], num_classes=args.num_classes)

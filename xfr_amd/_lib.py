@@ -5,7 +5,7 @@ import os
 from .program import OpDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libxfr_amd.so')
+LIB_PATH = os.environ.get('XFR_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libxfr_amd.so')      # XFR_AMD_LIB: A/B builds of the same ABI (tools/ab_env.sh)
 
 XFR_OK, XFR_INVALID_ARG, XFR_UNSUPPORTED_LAYER, XFR_OOM, XFR_HIP_ERROR, XFR_STATE_ERROR, XFR_RCCL_ERROR = range(7)
 ABI_VERSION = 4
@@ -13,6 +13,10 @@ ABI_VERSION = 4
 
 class TensorView(ctypes.Structure):
     _fields_ = [('data', ctypes.c_void_p), ('numel', ctypes.c_int64)]
+
+
+class U8Preprocess(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('channels', ctypes.c_int32), ('mean', ctypes.c_double * 4), ('weight', ctypes.c_double * 4)]
 
 
 class XfrError(RuntimeError):
@@ -44,6 +48,10 @@ SYMBOLS = [
     ('xfr_contrastive', _I, [_P, _P, _I, _I, _P, _F, _P, _P]),
     ('xfr_contrastive_raw', _I, [_P, _P, _I, _I, _P, _F, _P, _P]),
     ('xfr_triplet_contrastive', _I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I]),
+    ('xfr_engine_set_u8_preprocess', _I, [_P, ctypes.POINTER(U8Preprocess)]),
+    ('xfr_forward_u8', _I, [_P, _P, _I, _I, _P, _P]),
+    ('xfr_triplet_contrastive_u8', _I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I]),
+    ('xfr_debug_u8_preprocess', _I, [_P, _P, _I, _P, _P]),
     ('xfr_engine_set_pipeline', _I, [_P, _I]),
     ('xfr_engine_set_inputs_ready', _I, [_P, _I]),
     ('xfr_engine_set_tail_balance', _I, [_P, _I]),

@@ -316,6 +316,11 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
 // ---- simple forward / backward kernels -----------------------------------------------------------------------
 void launch_nchw_to_cnhw(const float* in, float* out, int N, int C, int HW, hipStream_t s);
 void launch_cnhw_to_nchw(const float* in, float* out, int N, int C, int HW, hipStream_t s);
+// uint8 H x W x C images (as a decoder hands them over) -> the network's fp32 input in CNHW, preprocessing included, in float64 like the
+// reference's numpy code: kind 0 = out[c] = (float)(u8[c] - mean[c]) (resnet.py:25-37, whitebox.py:235-258), kind 1 = luminance
+// (float)((r/255) w0 + (g/255) w1 + (b/255) w2) into ONE channel (lightcnn.py:19-25 through skimage's rgb2gray)
+struct U8Pre { int kind; int channels; double mean[4]; double weight[4]; };
+void launch_u8hwc_to_cnhw(const uint8_t* in, float* out, int N, int Cnet, int HW, const U8Pre& pre, hipStream_t s);
 // out = maybe_relu( maybe_relu_in(in) * alpha[c] + beta[c] )
 void launch_affine_c(const float* in, float* out, const float* alpha, const float* beta, int C, long per_c,
                      int relu_in, int relu_out, hipStream_t s);

@@ -30,6 +30,7 @@
 // no per-element address arithmetic and no branches.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <vector>
 #include "common.h"
 #include <cstdio>
@@ -1369,34 +1370,43 @@ int conv_gemm_pick_cfg(const ConvParams& p_in)
     return 4;
 }
 
+// Tuning state (stamps, launch log): process-global, shared by every engine of the process.  g_tuning says whether any of it is on -- the launch
+// path takes g_tune_mu only then, so production launches (tuning off) pay one relaxed atomic load; with tuning on, engines launching from several
+// host threads serialise on the mutex while they take their record, and set / dump / clear are safe against them.
+static std::mutex g_tune_mu;
+static std::atomic<int> g_tuning{0};
 static unsigned long long* g_stamps = nullptr;
 static int g_stamps_cap = 0;
 static int g_stamp_regions = 0, g_stamp_seq = 0;
-// capacity < 0: sampled mode -- |capacity| / 256 regions of 256 records, launch n writes up to 256 evenly spaced workgroups into region n % regions
-void conv_gemm_set_stamps(unsigned long long* dev_ptr, int capacity_workgroups)
-{
-    g_stamps = dev_ptr;
-    g_stamps_cap = dev_ptr ? (capacity_workgroups < 0 ? -capacity_workgroups : capacity_workgroups) : 0;
-    g_stamp_regions = (dev_ptr && capacity_workgroups < 0) ? (-capacity_workgroups) / 256 : 0;
-    g_stamp_seq = 0;
-}
-
 namespace {
 struct LogRec { void* stream; int cout, nhalves, K, M, kh, chain, cfg; };
 unsigned long long* g_log = nullptr;
 int g_log_cap = 0;
 std::vector<LogRec> g_log_recs;
+bool g_log_on() { return g_log != nullptr; }
 }
-// The tuning hooks below (stamps, launch log) are process-global and NOT thread-safe: one host thread, no engine launching on another
-// thread while they are being set, dumped or cleared (include/xfr_amd.h says so for xfr_debug_conv_log / xfr_debug_conv_stamps).
+// capacity < 0: sampled mode -- |capacity| / 256 regions of 256 records, launch n writes up to 256 evenly spaced workgroups into region n % regions
+void conv_gemm_set_stamps(unsigned long long* dev_ptr, int capacity_workgroups)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_stamps = dev_ptr;
+    g_stamps_cap = dev_ptr ? (capacity_workgroups < 0 ? -capacity_workgroups : capacity_workgroups) : 0;
+    g_stamp_regions = (dev_ptr && capacity_workgroups < 0) ? (-capacity_workgroups) / 256 : 0;
+    g_stamp_seq = 0;
+    g_tuning.store((g_stamps || g_log_on()) ? 1 : 0);
+}
+
 void conv_gemm_set_log(unsigned long long* log_dev, int capacity)
 {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
     g_log = log_dev;
     g_log_cap = log_dev ? capacity : 0;
     g_log_recs.clear();
+    g_tuning.store((g_stamps || g_log) ? 1 : 0);
 }
 int conv_gemm_dump_log(const char* path)
 {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
     if (!g_log) return 0;                       // logging was stopped: the host records are stale, the device buffer may be gone
     const size_t n = g_log_recs.size();
     std::vector<unsigned long long> h(8 * n + 8);
@@ -1415,14 +1425,21 @@ int conv_gemm_dump_log(const char* path)
 bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
-    p.stamps = g_stamps;
-    p.stamps_cap = g_stamps_cap;
-    p.stamp_regions = g_stamp_regions;
-    p.stamp_seq = g_stamps ? g_stamp_seq++ : 0;
+    p.stamps = nullptr;
+    p.stamps_cap = 0;
+    p.stamp_regions = 0;
+    p.stamp_seq = 0;
     p.span = nullptr;
-    if (g_log && (int)g_log_recs.size() < g_log_cap) {
-        p.span = g_log + 8 * g_log_recs.size();
-        g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.dualacc ? 2 : p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
+    if (g_tuning.load(std::memory_order_relaxed)) {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        p.stamps = g_stamps;
+        p.stamps_cap = g_stamps_cap;
+        p.stamp_regions = g_stamp_regions;
+        p.stamp_seq = g_stamps ? g_stamp_seq++ : 0;
+        if (g_log && (int)g_log_recs.size() < g_log_cap) {
+            p.span = g_log + 8 * g_log_recs.size();
+            g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.dualacc ? 2 : p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
+        }
     }
     int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
     {

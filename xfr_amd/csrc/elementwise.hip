@@ -268,6 +268,25 @@ __global__ __launch_bounds__(NT) void nchw_to_cnhw_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(NT) void u8hwc_to_cnhw_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int N, int Cnet, int HW, const U8Pre pre)
+{
+    const long total = (long)N * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int n = (int)(i / HW);
+        const int hw = (int)(i - (long)n * HW);
+        const uint8_t* px = in + i * pre.channels;
+        if (pre.kind == 0) {
+            for (int c = 0; c < Cnet; ++c) out[((long)c * N + n) * HW + hw] = (float)__dsub_rn((double)px[c], pre.mean[c]);
+        } else {
+            // (rgb / 255) @ w, left to right, no contraction
+            double v = __dmul_rn(__ddiv_rn((double)px[0], 255.0), pre.weight[0]);
+            v = __dadd_rn(v, __dmul_rn(__ddiv_rn((double)px[1], 255.0), pre.weight[1]));
+            v = __dadd_rn(v, __dmul_rn(__ddiv_rn((double)px[2], 255.0), pre.weight[2]));
+            out[(long)n * HW + hw] = (float)v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void cnhw_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                          int N, int C, int HW)
 {
@@ -1023,6 +1042,10 @@ void launch_ew_chain(const float* src, float* dst, int accumulate, const EwChain
 void launch_nchw_to_cnhw(const float* in, float* out, int N, int C, int HW, hipStream_t s)
 {
     hipLaunchKernelGGL(nchw_to_cnhw_kernel, dim3(grid_for((long)N * C * HW)), dim3(NT), 0, s, in, out, N, C, HW);
+}
+void launch_u8hwc_to_cnhw(const uint8_t* in, float* out, int N, int Cnet, int HW, const U8Pre& pre, hipStream_t s)
+{
+    hipLaunchKernelGGL(u8hwc_to_cnhw_kernel, dim3(grid_for((long)N * HW)), dim3(NT), 0, s, in, out, N, Cnet, HW, pre);
 }
 void launch_cnhw_to_nchw(const float* in, float* out, int N, int C, int HW, hipStream_t s)
 {

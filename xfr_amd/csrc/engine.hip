@@ -218,6 +218,11 @@ struct xfr_engine {
                                        // hook chain that follows (EW_AVGUP_IN; xfr_engine_set_epilogue_fusion bit 6 clear)
     bool fuse_branch = true;           // projection-shortcut blocks: the main path's hook chain as a side branch of the Add-output GEMM's epilogue (EW_STORE actions
                                        // 1 / 2; xfr_engine_set_epilogue_fusion bit 7 clear)
+    // uint8 entry points (xfr_forward_u8 / xfr_triplet_contrastive_u8): the image pointer handed to the forward is uint8 H x W x C and the layout
+    // kernel in front of the first convolution does the reference's preprocessing arithmetic (xfr_engine_set_u8_preprocess)
+    bool u8_on = false;
+    bool u8_set = false;
+    U8Pre u8_pre;
     bool lean = true;                  // xfr_engine_set_lean: plain sweeps (no trace / prior / capture / stored firing, batch % 4 == 0) take the lean schedule
     const BwdPlan* lean_cur = nullptr; // the plan whose lean tables the running probe forward / sweep follow (null: literal)
     bool lean_decide = false;          // lean_prepare's dry run of the probe forward: decide per convolution, record in lean_q_run / lean_final_run
@@ -636,7 +641,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
         HIP_TRY(hipEventRecord(ev.first, s));
         launch_conv_gemm(p, s);
         HIP_TRY(hipEventRecord(ev.second, s));
-        e->prof_flops += 2.0 * (double)(p.K_logical ? p.K_logical : p.K) * (double)p.M * (double)p.CoutTot * (double)p.nhalves;
+        e->prof_flops += 2.0 * (double)(p.K_logical ? p.K_logical : p.K) * (double)p.M * (double)p.CoutTot * (double)(p.dualacc ? 2 : p.nhalves);
     } else if (!launch_conv_gemm(p, s)) {
         return fail(XFR_STATE_ERROR, "%s", conv_gemm_refusal(conv_gemm_cannot_launch(p)));
     }
@@ -1130,7 +1135,9 @@ xfr_status forward_all(xfr_engine* e, const float* x_dev, int B, int last_tensor
     if (holdable) with_pos = true;           // later calls of the group may need the positive pass
     e->held_x = nullptr;
     const Tensor& in = e->tens[0];
-    launch_nchw_to_cnhw(x_dev, e->T(0), B, in.C, in.HW(), s);
+    if (e->dry_run) { }
+    else if (e->u8_on) launch_u8hwc_to_cnhw(reinterpret_cast<const uint8_t*>(x_dev), e->T(0), B, in.C, in.HW(), e->u8_pre, s);
+    else launch_nchw_to_cnhw(x_dev, e->T(0), B, in.C, in.HW(), s);
     const int last_op = e->tens[last_tensor].producer;
     e->fwd_done.assign(e->ops.size(), 0);
     e->pos_done.assign(e->ops.size(), 0);
@@ -1351,26 +1358,38 @@ xfr_status make_plan(xfr_engine* e, int seed_tensor, BwdPlan& plan, bool plain)
 //   2. chain -> chain: EW(a->b) followed by EW(b->c) becomes one launch (with an EW_STORE of b if b has other readers).
 //   3. GEMM -> chain: a non-scattering backward-data GEMM whose output only feeds a chain runs that chain in its
 //      epilogue, so the gradient between two GEMMs is never written to HBM un-hooked.
-void fuse_plan(xfr_engine* e, BwdPlan& plan)
+// ---- helpers shared by the fusion passes
+BwdStep::Sym fuse_mk(int type, int t0)
+{
+    BwdStep::Sym s; s.type = type; s.action = 0; s.t0 = t0; s.x_t = -1; s.f = 0.f; s.op = -1; s.slot = -1; s.tap = false;
+    return s;
+}
+bool fuse_reads(const BwdStep& b, int t)
+{
+    if (b.kind != ST_ZERO && b.src_t == t) return true;
+    for (const BwdStep::Sym& y : b.chain) if (y.type == EW_ADDP && y.t0 == t) return true;
+    for (const BwdStep::Sym& y : b.chain) if (y.type == EW_AVGUP_IN && y.slot == t) return true;      // the compact GEMM result in t's gradient region
+    if (b.accumulate && b.dst_t == t) return true;
+    return false;
+}
+bool fuse_writes(const BwdStep& b, int t)
+{
+    if (b.dst_t == t) return true;
+    for (const BwdStep::Sym& y : b.chain) if (y.type == EW_STORE && y.t0 == t) return true;
+    return false;
+}
+
+// Pass 1: copy forwarding.
+void fuse_copy_forwarding(xfr_engine* e, std::vector<BwdStep>& st)
 {
     typedef BwdStep::Sym Sym;
-    std::vector<BwdStep> st = plan.steps;
     const int nt = (int)e->tens.size();
-    auto mk = [](int type, int t0) { Sym s; s.type = type; s.action = 0; s.t0 = t0; s.x_t = -1; s.f = 0.f; s.op = -1; s.slot = -1; s.tap = false; return s; };
+    (void)nt; (void)sizeof(Sym);
+    auto mk = fuse_mk;
+    auto reads = fuse_reads;
+    auto writes = fuse_writes;
     auto scatter_conv = [&](const BwdStep& b) { return b.kind == ST_CONV_BWD && e->ops[b.op].d.stride != 1; };
-    auto reads = [&](const BwdStep& b, int t) {
-        if (b.kind != ST_ZERO && b.src_t == t) return true;
-        for (const Sym& y : b.chain) if (y.type == EW_ADDP && y.t0 == t) return true;
-        for (const Sym& y : b.chain) if (y.type == EW_AVGUP_IN && y.slot == t) return true;      // the compact GEMM result in t's gradient region
-        if (b.accumulate && b.dst_t == t) return true;
-        return false;
-    };
-    auto writes = [&](const BwdStep& b, int t) {
-        if (b.dst_t == t) return true;
-        for (const Sym& y : b.chain) if (y.type == EW_STORE && y.t0 == t) return true;
-        return false;
-    };
-    // ---- 1. copy forwarding
+    (void)mk; (void)reads; (void)writes; (void)scatter_conv;
     {
         std::vector<BwdStep> out;
         std::vector<int> alias(nt, -1);
@@ -1426,6 +1445,19 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
         }
         st.swap(out);
     }
+}
+
+// Pass 1b: Light-CNN's pool pair.
+void fuse_pool_pair(xfr_engine* e, std::vector<BwdStep>& st)
+{
+    typedef BwdStep::Sym Sym;
+    const int nt = (int)e->tens.size();
+    (void)nt; (void)sizeof(Sym);
+    auto mk = fuse_mk;
+    auto reads = fuse_reads;
+    auto writes = fuse_writes;
+    auto scatter_conv = [&](const BwdStep& b) { return b.kind == ST_CONV_BWD && e->ops[b.op].d.stride != 1; };
+    (void)mk; (void)reads; (void)writes; (void)scatter_conv;
     // ---- 1b. pool pair (lightcnn.py:252: maxpool(x) + avgpool(x), both 2x2 / 2 on the same x).  AVGPOOL_BWD(S -> D), accumulating
     // MAXPOOL_BWD(S -> D) and the in-place hook chain of D (the two pools' tensor hooks on the accumulated gradient) become ONE chain launch
     // whose head (EW_POOL2_IN) builds the summed gradient of a pixel from its window's gradient and argmax byte: D is written once
@@ -1464,12 +1496,19 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
         st[i] = f;
         st.erase(st.begin() + i + 1, st.begin() + i + 1 + drop);
     }
-    // ---- 2 + 3, to a fixed point: first among the chain launches only (plan.fused: the schedule of the sweeps that carry
-    // priors / captures), then with the backward GEMMs as heads of chains too (plan.fused_gemm)
-    // pass 2: additionally the MaxFeatureMap VJP as a fan-out in the epilogue of the GEMM that produces its gradient
-    for (int pass = 0; pass < 3; ++pass) {
-    if (pass == 1) plan.fused = st;
-    if (pass == 1 && e->fuse_avgup) {
+}
+
+// Pass 2b: down-sampling residual block with an average-pool shortcut.
+void fuse_downsample_avgpool(xfr_engine* e, std::vector<BwdStep>& st)
+{
+    typedef BwdStep::Sym Sym;
+    const int nt = (int)e->tens.size();
+    (void)nt; (void)sizeof(Sym);
+    auto mk = fuse_mk;
+    auto reads = fuse_reads;
+    auto writes = fuse_writes;
+    auto scatter_conv = [&](const BwdStep& b) { return b.kind == ST_CONV_BWD && e->ops[b.op].d.stride != 1; };
+    (void)mk; (void)reads; (void)writes; (void)scatter_conv;
         // ---- 2b (GEMM-fused schedules only: no traces, priors or stores there).  Down-sampling residual block, shortcut = AvgPool2d(2) [+ ConcatChannels],
         // main path entered through a 1x1 / stride 2 convolution (resnet.py:111-149).  Its block-input gradient D was built by five launches:
         //   COPY S -> P (channel prefix), EW P (the pooled tensor's hook, in place), AVGPOOL_BWD P -> D, ..., CONV_BWD -> D (scatter, read-modify-write),
@@ -1550,8 +1589,19 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             st.erase(st.begin() + i0);
             --i0;
         }
-    }
-    if (pass == 1 && e->fuse_avgup) {
+}
+
+// Pass 2b': down-sampling residual block with a projection shortcut.
+void fuse_downsample_projection(xfr_engine* e, std::vector<BwdStep>& st)
+{
+    typedef BwdStep::Sym Sym;
+    const int nt = (int)e->tens.size();
+    (void)nt; (void)sizeof(Sym);
+    auto mk = fuse_mk;
+    auto reads = fuse_reads;
+    auto writes = fuse_writes;
+    auto scatter_conv = [&](const BwdStep& b) { return b.kind == ST_CONV_BWD && e->ops[b.op].d.stride != 1; };
+    (void)mk; (void)reads; (void)writes; (void)scatter_conv;
         // ---- 2b'.  The same block input where the shortcut is a strided 1x1 projection (resnet50_128.py): ZERO D, CONV_BWD -> D (scatter), ...,
         // CONV_BWD -> D (scatter), EW D -> E.  Both GEMMs now work on the compact grid (the second accumulates there: dense rows), the zero fill
         // is gone and the chain's head puts the sum on the even pixels (EW_AVGUP_IN without a pooled source).
@@ -1604,8 +1654,19 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             st.erase(st.begin() + i0);
             --i0;
         }
-    }
-    if (pass == 2 && e->fuse_avgup) {
+}
+
+// Pass 3b: first block of a stage, both Add operands continue from the same clamp.
+void fuse_stage_head_relu(xfr_engine* e, std::vector<BwdStep>& st)
+{
+    typedef BwdStep::Sym Sym;
+    const int nt = (int)e->tens.size();
+    (void)nt; (void)sizeof(Sym);
+    auto mk = fuse_mk;
+    auto reads = fuse_reads;
+    auto writes = fuse_writes;
+    auto scatter_conv = [&](const BwdStep& b) { return b.kind == ST_CONV_BWD && e->ops[b.op].d.stride != 1; };
+    (void)mk; (void)reads; (void)writes; (void)scatter_conv;
         // ---- 3b (after the GEMM -> chain merges of pass 1).  First block of a stage: the GEMM that produces the gradient of the block's Add output ends [.., STORE(t), relu] -> D, where D (the
         // shortcut operand's gradient) and t (the main-path operand's) have different readers, and the main path's chain EW(t -> u) starts with the
         // same relu.  Both then continue from relu(v): the chain runs on in the GEMM's epilogue as [.., relu, STORE(D), rest] -> u -- the signature of
@@ -1650,8 +1711,19 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             a.dst_t = u;
             st.erase(st.begin() + j);
         }
-    }
-    if (pass == 2 && e->fuse_branch) {
+}
+
+// Pass 3c: first block of a stage with a projection shortcut, the main path's chain as a side branch.
+void fuse_stage_head_branch(xfr_engine* e, std::vector<BwdStep>& st)
+{
+    typedef BwdStep::Sym Sym;
+    const int nt = (int)e->tens.size();
+    (void)nt; (void)sizeof(Sym);
+    auto mk = fuse_mk;
+    auto reads = fuse_reads;
+    auto writes = fuse_writes;
+    auto scatter_conv = [&](const BwdStep& b) { return b.kind == ST_CONV_BWD && e->ops[b.op].d.stride != 1; };
+    (void)mk; (void)reads; (void)writes; (void)scatter_conv;
         // ---- 3c.  First block of a stage with a PROJECTION shortcut (resnet50_128.py): the GEMM that produces the gradient of the block's Add output
         // ends [.., mask, STORE(t), rest_s] -> D: D, the shortcut branch's gradient, continues in the epilogue, and t, the Add output's gradient, is
         // stored for the main path, whose own hook chain EW(t -> u) = [rest_m] was a launch of its own.  Both chains start from the same value:
@@ -1705,8 +1777,19 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             a.chain = merged;
             st.erase(st.begin() + j);
         }
-    }
-    if (pass == 2) plan.fused_gemm_nofan = st;
+}
+
+// Passes 2 + 3 to a fixed point: chain -> chain merges (pass 0), GEMM -> chain merges (pass >= 1), the MaxFeatureMap fan-out (pass 2).
+void fuse_merge_to_fixed_point(xfr_engine* e, std::vector<BwdStep>& st, int pass)
+{
+    typedef BwdStep::Sym Sym;
+    const int nt = (int)e->tens.size();
+    (void)nt; (void)sizeof(Sym);
+    auto mk = fuse_mk;
+    auto reads = fuse_reads;
+    auto writes = fuse_writes;
+    auto scatter_conv = [&](const BwdStep& b) { return b.kind == ST_CONV_BWD && e->ops[b.op].d.stride != 1; };
+    (void)mk; (void)reads; (void)writes; (void)scatter_conv;
     bool changed = true;
     while (changed) {
         changed = false;
@@ -1796,6 +1879,25 @@ void fuse_plan(xfr_engine* e, BwdPlan& plan)
             changed = true;
         }
     }
+}
+
+// The fused schedules of a plan, built by the passes above in this order.  plan.fused: copy forwarding, the pool pair and chain -> chain merges only (what
+// the observing sweeps run); plan.fused_gemm_nofan: + the down-sampling block rewrites and GEMM -> chain merges; plan.fused_gemm: + the MaxFeatureMap fan-out.
+void fuse_plan(xfr_engine* e, BwdPlan& plan)
+{
+    std::vector<BwdStep> st = plan.steps;
+    fuse_copy_forwarding(e, st);
+    fuse_pool_pair(e, st);
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass == 1) plan.fused = st;
+        if (pass == 1 && e->fuse_avgup) {
+            fuse_downsample_avgpool(e, st);
+            fuse_downsample_projection(e, st);
+        }
+        if (pass == 2 && e->fuse_avgup) fuse_stage_head_relu(e, st);
+        if (pass == 2 && e->fuse_branch) fuse_stage_head_branch(e, st);
+        if (pass == 2) plan.fused_gemm_nofan = st;
+        fuse_merge_to_fixed_point(e, st, pass);
     }
     plan.fused_gemm.swap(st);
 }
@@ -2503,7 +2605,9 @@ xfr_status xfr_forward(xfr_engine* e, const float* x_dev, int32_t n, int32_t ten
         if (st != XFR_OK) { const std::string why = g_err; join(); g_err = why; return st; }
         launch_cnhw_to_nchw(e->T(tensor_id), out_dev, n0, t.C, t.HW(), e->s_a);
         e->t_bank = nullptr;
-        st = forward_all(e, x_dev + (size_t)n0 * in_per_n, n - n0, tensor_id, false, e->s_b);
+        const float* x_hi = e->u8_on ? reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(x_dev) + (size_t)n0 * e->in_h * e->in_w * e->u8_pre.channels)
+                                     : x_dev + (size_t)n0 * in_per_n;
+        st = forward_all(e, x_hi, n - n0, tensor_id, false, e->s_b);
         if (st != XFR_OK) { const std::string why = g_err; join(); g_err = why; return st; }
         launch_cnhw_to_nchw(e->T(tensor_id), out_dev + (size_t)n0 * t.per_n(), n - n0, t.C, t.HW(), e->s_b);
         st = join();
@@ -2684,6 +2788,59 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     }
     e->cur_slot = 0;
     return prof_end(e, s);
+}
+
+xfr_status xfr_engine_set_u8_preprocess(xfr_engine* e, const xfr_u8_preprocess* p)
+{
+    if (!e || !p) return fail(XFR_INVALID_ARG, "null argument");
+    if (p->kind == XFR_U8_SUB_MEAN) {
+        if (p->channels != e->in_c || p->channels > 4) return fail(XFR_INVALID_ARG, "uint8 preprocessing: %d image channels for a %d-channel network input", p->channels, e->in_c);
+    } else if (p->kind == XFR_U8_LUMINANCE) {
+        if (p->channels != 3 || e->in_c != 1) return fail(XFR_INVALID_ARG, "uint8 luminance preprocessing takes 3-channel images into a 1-channel network input");
+    } else return fail(XFR_INVALID_ARG, "unknown uint8 preprocessing kind %d", p->kind);
+    e->u8_pre.kind = p->kind;
+    e->u8_pre.channels = p->channels;
+    for (int i = 0; i < 4; ++i) { e->u8_pre.mean[i] = p->mean[i]; e->u8_pre.weight[i] = p->weight[i]; }
+    e->u8_set = true;
+    e->held_x = nullptr;
+    return XFR_OK;
+}
+
+namespace {
+struct U8Guard { xfr_engine* e; explicit U8Guard(xfr_engine* e_) : e(e_) { e->u8_on = true; } ~U8Guard() { e->u8_on = false; } };
+}
+
+xfr_status xfr_forward_u8(xfr_engine* e, const uint8_t* x_u8_dev, int32_t n, int32_t tensor_id, float* out_dev, void* stream)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    if (!e->u8_set) return fail(XFR_STATE_ERROR, "xfr_engine_set_u8_preprocess has not been called");
+    U8Guard g(e);
+    return xfr_forward(e, reinterpret_cast<const float*>(x_u8_dev), n, tensor_id, out_dev, stream);
+}
+
+xfr_status xfr_triplet_contrastive_u8(xfr_engine* e, const uint8_t* probes_u8_dev, const uint8_t* gallery_u8_dev, int32_t n, int32_t encode_tensor, float scale,
+                                      float percentile, float* sal_dev, void* stream, int32_t inputs_ready)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    if (!e->u8_set) return fail(XFR_STATE_ERROR, "xfr_engine_set_u8_preprocess has not been called");
+    U8Guard g(e);
+    return xfr_triplet_contrastive(e, reinterpret_cast<const float*>(probes_u8_dev), reinterpret_cast<const float*>(gallery_u8_dev), n, encode_tensor, scale,
+                                   percentile, sal_dev, stream, inputs_ready);
+}
+
+xfr_status xfr_debug_u8_preprocess(xfr_engine* e, const uint8_t* x_u8_dev, int32_t n, float* out_nchw_dev, void* stream)
+{
+    if (!e || !x_u8_dev || !out_nchw_dev) return fail(XFR_INVALID_ARG, "null argument");
+    if (!e->u8_set) return fail(XFR_STATE_ERROR, "xfr_engine_set_u8_preprocess has not been called");
+    if (n < 1 || n > e->max_batch) return fail(XFR_INVALID_ARG, "batch %d outside [1, %d]", n, e->max_batch);
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const Tensor& in = e->tens[0];
+    launch_u8hwc_to_cnhw(x_u8_dev, e->T(0), n, in.C, in.HW(), e->u8_pre, s);
+    launch_cnhw_to_nchw(e->T(0), out_nchw_dev, n, in.C, in.HW(), s);
+    HIP_TRY(hipGetLastError());
+    e->held_x = nullptr;
+    return fence_slot0(e, s);
 }
 
 xfr_status xfr_engine_set_epilogue_fusion(xfr_engine* e, int32_t enable)

@@ -186,6 +186,61 @@ class Engine(object):
                                                         1 if inputs_ready else 0))
         return sal
 
+    # -- uint8 inputs (include/xfr_amd.h: xfr_forward_u8 / xfr_triplet_contrastive_u8) ---------------------------------
+    def set_u8_preprocess(self, kind, channels=3, mean=None, weight=None):
+        """kind 'sub_mean' (mean per channel; ResNet-101 / ResNet-50-128d) or 'luminance' (weights per channel of value / 255; Light-CNN)."""
+        p = _lib.U8Preprocess()
+        p.kind = {'sub_mean': 0, 'luminance': 1}[kind]
+        p.channels = int(channels)
+        for i, v in enumerate(mean or ()):
+            p.mean[i] = float(v)
+        for i, v in enumerate(weight or ()):
+            p.weight[i] = float(v)
+        _lib.check(self.lib.xfr_engine_set_u8_preprocess(self._h, ctypes.byref(p)))
+        self._u8_channels = int(channels)
+        self.options['u8_preprocess'] = (kind, int(channels), tuple(mean or ()), tuple(weight or ()))
+
+    def _prep_u8(self, x):
+        """uint8 N x H x W x C (as decoded) -> (device tensor, fresh); see _prep."""
+        c, h, w = self.program.in_shape
+        if x.dtype != torch.uint8 or x.dim() != 4 or tuple(x.shape[1:]) != (h, w, getattr(self, '_u8_channels', 3)):
+            raise ValueError('expected uint8 images N x %d x %d x %d, got %s %s' % (h, w, getattr(self, '_u8_channels', 3), x.dtype, tuple(x.shape)))
+        if x.shape[0] > self.max_batch:
+            raise ValueError('batch %d exceeds the engine max_batch %d' % (x.shape[0], self.max_batch))
+        y = x.detach().to(self.device, non_blocking=True).contiguous()
+        return y, (not x.is_cuda) or y.data_ptr() != x.data_ptr()
+
+    def preprocess_u8(self, x):
+        """The fp32 network input (N x C x H x W) the uint8 path builds: parity hook for the reference's preprocess functions."""
+        x, _ = self._prep_u8(x)
+        out = torch.empty((x.shape[0],) + tuple(self.program.in_shape), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_debug_u8_preprocess(self._h, x.data_ptr(), x.shape[0], out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def forward_u8(self, x, tensor_id):
+        x, _ = self._prep_u8(x)
+        c, h, w = self.tensor_shape(tensor_id)
+        out = torch.empty((x.shape[0], c, h, w), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_forward_u8(self._h, x.data_ptr(), x.shape[0], int(tensor_id), out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def triplet_contrastive_u8(self, probes, gallery, encode_tensor, scale=1.0 / 2500.0, percentile=None, inputs_ready=False):
+        """triplet_contrastive on uint8 N x H x W x C probes and 2N gallery images (mates then non-mates)."""
+        probes, f1 = self._prep_u8(probes)
+        gallery, f2 = self._prep_u8(gallery)
+        n = probes.shape[0]
+        if gallery.shape[0] != 2 * n:
+            raise ValueError('gallery must hold %d images, got %d' % (2 * n, gallery.shape[0]))
+        c1, h1, w1 = self.tensor_shape(1)
+        sal = torch.empty((n, h1, w1), device=self.device)
+        pct = -1.0 if percentile is None else float(percentile)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_triplet_contrastive_u8(self._h, probes.data_ptr(), gallery.data_ptr(), n, int(encode_tensor), float(scale), pct,
+                                                           sal.data_ptr(), _stream_ptr(self.device), 1 if (inputs_ready and not f1 and not f2) else 0))
+        return sal
+
     def set_pipeline(self, on):
         """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
         _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call; | 4: three forward slots
@@ -235,6 +290,9 @@ class Engine(object):
             self.set_forward_split(options['forward_split'])
         if 'lean' in options:
             self.set_lean(options['lean'])
+        if 'u8_preprocess' in options:
+            k, c, m, w = options['u8_preprocess']
+            self.set_u8_preprocess(k, c, m, w)
         if 'epilogue_fusion' in options:
             self.set_epilogue_fusion(options['epilogue_fusion'])
         if options.get('pipeline'):

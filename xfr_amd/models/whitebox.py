@@ -21,7 +21,7 @@ import torch
 
 from ..engine import Engine
 from .lightcnn import lightcnn_preprocess
-from .resnet import convert_resnet101v4_image
+from .resnet import MEAN_RGB, convert_resnet101v4_image
 
 
 def _is_dataframe(obj):
@@ -70,6 +70,9 @@ class WhiteboxNetwork(object):
             self._program = self.net.build_program()
             self._engine = Engine(self._program, want, dev)
             self._engine.apply_options(options)
+            spec = self.u8_preprocess_spec()
+            if spec is not None:
+                self._engine.set_u8_preprocess(*spec)
             self._engine_key = key
         if self._engine.loaded_version != self.net.version:
             self._engine.load_weights(self.net.state_dict())
@@ -79,6 +82,17 @@ class WhiteboxNetwork(object):
     def _mark(self, name):
         self.engine()
         return self._program.marks[name]
+
+    def u8_preprocess_spec(self):
+        """(kind, channels, mean, weight) of the pixel arithmetic in `preprocess` for the engine's uint8 entry points (xfr_forward_u8), or None."""
+        return None
+
+    def encode_u8(self, images_u8):
+        """Additive: encode() on uint8 N x H x W x C crops (already resized / cropped like `preprocess` does it): the images travel to the device as
+        uint8 and the engine applies the pixel arithmetic of `preprocess` itself, bit for bit (include/xfr_amd.h)."""
+        x = torch.as_tensor(images_u8)
+        eng = self.engine(x.shape[0])
+        return eng.forward_u8(x, self._mark('encode')).reshape(x.shape[0], -1)
 
     def _cls_weight(self, device):
         return self._classifier.weight.to(device)
@@ -144,6 +158,9 @@ class WhiteboxSTResnet(WhiteboxNetwork):
     def preprocess(self, im):
         return convert_resnet101v4_image(im.resize((224, 224))).unsqueeze(0)
 
+    def u8_preprocess_spec(self):
+        return ('sub_mean', 3, tuple(float(v) for v in MEAN_RGB), None)            # resnet.py:23-37
+
 
 class WhiteboxLightCNN(WhiteboxNetwork):
     """whitebox.py:113-159"""
@@ -163,6 +180,9 @@ class WhiteboxLightCNN(WhiteboxNetwork):
 
     def preprocess(self, im):
         return self.f_preprocess(im)
+
+    def u8_preprocess_spec(self):
+        return ('luminance', 3, None, (0.2125, 0.7154, 0.0721))                        # lightcnn.py:19-25 (skimage rgb2gray)
 
 
 class Whitebox_resnet50_128(WhiteboxNetwork):
@@ -199,6 +219,9 @@ class Whitebox_resnet50_128(WhiteboxNetwork):
         x = x[h_start:h_start + crop_size[0], w_start:w_start + crop_size[1]]
         x = x - mean
         return torch.from_numpy(x.transpose(2, 0, 1).astype(np.float32)).unsqueeze(0)
+
+    def u8_preprocess_spec(self):
+        return ('sub_mean', 3, (131.0912, 103.8827, 91.4953), None)                    # whitebox.py:238,256
 
 
 class _PList(object):
@@ -399,6 +422,14 @@ class Whitebox(object):
         if gallery is None:       # [mates; non-mates] as one 2N-image batch (pass `gallery` to avoid the copy)
             gallery = torch.cat((img_mates.to(eng.device), img_nonmates.to(eng.device)), dim=0)
         return eng.triplet_contrastive(img_probes, gallery, self.net._program.marks['encode'], scale, percentile, inputs_ready)
+
+    def triplet_images_ebp_batch_u8(self, probes_u8, mates_u8, nonmates_u8, scale=1.0 / 2500.0, percentile=None, inputs_ready=False):
+        """triplet_images_ebp_batch on uint8 N x H x W x C crops: a quarter of the input bytes cross the bus, the engine preprocesses."""
+        n = probes_u8.shape[0]
+        self.net.default_max_batch = max(self.net.default_max_batch, 2 * n)
+        eng = self._engine(2 * n)
+        gallery = torch.cat((torch.as_tensor(mates_u8).to(eng.device), torch.as_tensor(nonmates_u8).to(eng.device)), dim=0)
+        return eng.triplet_contrastive_u8(torch.as_tensor(probes_u8), gallery, self.net._program.marks['encode'], scale, percentile, inputs_ready)
 
     def layerwise_ebp(self, img_probe, k_layer, mode='argmax', k_element=None, k_poschannel=0, mwp=True):
         """Layerwise excitation backprop (whitebox.py:561-581): a standard EBP sweep picks the starting node of layer

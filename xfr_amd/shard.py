@@ -50,6 +50,7 @@ class Comm(object):
         import datetime
         self.rank, self.world, self.local = dist_env()
         self.timeout_s = float(timeout_s if timeout_s is not None else os.environ.get('XFR_DIST_TIMEOUT', '180'))
+        self.op_timeout_s = 0.4 * self.timeout_s
         self.store = None
         self.collective_ok = False
         self.init_error = None
@@ -61,6 +62,10 @@ class Comm(object):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         td = datetime.timedelta(seconds=self.timeout_s)
+        # a collective may use up 40 % of the budget before it gives up; the store waits (reports, votes, barriers) get all of it, so that a rank which
+        # arrives at a vote only after its collective has timed out is still waited for
+        self.op_timeout_s = 0.4 * self.timeout_s
+        td_op = datetime.timedelta(seconds=self.op_timeout_s)
         self.store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']) + 17, self.world, self.rank == 0, timeout=td)
         try:
             if os.environ.get('XFR_TEST_FAIL_INIT') == '1':
@@ -70,7 +75,7 @@ class Comm(object):
             if backend == 'nccl':
                 torch.cuda.set_device(self.local)
             if not dist.is_initialized():
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, timeout=td)
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, timeout=td_op)
             self.collective_ok = True
         except Exception as ex:        # noqa: BLE001 -- whatever the backend throws: the ranks go on over the store
             self.init_error = repr(ex)
@@ -78,26 +83,27 @@ class Comm(object):
         self.collective_ok = self.agree(self.collective_ok)
 
     # -- the store channel ---------------------------------------------------------------------------------------------------
-    def gather_objects(self, obj, tag, fail_fast=True):
+    def gather_objects(self, obj, tag, fail_fast=True, wait_s=None):
         """[obj of rank 0, ..., obj of rank world-1] on every rank (JSON through the store); a missing rank yields {'missing_rank': r}."""
         import json
         if self.world == 1:
             return [obj]
-        import datetime
         import time
         self.store.set('%s/%d' % (tag, self.rank), json.dumps(obj))
         out = []
         for r in range(self.world):
             key, t0, val = '%s/%d' % (tag, r), time.time(), None
             while val is None:
-                try:
-                    self.store.wait([key], datetime.timedelta(milliseconds=100))
+                # (store.check polls without blocking and without the warning c10d prints for every timed-out wait: a waiting rank must stay quiet)
+                if self.store.check([key]):
                     val = json.loads(self.store.get(key).decode())
-                except Exception as ex:    # noqa: BLE001 -- not there yet: has that rank reported an exception instead?
-                    if fail_fast and r != self.rank and self.store.check(['error/%d' % r]):
-                        raise RuntimeError('rank(s) [%d] failed: %s' % (r, self.store.get('error/%d' % r).decode().strip().splitlines()[-1]))
-                    if time.time() - t0 > self.timeout_s:
-                        val = {'missing_rank': r, 'error': repr(ex)}
+                    break
+                if fail_fast and r != self.rank and self.store.check(['error/%d' % r]):
+                    raise RuntimeError('rank(s) [%d] failed: %s' % (r, self.store.get('error/%d' % r).decode().strip().splitlines()[-1]))
+                if time.time() - t0 > (wait_s if wait_s is not None else self.timeout_s):
+                    val = {'missing_rank': r, 'error': 'no %s from rank %d within %.0f s' % (tag, r, wait_s if wait_s is not None else self.timeout_s)}
+                    break
+                time.sleep(0.002)
             out.append(val)
         return out
 
@@ -188,7 +194,7 @@ class Comm(object):
                 arena = engine.weight_arena()
                 work = dist.broadcast(arena, src=src, async_op=True)
                 import datetime
-                work.wait(datetime.timedelta(seconds=self.timeout_s))
+                work.wait(datetime.timedelta(seconds=self.op_timeout_s))
                 if arena.is_cuda:
                     torch.cuda.synchronize()
             except Exception as ex:    # noqa: BLE001
