@@ -577,6 +577,45 @@ class OracleWhitebox(object):
             raise ValueError('invalid layerwise EBP mode "%s"' % mode)
         return self.ebp(x, 0.0 * P0, mwp=mwp, priors={int(k_layer): prior})
 
+    def layerwise_contrastive_ebp(self, x, k_poschannel, k_negchannel, k_layer, mode='copy', percentile=80, k_element=None, gradlayer=None, mwp=False):
+        """whitebox.py:584-645 (deprecated there; restated for completeness)."""
+        self.ebp(x, self._onehot(x, k_poschannel))
+        P_mate = self.P
+        P0 = self._onehot(x, k_negchannel)
+        self.ebp(x, P0)
+        P_nonmate = self.P
+        Pm, Pn = P_mate[k_layer], P_nonmate[k_layer]
+        C = F.relu(Pm - Pn)
+        argmax = lambda t: torch.mul(t, 1.0 - torch.ne(t, torch.max(t)).type(torch.FloatTensor))          # noqa: E731
+        product = lambda: torch.sqrt(torch.mul(Pm.type(torch.DoubleTensor), C.type(torch.DoubleTensor))).type(torch.FloatTensor)     # noqa: E731
+        if mode == 'copy':
+            prior = C
+        elif mode == 'mean':
+            prior = 0.5 * (Pm + C)
+        elif mode == 'product':
+            prior = product()
+        elif mode == 'argmax':
+            prior = argmax(C)
+        elif mode == 'argmax_product':
+            prior = argmax(product())
+        elif mode == 'percentile' or mode == 'percentile_argmax':
+            (srt, idx) = torch.sort(torch.flatten(Pm.clone()))
+            cs = torch.cumsum(srt, 0)
+            mask = torch.zeros(srt.shape)
+            mask[idx] = (cs >= (percentile / 100.0) * cs[-1]).type(torch.FloatTensor)
+            prior = torch.mul(mask.reshape(Pm.shape), C.type(torch.FloatTensor)).clone()
+            if mode == 'percentile_argmax':
+                prior = argmax(prior)
+        elif mode == 'elementwise':
+            assert gradlayer[k_layer].shape == Pm.shape
+            Pf = (0 * C.detach().clone()).flatten()
+            Pf[k_element] = C.flatten()[k_element]
+            prior = Pf.reshape(C.shape)
+        else:
+            raise ValueError('unknown contrastive ebp mode "%s"' % mode)
+        k = int(k_layer) if int(k_layer) >= 0 else int(k_layer) + len(P_mate)
+        return self.ebp(x, 0.0 * P0, mwp=mwp, priors={k: prior})
+
     def weighted_subtree_ebp(self, x, k_poschannel, k_negchannel, topk=1, do_max_subtree=False,
                              do_mated_similarity_gating=True, subtree_mode='norelu', do_mwp_to_saliency=True):
         """whitebox.py:647-737."""

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect one round's rocprofv3 evidence for bench.py on the GPU box (run from the repo root, e.g. through gpurun):
-#   bash profiles/collect.sh r4      -> gpurun_out/prof_r4/..., summaries copied to profiles/r4/
+#   bash profiles/collect.sh r5      -> gpurun_out/prof_r5/..., summaries copied to profiles/r5/
 # Counters are collected in their own passes (--pmc never together with a trace domain other than the kernel trace).
 # Every BASELINE.json single-GPU configuration gets the same set: resnet101 (no suffix), resnet50_128 (_r50), lightcnn (_lcnn).
 set -u
-R=${1:-r4}
+R=${1:-r5}
 D=gpurun_out/prof_$R
 P=profiles/$R
 export TMPDIR=/tmp
@@ -34,7 +34,7 @@ for spec in $SPECS; do
   # the same launches timed by the kernels themselves (first GEMM of a step included correctly)
   python profiles/layer_table.py $D/launchlog$T.csv > $P/gemm_layers_inkernel$T.txt
   # the plain bench line (timed three-stream schedule, launch-log roofline, clock, CPU baseline) + the timeline it came from
-  $B --no-secondary --timeline-json $P/gemm_timeline$T.json > $P/bench_default$T.json 2> $D/bench_default$T.err
+  $B --no-secondary --timeline-json $P/gemm_timeline$T.json --launch-log-out $P/launch_log$T.csv > $P/bench_default$T.json 2> $D/bench_default$T.err
 done
 if [ -n "${2:-}" ]; then
   python bench.py > $P/bench_driver_line.json 2> $D/bench_driver_line.err
@@ -66,9 +66,21 @@ python tools/pair_probe.py 2> /dev/null | grep -v amdgpu > $P/pair_probe.txt
 for b in 32 64 96; do python bench.py --batch $b --steps 20 --warmup 4 --no-cpu-baseline --no-sustained --no-secondary 2> /dev/null; done > $P/bench_batch_sweep.jsonl
 python tools/embeddings_sweep.py --masks 6500 > $P/embeddings_sweep.json 2> /dev/null
 python tools/embeddings_sweep.py --masks 6500 --no-split > $P/embeddings_sweep_nosplit.json 2> /dev/null
+# round 5: the raw launch log of the timed schedule -> frac, recomputed without repo code; the lean schedule against the literal one on this box;
+# BASELINE.json configs[4] (job mix) and its dominant method under the profiler
+python profiles/frac_from_launch_log.py $P/launch_log.csv --alg-gflop 2768.4 > $P/frac_from_launch_log.txt 2>&1
+python profiles/frac_from_launch_log.py $P/launch_log_r50.csv --alg-gflop 2961.4 >> $P/frac_from_launch_log.txt 2>&1
+for rep in 1 2; do for m in resnet101 resnet50_128; do for f in "" "--no-lean"; do
+  python bench.py --model $m $f --no-cpu-baseline --no-secondary --no-sustained --no-profile --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m [$f]', round(d['value'],1), 'maps/s', round(d['ms_per_step'],3), 'ms')"
+done; done; done > $P/lean_ab.txt
+python bench.py --inpainting-game > $P/bench_inpainting_game.json 2> /dev/null
+python tools/subtree_probe.py --log 2> /dev/null | grep -v amdgpu > $P/weighted_subtree_probe.txt
+rocprofv3 $ST -d $D/subtree -o $R -- python tools/subtree_probe.py --reps 5 > /dev/null 2> $D/subtree.err
+cp $D/subtree/${R}_kernel_stats.csv $P/kernel_stats_weighted_subtree.csv
+rm -f $D/subtree/${R}_kernel_trace.csv
 # the line the driver sees: the default command, secondary configurations and whole-host CPU figure included
 python bench.py > $P/bench_driver_line.json 2> $D/bench_driver_line.err
-python tools/conv_sweep.py --cfgs 4,5,7,9 --reps 100 --set r101 2> /dev/null | grep -v amdgpu > $P/conv_sweep.txt
+python tools/conv_sweep.py --cfgs 4,5,7 --reps 100 --set r101 2> /dev/null | grep -v amdgpu > $P/conv_sweep.txt
 python tools/conv_sweep.py --cfgs 4,7 --reps 100 --set lcnn --nb 128 2> /dev/null | grep -v amdgpu >> $P/conv_sweep.txt
 mkdir -p gpurun_out/$P && cp -r $P/. gpurun_out/$P/
 echo "collected: $(ls $P | tr '\n' ' ')"

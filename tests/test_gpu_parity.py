@@ -320,6 +320,18 @@ def test_with_bias_mode_vs_oracle(gpu_device):
     wb2 = WB.Whitebox(wb.net, ebp_subtree_mode='all', with_bias=False)
     other = wb2.ebp(x, Pn, mwp=True)
     assert np.abs(other - got).max() > 1e-6 * np.abs(got).max()
+    # the lean schedule under with_bias (its dual-accumulator epilogue adds relu(bias) to the relu(W) tile, relu(beta) in the ReLU quotient): a batch
+    # of four copies, un-traced, against the oracle and against the literal schedule
+    wb.debug_trace = False
+    eng = wb._engine(4)
+    before = eng.lean_launches()
+    lean = wb.ebp(x.repeat(4, 1, 1, 1), Pn, mwp=True)
+    assert eng.lean_launches() > before
+    assert_map_close_robust(lean[0], want, 'with_bias ebp, lean')
+    eng.set_lean(False)
+    lit = wb.ebp(x.repeat(4, 1, 1, 1), Pn, mwp=True)
+    eng.set_lean(True)
+    assert_map_close(lean[0], lit[0], 'with_bias lean vs literal', rtol=1e-5)
 
 
 def test_truncation_tail_equals_reference_formula_on_engine_P(gpu_device):

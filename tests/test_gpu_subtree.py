@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import golden_cases as GC
-from parity_utils import assert_map_close, assert_map_close_robust, make_backbone, make_images
+from parity_utils import assert_map_close, assert_map_close_robust, make_backbone, make_images, map_metrics
 from xfr_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -217,3 +217,41 @@ def test_embeddings_sweep_tool(gpu_device):
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert res['masks'] == 48 and res['images_per_s'] > 0 and -1.0 <= res['mean_similarity'] <= 1.0
+
+
+@pytest.mark.parametrize('sub', ['norelu', 'affineonly_with_prior'])
+def test_layerwise_contrastive_ebp_golden(gpu_device, sub):
+    """layerwise_contrastive_ebp (whitebox.py:584-645; deprecated there, kept for drop-in completeness): every mode on three layers of the mini
+    ResNet against the maps of the real reference (tests/golden/make_golden_lwc.py).  The prior is a CONTRAST of two MWP tensors of one layer:
+    dense modes are held to the contrastive tolerance; the one-element modes (argmax, elementwise, ...) pick an element, and their whole map
+    scales with that element's contrast -- compared by direction (cosine) and to 2 % in scale."""
+    import warnings
+    g = GC.golden('golden_lwc_mini')
+    bb, sd = make_backbone('stresnet_mini', seed=3, recipe='mild', num_classes=5)
+    subj = GC.engine_subject('stresnet_mini', bb, sub)
+    subj.wb.debug_trace = False
+    subj.set_cls(synth.unit_rows(1, 512, seed=1) / 2500, synth.unit_rows(1, 512, seed=2) / 2500)
+    x = make_images('stresnet_mini', 1, seed=5)
+    P0 = torch.zeros((1, 2))
+    P0[0][0] = 1.0
+    subj.wb.ebp(x, P0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for k in [int(v) for v in g['mini/%s/layers' % sub]]:
+            kel = int(g['mini/%s/k_element_%d' % (sub, k)])
+            Pk = subj.wb.P[k]
+            grad = {k: Pk}
+            for mode in ('copy', 'mean', 'product', 'argmax', 'argmax_product', 'percentile', 'percentile_argmax', 'elementwise'):
+                want = g['mini/%s/%s_%d' % (sub, mode, k)]
+                got = subj.wb.layerwise_contrastive_ebp(x, 0, 1, k_layer=k, mode=mode, percentile=80, k_element=kel, gradlayer=grad, mwp=True)
+                assert got.shape == want.shape and np.isfinite(got).all(), (mode, k)
+                if np.abs(want).max() == 0:
+                    assert np.abs(got).max() <= 1e-12, (mode, k)
+                    continue
+                rel, cos = map_metrics(got, want)
+                if mode in ('copy', 'mean', 'product', 'percentile'):
+                    assert cos >= 0.9999 and rel <= 2e-2, (sub, mode, k, rel, cos)
+                else:
+                    scale = float(np.abs(got).max() / np.abs(want).max())
+                    assert cos >= 0.9999 and abs(scale - 1.0) <= 2e-2, (sub, mode, k, scale, cos)
+

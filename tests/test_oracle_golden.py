@@ -99,3 +99,27 @@ def test_well_conditioned_contrastive(arch, tag, mode, nc):
     bb, sd = make_backbone(arch, seed=0, num_classes=nc)
     assert synth.state_checksum(sd) == str(gold[tag + '/wsum'])
     GC.replay(GC.oracle_subject(arch, sd, mode), GC.synth_cases(arch, tag, mode), gold, check)
+
+
+def test_layerwise_contrastive_ebp_mini():
+    """whitebox.py:584-645 (deprecated by the reference; restated for completeness): every mode on three layers, against the reference's maps."""
+    import warnings
+    torch.set_num_threads(8)
+    from oracle import ebp_oracle as O
+    from parity_utils import make_images
+    g = GC.golden('golden_lwc_mini')
+    bb, sd = make_backbone('stresnet_mini', seed=3, recipe='mild', num_classes=5)
+    x = make_images('stresnet_mini', 1, seed=5)
+    ow = O.OracleWhitebox('stresnet_mini', sd, ('hooked', None), 'norelu')
+    ow.set_triplet_classifier(synth.unit_rows(1, 512, seed=1) / 2500, synth.unit_rows(1, 512, seed=2) / 2500)
+    ow.ebp(x, ow._onehot(x, 0))
+    shapes = [p for p in ow.P]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for k in [int(v) for v in g['mini/norelu/layers']]:
+            kel = int(g['mini/norelu/k_element_%d' % k])
+            for mode in ('copy', 'mean', 'product', 'argmax', 'argmax_product', 'percentile', 'percentile_argmax', 'elementwise'):
+                got = ow.layerwise_contrastive_ebp(x, 0, 1, k_layer=k, mode=mode, percentile=80, k_element=kel, gradlayer=shapes, mwp=True)
+                want = g['mini/norelu/%s_%d' % (mode, k)]
+                assert np.abs(np.asarray(got) - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-30), (mode, k)
+

@@ -466,6 +466,68 @@ class Whitebox(object):
         P = np.squeeze(pooled[0].cpu().numpy()).astype(np.float32)
         return self._mwp_to_saliency(P) if not mwp else P
 
+    @staticmethod
+    def _contrastive_prior(P_mate, P_nonmate, mode, percentile=80, k_element=None):
+        """The prior tensor layerwise_contrastive_ebp installs at its layer (whitebox.py:605-643), from the two MWP tensors of that layer."""
+        import torch.nn.functional as F
+        Pm, Pn = P_mate.detach().cpu().float(), P_nonmate.detach().cpu().float()
+        C = F.relu(Pm - Pn)
+        argmax = lambda t: torch.mul(t, 1.0 - torch.ne(t, torch.max(t)).type(torch.FloatTensor))          # noqa: E731
+        product = lambda: torch.sqrt(torch.mul(Pm.type(torch.DoubleTensor), C.type(torch.DoubleTensor))).type(torch.FloatTensor)     # noqa: E731
+        if mode == 'copy':
+            return C
+        if mode == 'mean':
+            return 0.5 * (Pm + C)
+        if mode == 'product':
+            return product()
+        if mode == 'argmax':
+            return argmax(C)
+        if mode == 'argmax_product':
+            return argmax(product())
+        if mode in ('percentile', 'percentile_argmax'):
+            assert (percentile >= 0 and percentile <= 100)
+            (Pn_sorted, idx) = torch.sort(torch.flatten(Pm.clone()))
+            cs = torch.cumsum(Pn_sorted, 0)
+            mask = torch.zeros(Pn_sorted.shape)
+            mask[idx] = (cs >= (percentile / 100.0) * cs[-1]).type(torch.FloatTensor)
+            prior = torch.mul(mask.reshape(Pm.shape), C.type(torch.FloatTensor)).clone()
+            return argmax(prior) if mode == 'percentile_argmax' else prior
+        if mode == 'elementwise':
+            P = (0 * C.detach().clone()).flatten()
+            P[k_element] = C.flatten()[k_element]
+            return P.reshape(C.shape)
+        raise ValueError('unknown contrastive ebp mode "%s"' % mode)
+
+    def layerwise_contrastive_ebp(self, img_probe, k_poschannel, k_negchannel, k_layer, mode='copy', percentile=80, k_element=None, gradlayer=None,
+                                  mwp=False):
+        """Layerwise contrastive excitation backprop (whitebox.py:584-645; deprecated by the reference in favour of weighted_subtree_ebp, kept for
+        drop-in completeness): the MWP tensors of layer `k_layer` under the two one-hot seeds (two sweeps that store that firing), a prior built from
+        them on the host (`_contrastive_prior`: the reference's expressions), and a zero-seeded sweep that propagates only the prior."""
+        warnings.warn("layerwise_contrastive_ebp is deprecated, use weighted_subtree_ebp instead")
+        assert (k_poschannel >= 0 and k_poschannel < self.net.num_classes())
+        assert (k_negchannel >= 0 and k_negchannel < self.net.num_classes())
+        assert img_probe.shape[0] == 1
+        eng = self._engine(1)
+        seed_tensor, seeds = self._class_seeds(1, k_poschannel, k_negchannel)
+        nf = eng.firing_count(seed_tensor)
+        k = int(k_layer)
+        if k < 0:
+            k += nf + 1
+        if not (0 <= k <= nf):
+            raise IndexError('list index out of range')
+        Pm = eng.ebp_firing(img_probe, seed_tensor, seeds[0:1], k)
+        Pn = eng.ebp_firing(img_probe, seed_tensor, seeds[1:2], k)
+        if mode == 'elementwise':
+            assert (tuple(gradlayer[k_layer].shape) == tuple(Pm.shape))
+        prior = self._contrastive_prior(Pm, Pn, mode, percentile, k_element)
+        if k == nf:      # a prior at the image hook fires after P[-2] has been recorded: nothing reaches it (see layerwise_ebp)
+            c1, h1, w1 = eng.tensor_shape(1)
+            P = np.zeros((h1, w1), dtype=np.float32)
+        else:
+            pooled = eng.layerwise(img_probe, seed_tensor, [k], dense_prior=prior[0])
+            P = np.squeeze(pooled[0].cpu().numpy()).astype(np.float32)
+        return self._mwp_to_saliency(P) if not mwp else P
+
     def weighted_subtree_ebp(self, img_probe, k_poschannel, k_negchannel, topk=1, verbose=True, do_max_subtree=False,
                              do_mated_similarity_gating=True, subtree_mode='norelu', do_mwp_to_saliency=True, sweep_batch=None):
         """Weighted subtree EBP (whitebox.py:647-737).  Same result as the reference, computed with: one true-weight
