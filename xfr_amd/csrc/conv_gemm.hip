@@ -1149,6 +1149,21 @@ int pick_tail_split(const ConvParams& p, int tiles, int nk, size_t tile_bytes)
     return bestS;
 }
 
+// An interpreted epilogue on the product path is a performance cliff (round 5: a one-step chain without a signature ran its GEMMs at 4 TFLOP/s for a
+// whole round before a profile showed it): say so once per process, with the signature the generator should have listed.
+void warn_interpreted(const ConvParams& q)
+{
+    static std::atomic<int> said{0};
+    if (q.chain_interpret || getenv("XFR_QUIET") || said.exchange(1)) return;
+    uint16_t codes[XFR_MAX_EW_STEPS];
+    const int n = ew_chain_codes(q.chain, codes);
+    fprintf(stderr, "xfr_amd: a GEMM launch (Cout %d, K %d, M %d) runs its %d-step fused chain through the INTERPRETED epilogue: no compiled signature [", q.CoutTot, q.K, q.M, q.chain.n);
+    for (int i = 0; i < n; ++i) fprintf(stderr, "%s%04x", i ? " " : "", codes[i]);
+    fprintf(stderr, "]%s.  Regenerate the table (python tools/gen_chain_sigs.py && make -C xfr_amd/csrc) if this network is a supported backbone; "
+                    "xfr_chain_epilogue_stats counts such launches.  (said once; XFR_QUIET=1 silences it)\n",
+            n < 0 ? " (the chain carries a trace / prior / capture: interpreted by design)" : (q.accumulate ? " for an accumulating launch" : ""));
+}
+
 // Chain of a launch: operand prefetch plan, compiled signature.  Returns 0, or why the launch cannot carry its chain (conv_gemm_refusal).
 int plan_chain(ConvParams& q)
 {
@@ -1191,6 +1206,7 @@ bool launch_one(const ConvParams& p, hipStream_t s)
         if (q.chain.n > 0) {      // fused micro-program (no relu_in)
             if (plan_chain(q)) return false;
             g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
+            if (q.chain_sig < 0) warn_interpreted(q);
             if constexpr (TCO == 64 && MODE != MODE_TAP4 && MODE != MODE_GEN) {
                 if (q.dualacc) {
                     hipLaunchKernelGGL((conv_gemm_kernel<TCO, TM, BK, NST, MODE, false, 4>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
@@ -1240,6 +1256,7 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
     if (q.chain.n > 0) {
         if (plan_chain(q)) return false;
         g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
+        if (q.chain_sig < 0) warn_interpreted(q);
         if (q.dualacc) {
             hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 4>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
             return true;

@@ -517,6 +517,8 @@ class Whitebox(object):
             raise IndexError('list index out of range')
         Pm = eng.ebp_firing(img_probe, seed_tensor, seeds[0:1], k)
         Pn = eng.ebp_firing(img_probe, seed_tensor, seeds[1:2], k)
+        if k < nf and (self._layernames(seed_tensor)[k].startswith('Linear(') or (Pm.shape[2] == 1 and Pm.shape[3] == 1)):
+            Pm, Pn = Pm.reshape(1, -1), Pn.reshape(1, -1)            # the reference's P of a flattened layer is N x D (see _PList)
         if mode == 'elementwise':
             assert (tuple(gradlayer[k_layer].shape) == tuple(Pm.shape))
         prior = self._contrastive_prior(Pm, Pn, mode, percentile, k_element)
