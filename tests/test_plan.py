@@ -212,17 +212,17 @@ def test_comm_entry_points_check_arguments():
 # average-pool shortcut rewrite (pass 2b), 131 = without the projection-shortcut side branch (3c), 259 = the shortcut in program order (forward side
 # only: the sweep is the default's), 0 = no fusion into GEMM epilogues at all (copy forwarding, the pool pair and chain -> chain merges remain).
 FUSION_TABLE = [
-    ('stresnet101', 'affineonly_with_prior', None, 377, 110, 321, 100, 7, 0, 41),
-    ('stresnet101', 'norelu', None, 377, 110, 321, 100, 7, 0, 41),
-    ('resnet50_128', 'affineonly_with_prior', None, 157, 60, 161, 53, 5, 0, 27),
-    ('resnet50_128', 'norelu', None, 157, 60, 161, 53, 5, 0, 27),
+    ('stresnet101', 'affineonly_with_prior', None, 377, 110, 321, 100, 7, 0, 48),
+    ('stresnet101', 'norelu', None, 377, 110, 321, 100, 7, 0, 48),
+    ('resnet50_128', 'affineonly_with_prior', None, 157, 60, 161, 53, 5, 0, 34),
+    ('resnet50_128', 'norelu', None, 157, 60, 161, 53, 5, 0, 34),
     ('lightcnn29v2', 'affineonly_with_prior', None, 86, 33, 166, 29, 4, 0, 0),
     ('lightcnn29v2', 'norelu', None, 86, 33, 166, 29, 4, 0, 0),
-    ('stresnet101', 'affineonly_with_prior', 67, 377, 120, 321, 100, 10, 4, 41),
-    ('resnet50_128', 'norelu', 67, 157, 63, 161, 53, 5, 0, 27),
-    ('stresnet101', 'norelu', 131, 377, 114, 321, 100, 11, 0, 41),
-    ('resnet50_128', 'norelu', 131, 157, 64, 161, 53, 9, 0, 27),
-    ('stresnet101', 'affineonly_with_prior', 259, 377, 110, 321, 100, 7, 0, 41),
+    ('stresnet101', 'affineonly_with_prior', 67, 377, 120, 321, 100, 10, 4, 48),
+    ('resnet50_128', 'norelu', 67, 157, 63, 161, 53, 5, 0, 34),
+    ('stresnet101', 'norelu', 131, 377, 114, 321, 100, 11, 0, 48),
+    ('resnet50_128', 'norelu', 131, 157, 64, 161, 53, 9, 0, 34),
+    ('stresnet101', 'affineonly_with_prior', 259, 377, 110, 321, 100, 7, 0, 48),
     ('stresnet101', 'affineonly_with_prior', 0, 377, 124, 321, 100, 14, 4, 0),
     ('resnet50_128', 'norelu', 0, 157, 67, 161, 53, 9, 0, 0),
     ('lightcnn29v2', 'affineonly_with_prior', 0, 86, 45, 166, 29, 8, 0, 0),

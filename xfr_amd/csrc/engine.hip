@@ -776,7 +776,9 @@ void fuse_probe_forward(xfr_engine* e, int k, int B, ConvParams& p, hipStream_t 
     // lean: every hook on the raw output is the BatchNorm's (its a and x are the two accumulators), and the call asked for it
     // (tuning: XFR_LEAN_MAX_K -- only convolutions with at most that many K rows go lean)
     const int lean_max_k = [] { const char* v = getenv("XFR_LEAN_MAX_K"); return v ? atoi(v) : 512; }();
-    bool lean = lean_try && dual && d.out != 1 && e->ops[k].Kf <= lean_max_k && e->tens[d.out].need_pv &&
+    // ... and for KxK convolutions: their two-accumulator form ties with the dual launch up to K = 1152 (measured, profiles/r5/experiments/lean_k_threshold.txt)
+    const int lean_max_k3 = [&] { const char* v = getenv("XFR_LEAN_MAX_K3"); return v ? atoi(v) : std::max(lean_max_k, 1152); }();
+    bool lean = lean_try && dual && d.out != 1 && e->ops[k].Kf <= (d.kh * d.kw > 1 ? lean_max_k3 : lean_max_k) && e->tens[d.out].need_pv &&
                 (e->lean_decide || (e->lean_cur && e->lean_cur->lean_q[d.out] == 1));
     if (lean)
         for (const Hook& h : e->tens[d.out].hooks)
