@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--topk', type=int, default=32)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--max-batch', type=int, default=128)
+    ap.add_argument('--sweep-batch', type=int, default=None, help='candidate layers per probe in the first layerwise round (default: min(2 * max_batch / n, 2 * topk))')
     ap.add_argument('--log', action='store_true', help='per-shape table of the GEMM launches of one call (in-kernel launch log)')
     args = ap.parse_args()
     import numpy as np
@@ -52,12 +53,12 @@ def main():
             T[_name][1] += 1
             return r
         setattr(eng, name, timed)
-    wb.weighted_subtree_ebp_batch(x, xm, xn, topk=args.topk)          # warm
+    wb.weighted_subtree_ebp_batch(x, xm, xn, topk=args.topk, sweep_batch=args.sweep_batch)          # warm
     T.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.reps):
-        res = wb.weighted_subtree_ebp_batch(x, xm, xn, topk=args.topk)
+        res = wb.weighted_subtree_ebp_batch(x, xm, xn, topk=args.topk, sweep_batch=args.sweep_batch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps
     out = {'probes': n, 'topk': args.topk, 'ms_per_call': 1e3 * dt, 'ms_per_probe': 1e3 * dt / n,
@@ -66,7 +67,7 @@ def main():
     out['phases_ms_per_call']['host + merge (rest)'] = round(1e3 * dt - sum(out['phases_ms_per_call'].values()), 2)
     print(json.dumps(out))
     if args.log:
-        csv = tuning.record_launch_log(lambda: wb.weighted_subtree_ebp_batch(x, xm, xn, topk=args.topk), 0, dev, launches_per_step_cap=40000)
+        csv = tuning.record_launch_log(lambda: wb.weighted_subtree_ebp_batch(x, xm, xn, topk=args.topk, sweep_batch=args.sweep_batch), 0, dev, launches_per_step_cap=40000)
         agg = collections.OrderedDict()
         for l in list(open(csv))[1:]:
             r = l.strip().split(',')

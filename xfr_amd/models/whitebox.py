@@ -593,13 +593,14 @@ class Whitebox(object):
             J = int(sweep_batch or max(1, min((2 * eng.max_batch) // n, max(8, 2 * topk))))
             pos = [nf] * n
             valid = [[] for _ in range(n)]                                      # per probe: (k, P on the device), heaviest first
+            rounds = 0
 
-            def take(b):
-                """The next (up to J) layers of probe b, heaviest first, that can yield a valid subtree.  A layer whose chosen
+            def take(b, limit):
+                """The next (up to `limit`) layers of probe b, heaviest first, that can yield a valid subtree.  A layer whose chosen
                 element has P == 0 gives an all-zero prior, hence an all-zero map (np.max(P) > 0 fails, :706): it is invalid
                 without being swept.  k == 1 is excluded by the reference (:707)."""
                 ks = []
-                while pos[b] > 0 and len(ks) < J:
+                while pos[b] > 0 and len(ks) < limit:
                     pos[b] -= 1
                     k = int(order[b][pos[b]])
                     if verbose:
@@ -609,12 +610,17 @@ class Whitebox(object):
                 return ks
 
             while any(pos[b] > 0 and len(valid[b]) < topk for b in range(n)):
-                F = -np.ones((J, n), dtype=np.int32)
-                E = np.zeros((J, n), dtype=np.int32)
-                V = np.zeros((J, n), dtype=np.float32)
+                # the first round sweeps J candidates per probe; a later round only what the probes still lack (plus a margin for sweeps that come
+                # back all-zero) -- the order of evaluation, hence the selection, is the same, the last round is a fraction of the first
+                lim = [J if rounds == 0 else min(J, 2 * (topk - len(valid[b])) + 2) for b in range(n)]
+                rounds += 1
+                Jr = max(1, max(lim[b] for b in range(n) if len(valid[b]) < topk))
+                F = -np.ones((Jr, n), dtype=np.int32)
+                E = np.zeros((Jr, n), dtype=np.int32)
+                V = np.zeros((Jr, n), dtype=np.float32)
                 todo = []
                 for b in range(n):
-                    ks = take(b) if len(valid[b]) < topk else []
+                    ks = take(b, lim[b]) if len(valid[b]) < topk else []
                     row = {k: j for j, k in enumerate(sorted(ks))}             # ascending firing: a sweep joins at its own firing
                     for k, j in row.items():
                         F[j, b], E[j, b], V[j, b] = k, idx[k, b], vals[k, b]
