@@ -635,7 +635,14 @@ class Whitebox(object):
                             valid[b].append((k, maps[row[k], b]))
             # ONE device-to-host copy for every valid map of every probe (was: one synchronising copy per map)
             flat = [P for vb in valid for _, P in vb]
-            host = torch.stack(flat).cpu().numpy().astype(np.float32) if flat else np.zeros((0,) + tuple(eng.tensor_shape(1)[1:]), np.float32)
+            batched = do_mwp_to_saliency and not self.convert_saliency_uint8
+            dev_maps = torch.stack(flat) if flat else None
+            if dev_maps is None:
+                host = np.zeros((0,) + tuple(eng.tensor_shape(1)[1:]), np.float32)
+            elif batched:
+                host = self._to_host_scratch(dev_maps)                          # only read by the merges below: a view of the pinned scratch
+            else:
+                host = dev_maps.cpu().numpy().astype(np.float32)                # returned to the caller: its own memory
             o, vh = 0, []
             for vb in valid:
                 vh.append([(k, host[o + i]) for i, (k, _) in enumerate(vb)])
@@ -643,20 +650,33 @@ class Whitebox(object):
             valid = vh
         finally:
             eng.hold_forward(False)
-        batched = do_mwp_to_saliency and not self.convert_saliency_uint8
         res = [self._merge_subtrees(valid[b][::-1], [float(v) for v in w[:, b]], do_max_subtree, do_mwp_to_saliency and not batched) for b in range(n)]
         if batched and n > 0:
-            # ... and ONE saliency conversion (blur, clamp, normalise: whitebox.py:456-459) for the merged map and the top-k maps of every probe
-            # instead of topk + 1 device round trips per probe; the conversion is per map, so batching it changes nothing
-            stack = np.stack([m for r in res for m in [r[0]] + list(r[1])])
-            conv = self._mwp_to_saliency(stack)
+            # ... and ONE saliency conversion (blur, clamp, normalise: whitebox.py:456-459) for the merged maps and one for the top-k maps of every
+            # probe instead of topk + 1 device round trips per probe (the conversion is per map, so batching it changes nothing).  The top-k maps are
+            # converted from the copies that never left the device; only the merged maps travel host -> device.
+            merged = self._mwp_to_saliency(np.stack([r[0] for r in res]))
+            if dev_maps is not None:
+                cap = max(1, 2 * eng.max_batch)
+                top = torch.cat([eng.mwp_to_saliency(dev_maps[i:i + cap]) for i in range(0, dev_maps.shape[0], cap)], dim=0).cpu().numpy()
             o, out = 0, []
-            for r in res:
-                k = len(r[1])
-                out.append((conv[o], [conv[o + 1 + i] for i in range(k)], r[2], r[3]))
-                o += 1 + k
+            for b, r in enumerate(res):
+                k = len(r[1])                                                   # r[1] is valid[b] reversed (ascending weight)
+                out.append((merged[b], [top[o + k - 1 - i] for i in range(k)], r[2], r[3]))
+                o += k
             res = out
         return res
+
+    def _to_host_scratch(self, t):
+        """Device -> host through a cached pinned buffer; the result is a VIEW of that buffer (valid until the next call)."""
+        n = t.numel()
+        buf = self.__dict__.get('_pinned_scratch')
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(n, dtype=torch.float32, pin_memory=True)
+            self.__dict__['_pinned_scratch'] = buf
+        v = buf[:n].view(t.shape)
+        v.copy_(t.to(torch.float32))
+        return v.numpy()
 
     def _merge_subtrees(self, valid, P_subtree, do_max_subtree, do_mwp_to_saliency):
         """whitebox.py:706-737 on the valid subtrees (ascending weight, like the reference's [-topk:])."""
