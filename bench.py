@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_FWD = {'resnet101': 14.419e9, 'resnet50_128': 7.712e9, 'lightcnn': 7.275e9}   # 2*MAC over conv+linear
+PEAK_BF16_MFMA = 2516.6e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz (dense)
 PEAK_F32_MFMA = 157.3e12         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
 ROW0_COS = 0.99999               # sample 0 against the map the reference computes for the same unit of work (tests/golden/golden_bench.npz, golden_synth.npz): the parity tests' cosine bar
 
@@ -475,6 +476,14 @@ def roofline_object(W, step, ms_step, dev, reps=2, launch_log_out=None):
             'gemm_ms_per_step_serial': s_ms, 'avg_launch_ms_serial': s_ms / max(s_n, 1),
             'executed_flop_per_step': s_fl, 'algorithmic_flop_per_step': W.flop_per_unit * B, 'flop_per_step_used': alg_step,
             'mfma_util_source': 'profiles/rNN/pmc_mfma%s.txt (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024), serial schedule)' % (W.pmc_tag or '')}
+    share = tl.get('split_flop_share', 0.0)
+    if share > 0:
+        # --split-gemm: part of the FLOPs ran as bf16x6 on the bf16 pipe (2516.6 / 6 = 419.4 TFLOP/s fp32-equivalent).  The roofline is then the
+        # work-weighted (harmonic) mix of the two peaks; the fraction against the fp32 MFMA peak alone is kept beside it
+        mixed = 1.0 / (share / (PEAK_BF16_MFMA / 6e12) + (1.0 - share) / peak)
+        roof.update({'peak': mixed, 'frac': achieved / mixed, 'frac_vs_fp32_mfma_peak': achieved / peak, 'bf16x6_flop_share': share,
+                     'bf16x6_launches_per_step': tl.get('split_launches_per_step'),
+                     'peak_note': 'harmonic mix of the fp32 MFMA peak (%.1f) and the bf16x6 ceiling (%.1f fp32-equivalent TFLOP/s) by FLOP share' % (peak, PEAK_BF16_MFMA / 6e12)})
     if clk:
         # 157.3 TFLOP/s is the peak at the nominal 2.4 GHz; what the chip can do at the clock it actually held
         roof['shader_clock_GHz'] = clk
@@ -620,6 +629,8 @@ def main():
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
     ap.add_argument('--inpainting-game', action='store_true', help='only the BASELINE.json configs[4] job mix (one GPU): print its object and exit')
+    ap.add_argument('--no-split-leg', action='store_true', help='skip the experimental bf16x6 measurement that rides on the line (experimental_bf16x6)')
+    ap.add_argument('--split-gemm', action='store_true', help='xfr_engine_set_split_gemm(1): bf16x6 GEMMs for the deep-K layers (experimental; A/B against the fp32 MFMA kernels)')
     ap.add_argument('--no-lean', action='store_true', help='xfr_engine_set_lean(0): the literal hook operands in every sweep (A/B against the default lean schedule)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
     ap.add_argument('--bind', action='store_true', help='pin every rank to its own CPU set (the GPU\'s NUMA node split among the ranks that share it): 8 launch threads of ~500 launches per step each do not migrate or share cores')
@@ -705,6 +716,8 @@ def run(args, comm):
         eng.set_epilogue_fusion(args.fusion)
     if args.no_lean:
         eng.set_lean(False)
+    if args.split_gemm:
+        eng.set_split_gemm(True)
     if not args.no_pipeline and not args.serial:
         eng.set_pipeline(_pipe_level(W.pipeline))      # inputs are resident and never modified: the pipelining contract holds
     step = W.step
@@ -793,6 +806,27 @@ def run(args, comm):
             roof['unfused_epilogues_serial'] = {'achieved': alg_step * reps / (u_ms * 1e-3) / 1e12, 'frac': alg_step * reps / (u_ms * 1e-3) / PEAK_F32_MFMA,
                                                 'gemm_ms_per_step': u_ms / reps, 'avg_launch_ms': u_ms / max(u_n, 1)}
 
+    # the same step with the deep-K convolutions on the bf16 matrix pipe (xfr_engine_set_split_gemm, conv_gemm.hip K17: every fp32 operand as three bf16
+    # pieces, six exact piece products, fp32 accumulation).  EXPERIMENTAL and never `value`: its GEMMs are 1.5-3x noisier than the fp32 MFMA kernels' (rms
+    # against float64), which the ill-conditioned contrast of the fixture triplet shows -- reported with the same output checks as the headline.
+    split_leg = None
+    if rank == 0 and world == 1 and not args.serial and not args.split_gemm and not args.no_split_leg:
+        try:
+            before = eng.split_gemm_launches()
+            eng.set_split_gemm(True)
+            rs = timed_loop(W, args.steps, max(args.warmup, 3), barrier, world, dev, comm)
+            n_split = (eng.split_gemm_launches() - before) / float(args.steps + max(args.warmup, 3))
+            row0s = fixture_cosine(rs['sal'][0], W.fixture) if W.fixture else None
+            split_leg = {'maps_s': B * args.steps / rs['dt'], 'ms_per_step': 1e3 * rs['dt'] / args.steps, 'bf16x6_launches_per_step': n_split,
+                         'outputs_finite_and_normalised': bool(rs['ok']), 'row0_cosine_vs_reference': row0s,
+                         'row0_check_passes': (row0s is not None and row0s >= ROW0_COS) if W.fixture else None,
+                         'what': 'xfr_engine_set_split_gemm(1): stride-1 convolutions with K >= 1024 (1x1) / K >= 1152 (KxK) on 14 x 14 and larger maps run as bf16x6 '
+                                 'on the bf16 MFMA pipe (six v_mfma_f32_32x32x16_bf16 per K = 16 instead of eight fp32 MFMAs per K = 16); off by default'}
+        except Exception as ex:      # the experimental leg never fails the line
+            split_leg = {'error': repr(ex)}
+        finally:
+            eng.set_split_gemm(False)
+
     secondary = None
     if rank == 0 and world == 1 and args.model == 'resnet101' and not args.no_secondary and not args.serial and args.batch is None and args.mode is None:
         # BASELINE.json configs[2] and configs[3] on the same line (the driver only runs the default command)
@@ -837,6 +871,8 @@ def run(args, comm):
             line['scaling_note'] = 'N > 1 has only ever run with several ranks on ONE GPU here (gloo); no multi-GPU node was available to the builder'
         if u8_e2e is not None:
             line['u8_end_to_end'] = u8_e2e
+        if split_leg is not None:
+            line['experimental_bf16x6'] = split_leg
         if sustained is not None:
             line['sustained_maps_s'] = world * sustained['maps_s']
             line['sustained'] = sustained

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define XFR_AMD_ABI_VERSION 4
+#define XFR_AMD_ABI_VERSION 5
 
 typedef enum {
     XFR_OK = 0,
@@ -298,6 +298,16 @@ xfr_status xfr_debug_u8_preprocess(xfr_engine* e, const uint8_t* x_u8_dev, int32
  * always run literal, so a sample's map can differ in its last digits between a batch of 32 and a batch of 1: callers that need batch-invariant
  * arithmetic switch this off together with xfr_engine_set_tail_balance. */
 xfr_status xfr_engine_set_lean(xfr_engine* e, int32_t enable);
+/* bf16x6 GEMMs (off by default; ABI version 5; experimental).  The deep-K stride-1 convolutions of 14 x 14 and larger maps (K >= 1024 for 1x1,
+ * K >= 1152 for KxK, 128 | Cout) run on the bf16 matrix pipe: every fp32 operand is the exact sum of three bf16 pieces, the six piece products of
+ * order <= 2 are accumulated in fp32 (conv_gemm.hip K17).  Results differ from the fp32 MFMA kernels like a different summation order does (~1e-6 of
+ * a launch's largest output; DESIGN.md section 4 K17 for the maps); the choice is a property of the layer, never of the batch.  The weight packs of
+ * those layers get bf16 planes at their first launch (+1.5x their size); every entry point that changes the weights (or hands out the arena,
+ * xfr_engine_weight_arena -- call it again after later writes) drops them.  XFR_SPLIT_GEMM=1 in the environment switches new engines on. */
+xfr_status xfr_engine_set_split_gemm(xfr_engine* e, int32_t enable);
+/* Launches of the bf16x6 kernel so far, process-wide. */
+xfr_status xfr_engine_split_gemm_stats(xfr_engine* e, int64_t* launches);
+
 /* Convolution launches that took the lean form so far (W and relu(W) accumulated by one workgroup, quotient stored): 0 on an engine whose calls
  * all ran the literal schedule. */
 xfr_status xfr_engine_lean_stats(xfr_engine* e, int64_t* dual_launches);

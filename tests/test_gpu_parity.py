@@ -61,6 +61,8 @@ def _check_factory():
     (128, 8, 8, 4, 256, 1, 1, 0),      # 1x1 vector path
     (64, 16, 16, 2, 32, 1, 2, 0),      # strided 1x1
     (128, 8, 8, 2, 40, 8, 1, 0),       # Linear on a flattened 8x8 map (64 taps)
+    (256, 14, 14, 5, 256, 3, 1, 1),    # layer-3 3x3: the bf16x6 kernel's gather (cfg 9), ragged M (980 = 7 x 128 + 84)
+    (1024, 14, 14, 3, 128, 1, 1, 0),   # deep-K 1x1 on the bf16x6 kernel, one 128-row tile
 ])
 @pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8, 9, 10, 12, 10004, 20004, 30005, 80004, 20006, 30008, 20012])
 def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
@@ -250,6 +252,76 @@ def test_golden_contrastive_cases_on_the_lean_schedule(gpu_device, arch, mode):
         gs = GC.golden('golden_synth')
         GC.replay(subj, GC.synth_cases(arch, 'r50', mode), gs, check)
     assert subj.wb._engine(4).lean_launches() > 0
+
+
+@pytest.mark.parametrize('arch,mode', [('stresnet101', 'affineonly_with_prior'), ('stresnet101', 'norelu'), ('resnet50_128', 'norelu')])
+def test_golden_cases_on_the_split_gemm(gpu_device, arch, mode):
+    """xfr_engine_set_split_gemm(1): the deep-K convolutions on the bf16 matrix pipe (bf16x6, conv_gemm.hip K17).  The golden cases of the ResNets once
+    more with it on -- same vectors from the real reference, same tolerances as the fp32 MFMA kernels are held to; the kernel's launches are counted."""
+    if arch == 'stresnet101':
+        gold, cases = GC.golden('golden_r101'), GC.r101_cases(mode)
+        bb, sd = make_backbone(arch, seed=0, num_classes=65359)
+    else:
+        gold, cases = GC.golden('golden_r50'), GC.r50_cases(mode)
+        bb, sd = make_backbone(arch, seed=0)
+    subj = GC.engine_subject(arch, bb, mode)
+    eng = subj.wb._engine(1)
+    eng.set_split_gemm(True)
+    before = eng.split_gemm_launches()
+    inner = _check_factory()
+
+    def check(key, res, trace, g):
+        prev = PARITY_REPORT.get(key)
+        inner(key, res, trace, g)
+        PARITY_REPORT[key + ' [bf16x6]'] = PARITY_REPORT.pop(key)
+        if prev is not None:
+            PARITY_REPORT[key] = prev
+    GC.replay(subj, cases, gold, check)
+    if arch == 'resnet50_128':
+        GC.replay(subj, GC.synth_cases(arch, 'r50', mode), GC.golden('golden_synth'), check)
+    assert subj.wb._engine(1).split_gemm_launches() > before
+
+
+@pytest.mark.parametrize('arch,mode', [('stresnet101', 'affineonly_with_prior'), ('resnet50_128', 'norelu')])
+def test_split_gemm_equals_fp32_kernels(gpu_device, arch, mode):
+    """The bf16x6 kernel against the fp32 MFMA kernels on the same engine, same inputs: every fp32 operand is the exact sum of three bf16 pieces and
+    the six piece products of order <= 2 are exact in fp32; what differs is the bf16 MFMA's own summation (rms error against float64 1.5-3x the fp32
+    kernels', tools/conv_error_probe.py; its one-sided part is cancelled by the kernel's sign phases).  Encodings 1e-5, plain-EBP maps 5e-5 of the
+    maximum (measured 5e-7 .. 2e-5), contrastive maps (a difference of nearly equal tensors: parity_utils) LEAN_RTOL_CONTRAST (measured 5e-6 .. 1.5e-3)."""
+    n = 4
+    bb, sd = make_backbone(arch, seed=6, num_classes=None if arch == 'resnet50_128' else 7)
+    subj = GC.engine_subject(arch, bb, mode)
+    wb = subj.wb
+    x = make_images(arch, n, seed=33, smooth=True).to(gpu_device)
+    D = emb_dim(arch)
+    xm = (synth.unit_rows(n, D, seed=3) / 2500).to(gpu_device)
+    xn = (synth.unit_rows(n, D, seed=4) / 2500).to(gpu_device)
+    subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
+    eng = wb._engine(2 * n)
+    res, launches = {}, {}
+    for split in (1, 0):
+        eng.set_split_gemm(split)
+        before = eng.split_gemm_launches()
+        res[split] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
+                      wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone(),
+                      torch.as_tensor(wb.ebp(x, torch.tensor([[1.0, 0.0]]))))
+        launches[split] = eng.split_gemm_launches() - before
+    assert launches[1] > 0 and launches[0] == 0, launches
+    e1, e0 = res[1][0].float().cpu(), res[0][0].float().cpu()
+    assert float((e1 - e0).abs().max()) <= 1e-5 * float(e0.abs().max())
+    for what, a, b in zip(('contrastive (triplet entry)', 'truncated (triplet entry)', 'ebp'), res[1][1:], res[0][1:]):
+        a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+        for i in range(a.shape[0]):
+            tag = '%s/%s bf16x6 against fp32: %s row %d' % (arch, mode, what, i)
+            rel, cos = map_metrics(a[i], b[i])
+            PARITY_REPORT['split-vs-fp32/' + tag] = {'max_abs_diff_over_max': float(rel), 'cosine': float(cos), 'criterion': 'against the fp32 kernels'}
+            if what == 'ebp':
+                assert_map_close(a[i], b[i], tag, rtol=5e-5)
+            elif what.startswith('truncated'):
+                assert_map_close_robust(a[i], b[i], tag, rtol=LEAN_RTOL_CONTRAST)
+            else:
+                assert_map_close(a[i], b[i], tag, rtol=LEAN_RTOL_CONTRAST)
+    eng.set_split_gemm(0)
 
 
 # ---- oracle on fresh seeded inputs, batched ----------------------------------------------------------------------------

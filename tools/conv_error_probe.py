@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Error of the GEMM kernels against a float64 convolution (CPU): RMS and mean signed error of the fp32 MFMA kernels (cfg 4, 7) and the bf16x6 kernel
+(cfg 9) on deep-K layer shapes, with post-ReLU-like (half zero, non-negative) and signed inputs.   python tools/conv_error_probe.py"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import numpy as np
+    import torch
+    from xfr_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    torch.set_num_threads(16)
+    for (cin, h, w, nb, cout, k, pad) in [(256, 14, 14, 8, 256, 3, 1), (1024, 14, 14, 8, 256, 1, 0), (128, 28, 28, 4, 128, 3, 1)]:
+        for kind in ('relu', 'signed', 'wide'):
+            g = torch.Generator().manual_seed(1)
+            x = torch.randn((nb, cin, h, w), generator=g, dtype=torch.float64)
+            if kind == 'relu':
+                x = x.clamp_min(0)
+            if kind == 'wide':            # gradient-like: magnitudes over many decades
+                x = x * torch.exp(8 * torch.randn((nb, cin, h, w), generator=g, dtype=torch.float64))
+            x = x.float()
+            wt = (torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5).contiguous()
+            want = torch.nn.functional.conv2d(x.double(), wt.double(), None, padding=pad)
+            mag = torch.nn.functional.conv2d(x.double().abs(), wt.double().abs(), None, padding=pad)       # sum of |terms|
+            xg = x.to(dev).permute(1, 0, 2, 3).contiguous()
+            line = '%-28s %-6s' % ((cin, h, cout, k), kind)
+            for cfg in (4, 7, 9):
+                out = torch.zeros((cout, nb) + tuple(want.shape[2:]), device=dev)
+                ms = ctypes.c_float()
+                _lib.check(lib.xfr_debug_conv(xg.data_ptr(), wt.data_ptr(), None, out.data_ptr(), cin, h, w, nb, cout, k, k, 1, pad, 0, cfg, 1, ctypes.byref(ms)))
+                got = out.permute(1, 0, 2, 3).cpu().double()
+                e = (got - want) / mag
+                line += ' | cfg %d: rms %.2e mean %+.2e max %.2e' % (cfg, float(e.pow(2).mean().sqrt()), float(e.mean()), float(e.abs().max()))
+            print(line, flush=True)
+
+
+if __name__ == '__main__':
+    main()

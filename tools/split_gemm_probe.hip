@@ -34,6 +34,25 @@ constexpr int TN = 128;         // activation columns per workgroup (256 lanes =
 
 struct Split3 { unsigned h0, h1, h2; };      // the three pieces, each in the upper half of a word
 
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef __bf16 v2bf_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)      // v_cvt_pk_bf16_f32: two round-to-nearest-even conversions, lo in the low half
+{
+    const v2f_t t = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, v2bf_t));
+}
+// Round-to-nearest split of a PAIR (even k in the low half): every piece is at most half a bf16 ulp of the one before, so the three dropped products of
+// order 3 are ~2^-25 of the product and of either sign.  (A truncating split -- one AND per piece -- leaves remainders of up to a whole ulp, all of the
+// value's sign: dropped terms ~2^-21 that add up along K instead of averaging out; measured: maps 4x further from the reference than the fp32 kernels.)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2)
+{
+    p0 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);       // exact
+    p1 = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);     // exact, <= 8 significant bits
+    p2 = cvt_pk_bf16(sa, sb);
+}
+
 __device__ __forceinline__ Split3 split3(float v)
 {
     Split3 s;
@@ -268,13 +287,11 @@ __global__ __launch_bounds__(256) void split_gemm_deep_kernel(const uint16_t* __
     };
     auto store_x = [&](const float (&v)[8], int stage) {
         if (NSPLIT == 3) {
-            Split3 s[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) s[i] = split3(v[i]);
             uint4 p0, p1, p2;
-            p0.x = pack_hi(s[1].h0, s[0].h0); p0.y = pack_hi(s[3].h0, s[2].h0); p0.z = pack_hi(s[5].h0, s[4].h0); p0.w = pack_hi(s[7].h0, s[6].h0);
-            p1.x = pack_hi(s[1].h1, s[0].h1); p1.y = pack_hi(s[3].h1, s[2].h1); p1.z = pack_hi(s[5].h1, s[4].h1); p1.w = pack_hi(s[7].h1, s[6].h1);
-            p2.x = pack_hi(s[1].h2, s[0].h2); p2.y = pack_hi(s[3].h2, s[2].h2); p2.z = pack_hi(s[5].h2, s[4].h2); p2.w = pack_hi(s[7].h2, s[6].h2);
+            split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+            split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+            split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+            split_pair(v[6], v[7], p0.w, p1.w, p2.w);
             write_piece(p0, stage, 0); write_piece(p1, stage, 1); write_piece(p2, stage, 2);
         } else {
             uint4 p0;
@@ -481,14 +498,20 @@ __global__ __launch_bounds__(256) void split_gemm_directb_kernel(const uint16_t*
 }
 
 // host: W[Cout][K] fp32 -> tiles [Cout/TM][K/16][piece][k-half][TM][8] of bf16 pieces (truncation split, exact)
-static void split_host(float v, uint16_t out[3])
+static uint16_t bf16_rne(float v)
 {
     uint32_t u; memcpy(&u, &v, 4);
-    uint32_t h0 = u & 0xffff0000u; float f0; memcpy(&f0, &h0, 4);
-    float r1 = v - f0; uint32_t u1; memcpy(&u1, &r1, 4);
-    uint32_t h1 = u1 & 0xffff0000u; float f1; memcpy(&f1, &h1, 4);
-    float r2 = r1 - f1; uint32_t u2; memcpy(&u2, &r2, 4);
-    out[0] = h0 >> 16; out[1] = h1 >> 16; out[2] = u2 >> 16;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static void split_host(float v, uint16_t out[3])
+{
+    out[0] = bf16_rne(v);
+    const float r1 = v - bf16_f(out[0]);
+    out[1] = bf16_rne(r1);
+    const float r2 = r1 - bf16_f(out[1]);
+    out[2] = bf16_rne(r2);
 }
 
 static std::vector<uint16_t> tile_weights(const std::vector<float>& W, int Cout, int K, int TM)

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XFR_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libxfr_amd.so')      # XFR_AMD_LIB: A/B builds of the same ABI (tools/ab_env.sh)
 
 XFR_OK, XFR_INVALID_ARG, XFR_UNSUPPORTED_LAYER, XFR_OOM, XFR_HIP_ERROR, XFR_STATE_ERROR, XFR_RCCL_ERROR = range(7)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class TensorView(ctypes.Structure):
@@ -56,6 +56,8 @@ SYMBOLS = [
     ('xfr_engine_set_inputs_ready', _I, [_P, _I]),
     ('xfr_engine_set_tail_balance', _I, [_P, _I]),
     ('xfr_engine_set_lean', _I, [_P, _I]),
+    ('xfr_engine_set_split_gemm', _I, [_P, _I]),
+    ('xfr_engine_split_gemm_stats', _I, [_P, ctypes.POINTER(ctypes.c_int64)]),
     ('xfr_engine_lean_stats', _I, [_P, ctypes.POINTER(ctypes.c_int64)]),
     ('xfr_engine_set_forward_split', _I, [_P, _I]),
     ('xfr_engine_hold_forward', _I, [_P, _I]),

@@ -273,6 +273,7 @@ struct ConvParams {
     int dualacc;        // 1 (nhalves == 1): every workgroup accumulates W AND relu(W) -- taken from the W fragment in registers, no second pack is read -- over the
                         // same staged input tile; the chain (compiled, first step EW_LEAN_Q) sees both.  The lean probe forward: bias_pos is the second bias
     int relu_in;        // clamp the gathered input at 0 (A = relu(input))
+    int split_ok;       // 1: the launch may take the bf16x6 kernel (conv_gemm.hip K17) where the layer is one it covers (xfr_engine_set_split_gemm)
     int accumulate;     // out += result
     int out_H, out_W, out_stride;  // out_stride > 1: scatter the (OH,OW) grid into an (out_H,out_W) tensor
     int chain_B;        // forward batch for the a-index of the epilogue chain
@@ -305,6 +306,12 @@ bool launch_conv_gemm(const ConvParams& p, hipStream_t s);
 int conv_gemm_cannot_launch(const ConvParams& p);
 const char* conv_gemm_refusal(int why);
 int conv_gemm_pick_cfg(const ConvParams& p);
+// bf16x6 split GEMM (conv_gemm.hip K17, configuration 9; ConvParams::split_ok).  The fp32 pack of a covered layer gets its bf16 planes at its first launch
+// (split on that launch's stream, which is then drained once: other streams may use the planes at once).  conv_gemm_forget_split: the packs inside
+// [lo, lo + bytes) changed or go away -- drop their planes (the next launch splits again).
+void conv_gemm_forget_split(const void* lo, size_t bytes);
+int conv_gemm_split_covers(const ConvParams& p);
+long conv_gemm_split_launches();
 
 // g = src[idx]; run chain; dst[idx] = (accumulate ? dst[idx] : 0) + g.   Tensors are [C][SB][HW] for the gradient
 // and [C][B][HW] for the forward-side sources (sample b = sb % B).

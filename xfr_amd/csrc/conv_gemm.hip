@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "common.h"
 #include <cstdio>
@@ -1102,6 +1103,244 @@ __global__ __launch_bounds__(NT, CHAIN == 4 ? XFR_KS_DUAL_WAVES : 5) void conv_g
     stamp(p, wave, lane, 4);
 }
 
+// ---- K17: conv_gemm_split_kernel -- fp32-accurate GEMM on the bf16 MFMA pipe ("bf16x6") ---------------------------------------------------------------
+// An fp32 value is EXACTLY the sum of three bf16 pieces (8 + 8 + 8 significant bits, each piece the round-to-nearest bf16 of what is left); a bf16 x
+// bf16 product is exact in fp32; the six products (i, j) with i + j <= 2, accumulated in fp32 smallest first, reproduce the fp32 product to ~2^-23 -- the
+// maps cannot tell it from a re-ordered fp32 sum (tests/precision/split_probe.py, profiles/r5/experiments/bf16_split.txt).  Six
+// v_mfma_f32_32x32x16_bf16 take 6 x 32 cycles where the sixteen fp32 MFMAs of the same K = 16 take 8 x 64.
+//   * W: split once per pack (conv_gemm_register_split) into three bf16 planes, tiled [128-row tile][K step][piece][k half][128][8]: a K-step of a row
+//     tile is one contiguous 12 KB block that goes global -> LDS without registers (three LDS stages, two steps ahead);
+//   * X: fp32 as the producing epilogues left it; the workgroup's 256 lanes gather a 16 x 128 slab three steps ahead into registers (the tap-major
+//     gather of K2: per-lane shifted offset per filter tap, channels as the scalar offset, padding / m tails / steps past the end out of the buffer's
+//     range = 0), split every value once and write the three planes to LDS in fragment order (ds_write as inline asm: a compiler-visible ds_write after a
+//     buffer_load...lds is ordered with s_waitcnt vmcnt(0), which would drain exactly that prefetch);
+//   * 128 x 128 block tile, wave (wr, wc) holds the quadrants (wr, wc) of the four 64 x 64 sub-tiles -- so each sub-tile is laid out exactly like the
+//     block tile of K1 / K2 and runs their epilogues (block_epilogue) unchanged;
+//   * the loop is unrolled by three (stage and register-set indices are static; up to two steps past the end multiply zeros), one counted wait and one
+//     raw barrier per step.
+// Layers: stride-1 convolutions (1x1 and tap-major KxK) with Cin % 16 == 0, 128 | Cout, no dual-accumulator launch, dense output.
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr int SP_T = 128, SP_BK = 16;
+constexpr int SP_A_BYTES = 3 * 2 * SP_T * 16, SP_B_BYTES = 3 * 2 * SP_T * 16;
+constexpr size_t SP_LDS = 3 * (size_t)(SP_A_BYTES + SP_B_BYTES);
+
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef __bf16 v2bf_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)      // v_cvt_pk_bf16_f32: two round-to-nearest-even conversions, lo in the low half
+{
+    const v2f_t t = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, v2bf_t));
+}
+// Round-to-nearest split of a PAIR (even k in the low half): v = p0 + p1 + p2 exactly, every piece at most half a bf16 ulp of the one before, so the three
+// dropped products of order 3 are ~2^-25 of the product and of either sign.  (A truncating split -- one AND per piece -- leaves remainders of up to a
+// whole ulp, all of the value's sign: dropped terms ~2^-21 that add up along K instead of averaging out.  Measured in round 5: golden maps 4x further
+// from the reference than with the fp32 kernels; with this split they are where the fp32 kernels are.)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2)
+{
+    p0 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);       // exact
+    p1 = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);     // exact, <= 8 significant bits
+    p2 = cvt_pk_bf16(sa, sb);
+}
+
+template <bool RELU, int CHAIN>
+__global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams p, const uint16_t* __restrict__ ws0, const uint16_t* __restrict__ ws1,
+                                                            const int n_co_tiles, const int n_m_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+    constexpr int XBASE = 3 * SP_A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int lid = xcd_remap(blockIdx.x, n_co_tiles * n_m_tiles);
+    const int tile_m = lid / n_co_tiles;
+    const int tile_co_all = lid - tile_m * n_co_tiles;
+    const int n_co_half = n_co_tiles / p.nhalves;
+    const int half = tile_co_all / n_co_half;
+    const int tile_co = tile_co_all - half * n_co_half;
+    const int co0 = tile_co * SP_T, m0 = tile_m * SP_T;
+    const uint16_t* __restrict__ wsel = half ? ws1 : ws0;
+    const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
+    float* __restrict__ osel = half ? p.out1 : p.out0;
+    const int nk = p.K / SP_BK;
+    const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, n_co_half * nk * SP_A_BYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+
+    // staging role: column m0 + (tid & 127), k-half wave >> 1 (wave-uniform)
+    const int sm = tid & 127, skh = wave >> 1;
+    int base_m = 0;
+    unsigned long long tapmask = 0ull;
+    {
+        const int m = m0 + sm;
+        const bool m_ok = m < p.M;
+        const int mm = m_ok ? m : 0;
+        const int ohw = p.OH * p.OW;
+        const int n = mm / ohw;
+        const int r = mm - n * ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+        base_m = n * p.H * p.W + ih0 * p.W + iw0;
+        if (m_ok) {
+            unsigned long long vw = 0ull;
+            for (int dw = 0; dw < p.kw; ++dw)
+                if ((unsigned)(iw0 + dw) < (unsigned)p.W) vw |= 1ull << dw;
+            for (int dh = 0; dh < p.kh; ++dh)
+                if ((unsigned)(ih0 + dh) < (unsigned)p.H) tapmask |= vw << (dh * p.kw);
+        }
+    }
+    const unsigned xs_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds) + XBASE + (skh * SP_T + sm) * 16;   // this lane's LDS slot
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto load_w = [&](int kt, int stage) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)      // steps past the end: out of range, the hardware writes zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(lds + stage * SP_A_BYTES + (b * 4 + wave) * 1024), 16,
+                                                     ((b * 4 + wave) * 1024 + lane * 16) | (kt < nk ? 0u : OOB), (tile_co * nk + kt) * SP_A_BYTES, 0, 0);
+    };
+    // the X loads walk the K-steps in order: (tap, first channel) of the next step to be loaded, and that tap's per-lane offset
+    int ld_tap = 0, ld_ci0 = 0;
+    unsigned ld_voff = (tapmask & 1ull) ? (unsigned)base_m * 4u : OOB;
+    auto load_x = [&](int kt, float (&v)[8]) {
+        const unsigned voff = ld_voff | (kt < nk ? 0u : OOB);
+        const unsigned so = (unsigned)(ld_ci0 + skh * 8) * chan_bytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rIn, voff, so + (unsigned)i * chan_bytes, 0));
+        ld_ci0 += SP_BK;
+        if (ld_ci0 >= p.Cin) {          // wave-uniform: next filter tap => new per-lane shifted offset
+            ld_ci0 = 0;
+            ld_tap += 1;
+            const int dh = ld_tap / p.kw, dw = ld_tap - dh * p.kw;
+            ld_voff = (ld_tap < p.kh * p.kw && ((tapmask >> ld_tap) & 1ull)) ? (unsigned)(base_m + dh * p.W + dw) * 4u : OOB;
+        }
+    };
+    auto write_piece = [&](v4u q, int stage, int piece) {
+        asm volatile("ds_write_b128 %0, %1" :: "v"(xs_addr + stage * SP_B_BYTES + piece * 2 * SP_T * 16), "v"(q));
+    };
+    // `flip`: 0x80008000 for a K-step of a NEGATED phase (below), else 0 -- the sign bits of both bf16 of a word
+    auto store_x = [&](const float (&v)[8], int stage, unsigned flip) {
+        v4u p0, p1, p2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = RELU ? fmaxf(v[2 * i], 0.f) : v[2 * i], b = RELU ? fmaxf(v[2 * i + 1], 0.f) : v[2 * i + 1];
+            unsigned q0, q1, q2;
+            split_pair(a, b, q0, q1, q2);
+            p0[i] = q0 ^ flip; p1[i] = q1 ^ flip; p2[i] = q2 ^ flip;
+        }
+        write_piece(p0, stage, 0); write_piece(p1, stage, 1); write_piece(p2, stage, 2);
+    };
+    // Sign phases.  The bf16 MFMA does not round its sum to nearest like the fp32 MFMA (an fmaf chain) does: measured against float64, every output of a
+    // bf16x6 GEMM sits ~4e-9 of its sum of magnitudes BELOW the exact value (fp32 kernels: 2e-11, either sign) -- 0.1 of the rms error, but of one sign in
+    // every element of every layer, which a contrastive map amplifies.  So every SP_PHASE K-steps the sum changes sign: X pieces are stored negated (one
+    // XOR per word) and the accumulators are negated in place (exact); the hardware's downward error then pushes the true sum UP, and the two cancel.
+    constexpr int SP_PHASE = 4;
+    auto phase_neg = [](int kt) { return ((kt / SP_PHASE) & 1) != 0; };
+    // one K-step; ST = kt % 3 (static), xcur = X(kt+1) registers (split here), xnew = registers that receive X(kt+3)
+    auto step = [&](int kt, auto ST, float (&xcur)[8], float (&xnew)[8]) {
+        constexpr int st = decltype(ST)::value, st1 = (st + 1) % 3, st2 = (st + 2) % 3;
+        load_w(kt + 2, st2);
+        load_x(kt + 3, xnew);
+        const unsigned char* As = lds + st * SP_A_BYTES;
+        const unsigned char* Bs = lds + XBASE + st * SP_B_BYTES;
+        v8bf af[3][2], bf[3][2];
+        // quadrant (wr, wc) of sub-tile (i, j): rows i * 64 + wr * 32, columns j * 64 + wc * 32
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[pc][i] = *(const v8bf*)(As + ((pc * 2 + lhi) * SP_T + i * 64 + wr * 32 + l31) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[pc][j] = *(const v8bf*)(Bs + ((pc * 2 + lhi) * SP_T + j * 64 + wc * 32 + l31) * 16);
+        }
+        // (piece of W, piece of X), smallest products first
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], acc[i][j], 0, 0, 0);
+        store_x(xcur, st1, phase_neg(kt + 1) ? 0x80008000u : 0u);
+        if (phase_neg(kt + 1) != phase_neg(kt)) {       // wave-uniform, every SP_PHASE steps: the accumulators change sign with the products
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
+        }
+        // W(kt+1) (issued during step kt-1) has landed when at most X(kt+2), W(kt+2), X(kt+3) are outstanding: 8 + 3 + 8
+        asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    float x0[8], x1[8], x2[8];
+    load_w(0, 0);
+    load_x(0, x0);
+    store_x(x0, 0, 0u);
+    load_w(1, 1);
+    load_x(1, x0);
+    load_x(2, x1);
+    asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // W(0) and the split of X(0) are in LDS
+    std::integral_constant<int, 0> S0; std::integral_constant<int, 1> S1; std::integral_constant<int, 2> S2;
+    for (int kt = 0; kt < nk; kt += 3) {        // up to two steps past the end multiply zeros: no branch on kt inside the body
+        step(kt, S0, x0, x2);
+        step(kt + 1, S1, x1, x0);
+        step(kt + 2, S2, x2, x1);
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (phase_neg(((nk + 2) / 3) * 3)) {        // the phase the loop ended in (the last step already switched to the phase of the step after it)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
+    }
+
+    // the four 64 x 64 sub-tiles leave through the epilogues of K1 (each starts with a workgroup barrier before it reuses the LDS).  A REAL loop -- one
+    // epilogue instance in the code, not four (the compiled-chain family is 86 signatures) -- over a fixed register tile: the other three shift down.
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        v16f t[1][1];
+        t[0][0] = acc[0][0];
+        block_epilogue<CHAIN, true>(p, t, smem, tid, lane, wave, co0 + (q >> 1) * 64, m0 + (q & 1) * 64, half, -1, 0, 1, osel, bsel, nullptr);
+        acc[0][0] = acc[0][1];
+        acc[0][1] = acc[1][0];
+        acc[1][0] = acc[1][1];
+    }
+}
+
+// W[k][ldw] fp32 (k rows, output channel = column) -> bf16 planes [cout / 128][K / 16][piece][k half][128][8]
+__global__ void split_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ planes, int K, int cout, int ldw)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)K * cout) return;
+    const int k = (int)(idx / cout), co = (int)(idx - (long)k * cout);
+    unsigned h[3], dummy = 0;
+    {
+        const float v = w[(long)k * ldw + co];
+        unsigned q0, q1, q2;
+        split_pair(v, 0.f, q0, q1, q2);          // the value in the low half
+        h[0] = q0 & 0xffffu; h[1] = q1 & 0xffffu; h[2] = q2 & 0xffffu;
+        (void)dummy;
+    }
+    const int rt = co / SP_T, r = co - rt * SP_T, kt = k / SP_BK, kk = k - kt * SP_BK, nk = K / SP_BK;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        planes[((((long)(rt * nk + kt) * 3 + q) * 2 + kk / 8) * SP_T + r) * 8 + kk % 8] = (uint16_t)h[q];
+}
+
 int num_cus()
 {
     static const int n = [] {
@@ -1296,6 +1535,77 @@ bool launch_cfg_ks(const ConvParams& p, hipStream_t s)
     return launch_one_ks<BK, NST, MODE_TAP>(p, s);
 }
 
+// ---- the bf16x6 kernel's host side: a registry of split packs (fp32 pack pointer -> bf16 planes), filled by the engine for the layers it covers
+struct SplitPack { uint16_t* planes; int K, cout, ldw; };
+static std::mutex g_split_mu;
+static std::unordered_map<const float*, SplitPack> g_split;
+
+bool split_layer_ok(const ConvParams& p)
+{
+    if (p.dualacc || p.out_stride != 1 || p.as_strided || p.co_pair > 0 || p.stride != 1) return false;
+    if ((p.Cin % SP_BK) != 0 || (p.K % SP_BK) != 0 || (p.CoutTot % SP_T) != 0) return false;
+    if (p.OH * p.OW < 196) return false;       // 7 x 7 maps: 25 column tiles per 64 images leave most CUs idle (68 against 111 TFLOP/s on layer 4)
+    if (p.kh == 1 && p.kw == 1) return p.pad == 0 && p.K >= 1024;
+    return p.tap_major == 1 && p.kh * p.kw <= 64 && p.K >= 1152;
+}
+
+static std::atomic<long> g_split_launches{0};
+
+// the planes of pack w, split now if this is its first launch: the split runs on the launch's stream, which is drained before the entry becomes visible
+// (another stream's launch of the same layer may follow at once)
+const uint16_t* split_planes(const float* w, int K, int cout, int ldw, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split.find(w);
+    if (it != g_split.end()) return (it->second.K == K && it->second.cout == cout && it->second.ldw == ldw) ? it->second.planes : nullptr;
+    SplitPack sp{nullptr, K, cout, ldw};
+    if (hipMalloc(&sp.planes, (size_t)K * cout * 3 * sizeof(uint16_t)) != hipSuccess) return nullptr;
+    const long n = (long)K * cout;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, sp.planes, K, cout, ldw);
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(sp.planes); return nullptr; }
+    g_split[w] = sp;
+    return sp.planes;
+}
+
+template <bool RELU, int CHAIN>
+void launch_split_inst(const ConvParams& q, const uint16_t* w0, const uint16_t* w1, int grid, int n_co, int n_m, hipStream_t s)
+{
+    static const bool attr = [] {      // once per instantiation: the kernel's 72 KB of dynamic LDS exceed the default limit
+        return hipFuncSetAttribute((const void*)conv_gemm_split_kernel<RELU, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_LDS) == hipSuccess;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL((conv_gemm_split_kernel<RELU, CHAIN>), dim3(grid), dim3(NT), SP_LDS, s, q, w0, w1, n_co, n_m);
+}
+
+// false: the launch is not one the split kernel covers (or its pack is not registered) -- the caller takes the fp32 kernel the rules give
+bool launch_split(const ConvParams& p, hipStream_t s)
+{
+    if (!split_layer_ok(p)) return false;
+    if (p.chain.n > 0 && p.relu_in) return false;
+    const uint16_t* w0 = split_planes(p.w, p.K, p.CoutTot, p.ldw, s);
+    const uint16_t* w1 = p.nhalves == 2 ? split_planes(p.w_pos, p.K, p.CoutTot, p.ldw, s) : nullptr;
+    if (!w0 || (p.nhalves == 2 && !w1)) return false;
+    g_split_launches++;
+    const int n_co = (p.CoutTot / SP_T) * p.nhalves;
+    const int n_m = (p.M + SP_T - 1) / SP_T;
+    ConvParams q = p;
+    q.tail_q = 0;
+    q.tail_s = 1;
+    if (q.chain.n > 0) {
+        if (plan_chain(q)) return false;
+        if (q.chain_sig >= 0 && chain_sig_is_dual(q.chain_sig)) return false;      // (only ever with dualacc, which the layer test excludes)
+        g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
+        if (q.chain_sig < 0) warn_interpreted(q);
+        if (q.chain_sig >= 0 && chain_sig_is_mfm(q.chain_sig)) launch_split_inst<false, 3>(q, w0, w1, n_co * n_m, n_co, n_m, s);
+        else if (q.chain_sig >= 0) launch_split_inst<false, 1>(q, w0, w1, n_co * n_m, n_co, n_m, s);
+        else launch_split_inst<false, 2>(q, w0, w1, n_co * n_m, n_co, n_m, s);
+        return true;
+    }
+    if (p.relu_in) launch_split_inst<true, 0>(q, w0, w1, n_co * n_m, n_co, n_m, s);
+    else launch_split_inst<false, 0>(q, w0, w1, n_co * n_m, n_co, n_m, s);
+    return true;
+}
+
 template <int TCO, int TM, int BK, int NST>
 bool launch_cfg(const ConvParams& p_in, hipStream_t s)
 {
@@ -1328,6 +1638,22 @@ int conv_gemm_chain_sig(const EwChain& ch)
 }
 int conv_gemm_num_chain_sigs() { return kNumChainSigs; }
 
+// bf16x6 split packs (K17): drop the planes of every pack inside [lo, lo + bytes) -- its contents changed, or its memory goes away
+void conv_gemm_forget_split(const void* lo, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    const char* a = static_cast<const char*>(lo);
+    for (auto it = g_split.begin(); it != g_split.end();) {
+        const char* w = reinterpret_cast<const char*>(it->first);
+        if (w >= a && w < a + bytes) {
+            if (it->second.planes) (void)hipFree(it->second.planes);     // hipFree waits for the device: no launch still reads them
+            it = g_split.erase(it);
+        } else ++it;
+    }
+}
+int conv_gemm_split_covers(const ConvParams& p) { return split_layer_ok(p) ? 1 : 0; }
+long conv_gemm_split_launches() { return g_split_launches.load(); }
+
 int conv_gemm_cannot_launch(const ConvParams& p)
 {
     if (p.chain.n <= 0) return 0;
@@ -1351,12 +1677,14 @@ void conv_gemm_chain_launch_counts(long* compiled, long* interpreted)
     if (interpreted) *interpreted = g_chain_launches[1].load();
 }
 
-int conv_gemm_pick_cfg(const ConvParams& p_in)
+static int pick_cfg_impl(const ConvParams& p_in, bool allow_split);
+int conv_gemm_pick_cfg(const ConvParams& p_in) { return pick_cfg_impl(p_in, true); }
+static int pick_cfg_impl(const ConvParams& p_in, bool allow_split)
 {
     // A dual-accumulator launch does the work of the dual (W / relu(W)) launch of the same layer with half the workgroups, twice as long each: it
     // takes the kernel that launch takes (the rules below see the dual launch's tile count), never the 32 x 128 tile.
     ConvParams p = p_in;
-    if (p.dualacc) { p.nhalves = 2; p.dualacc = 0; const int c = conv_gemm_pick_cfg(p); return c == 12 ? 4 : c; }
+    if (p.dualacc) { p.nhalves = 2; p.dualacc = 0; const int c = pick_cfg_impl(p, false); return c == 12 ? 4 : c; }
     // Measured on MI355X over the ResNet-101 / ResNet-50 / Light-CNN GEMM shapes (M = 1.5k..400k, K = 64..4608,
     // Cout = 64..2048): the 64x64 tile wins or ties everywhere -- these grids are small (1-12 workgroups per CU), so
     // finer tiles balance the 256 CUs better and keep more waves per SIMD than 128-wide tiles buy in reuse.
@@ -1364,6 +1692,8 @@ int conv_gemm_pick_cfg(const ConvParams& p_in)
     // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
     // Channel counts that leave the last 64-row tile at most half full (Light-CNN: 96 = 64 + 32): the 32 x 128 block tile wastes no MFMA row.
     // A property of the layer; K order of the 64 x 64 tile, so the bits do not move where that one ran before.
+    // bf16x6 (K17): a property of the LAYER and of the engine's setting, never of the batch
+    if (allow_split && p.split_ok && split_layer_ok(p)) return 9;
     {
         const int rem = p.CoutTot % 64;
 #ifndef XFR_NO_ROW_TILE      /* A/B builds only (profiles/r4/experiments/row_tile_ab.txt) */
@@ -1480,6 +1810,10 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     }
     // cfg 6 / 7: the intra-workgroup split-K kernel, (BK, ring stages) = (8, 3): 48 KB of LDS, three workgroups per CU; (4, 4): 32 KB, five.
     // Round 3 sweep (tools/conv_sweep.py): (4, 5) and (4, 6) tie with (4, 4), (16, 3) -- one workgroup per CU -- loses 15 %.
+    if (cfg == 9) {
+        if (launch_split(p, s)) return true;
+        cfg = pick_cfg_impl(p, false);     // not covered (a chain family without a split instantiation, an unregistered pack): the fp32 rules
+    }
     if (cfg == 6 && ks_ok<8>(p)) return launch_cfg_ks<8, 3>(p, s);
     if (cfg == 7 && ks_ok<4>(p)) return launch_cfg_ks<4, 4>(p, s);
     if (cfg == 5) return launch_cfg<64, 64, 32, 3>(p, s);

@@ -223,6 +223,7 @@ struct xfr_engine {
     bool u8_on = false;
     bool u8_set = false;
     U8Pre u8_pre;
+    bool split_gemm = false;           // xfr_engine_set_split_gemm: covered layers run the bf16x6 kernel (conv_gemm.hip K17)
     bool lean = true;                  // xfr_engine_set_lean: plain sweeps (no trace / prior / capture / stored firing, batch % 4 == 0) take the lean schedule
     const BwdPlan* lean_cur = nullptr; // the plan whose lean tables the running probe forward / sweep follow (null: literal)
     bool lean_decide = false;          // lean_prepare's dry run of the probe forward: decide per convolution, record in lean_q_run / lean_final_run
@@ -603,6 +604,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
     p.chain_interpret = e->interpret_chains ? 1 : 0;
+    p.split_ok = e->split_gemm ? 1 : 0;
     p.tail_force = 1;
     if (e->tail_balance) {
         p.tail_force = 0;
@@ -2410,6 +2412,7 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     if (st == XFR_OK) st = layout_arena(e);
     if (st == XFR_OK) st = allocate(e);
     if (st != XFR_OK) { xfr_engine_destroy(e); return st; }
+    if (const char* v = getenv("XFR_SPLIT_GEMM")) e->split_gemm = atoi(v) != 0;      // A/B runs; the API is xfr_engine_set_split_gemm
     *out = e;
     return XFR_OK;
 }
@@ -2420,7 +2423,7 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     (void)hipSetDevice(e->device);
     if (e->ws) (void)hipFree(e->ws);
     if (e->idx_ws) (void)hipFree(e->idx_ws);
-    if (e->arena) (void)hipFree(e->arena);
+    if (e->arena) { conv_gemm_forget_split(e->arena, e->arena_floats * sizeof(float)); (void)hipFree(e->arena); }
     if (e->dbl_ws) (void)hipFree(e->dbl_ws);
     if (e->trunc_ws) (void)hipFree(e->trunc_ws);
     if (e->ws_enc) (void)hipFree(e->ws_enc);
@@ -2527,6 +2530,7 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
             }
         }
     }
+    conv_gemm_forget_split(e->arena, e->arena_floats * sizeof(float));          // bf16 planes of the old weights (K17)
     HIP_TRY(hipMemcpy(e->arena, host.data(), e->arena_floats * sizeof(float), hipMemcpyHostToDevice));
     e->weights_loaded = true;
     return XFR_OK;
@@ -2535,6 +2539,7 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
 xfr_status xfr_engine_weight_arena(xfr_engine* e, void** dev_ptr, size_t* bytes)
 {
     if (!e || !dev_ptr || !bytes) return fail(XFR_INVALID_ARG, "null argument");
+    conv_gemm_forget_split(e->arena, e->arena_floats * sizeof(float));          // the caller is about to write: bf16 planes (K17) are rebuilt at the next launch
     *dev_ptr = e->arena;
     *bytes = e->arena_floats * sizeof(float);
     return XFR_OK;
@@ -2887,6 +2892,21 @@ xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     e->tail_balance = enable != 0;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_set_split_gemm(xfr_engine* e, int32_t enable)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    e->split_gemm = enable != 0;
+    e->held_x = nullptr;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_split_gemm_stats(xfr_engine* e, int64_t* launches)
+{
+    if (!e || !launches) return fail(XFR_INVALID_ARG, "null argument");
+    *launches = conv_gemm_split_launches();       // process-wide: the kernel's launch counter is not per engine
     return XFR_OK;
 }
 
@@ -3312,6 +3332,7 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     p.tail_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tws) + XFR_TAIL_WS_BYTES);
     HIP_TRY(hipMemset(p.tail_cnt, 0, XFR_TAIL_MAX_TILES * sizeof(unsigned)));
     p.tail_force = (cfg / 10000) % 100;  // 0 heuristic, 1 off, S >= 2 forced
+    const bool split = (cfg % 100) == 9;  // the bf16x6 kernel (layers it does not cover run the fp32 kernel the rules give, like in the engine)
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
@@ -3361,6 +3382,7 @@ xfr_status xfr_debug_conv(const float* in_dev, const float* w_host, const float*
     }
     if (ms_out) *ms_out = ms / reps;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (split) conv_gemm_forget_split(wd, host.size() * sizeof(float));
     (void)hipFree(wd);
     (void)hipFree(tws);
     if (bd) (void)hipFree(bd);
@@ -3466,6 +3488,7 @@ xfr_status xfr_broadcast_weights(xfr_engine* e, xfr_comm* c, int32_t root, void*
     if (c->rank == root && !e->weights_loaded) return fail(XFR_STATE_ERROR, "the root rank has no weights loaded");
     HIP_TRY(hipSetDevice(e->device));
     const size_t bytes = e->arena_floats * sizeof(float);
+    conv_gemm_forget_split(e->arena, bytes);
     RCCL_TRY(g_rccl.Broadcast(e->arena, e->arena, bytes, /* ncclChar */ 0, root, c->comm, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     e->weights_loaded = true;

@@ -276,6 +276,17 @@ class Engine(object):
         _lib.check(self.lib.xfr_engine_set_lean(self._h, int(bool(on))))
         self.options['lean'] = bool(on)
 
+    def set_split_gemm(self, on):
+        """bf16x6 GEMMs for the deep-K stride-1 convolutions (default off; experimental; include/xfr_amd.h, conv_gemm.hip K17)."""
+        _lib.check(self.lib.xfr_engine_set_split_gemm(self._h, int(bool(on))))
+        self.options['split_gemm'] = bool(on)
+
+    def split_gemm_launches(self):
+        """Launches of the bf16x6 kernel so far (process-wide)."""
+        n = ctypes.c_int64(0)
+        _lib.check(self.lib.xfr_engine_split_gemm_stats(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def lean_launches(self):
         """Convolution launches of this engine that took the lean (dual-accumulator) form so far."""
         n = ctypes.c_int64(0)
@@ -290,6 +301,8 @@ class Engine(object):
             self.set_forward_split(options['forward_split'])
         if 'lean' in options:
             self.set_lean(options['lean'])
+        if 'split_gemm' in options:
+            self.set_split_gemm(options['split_gemm'])
         if 'u8_preprocess' in options:
             k, c, m, w = options['u8_preprocess']
             self.set_u8_preprocess(k, c, m, w)

@@ -46,6 +46,10 @@ def analyse_launch_log(csv_path, steps, flop_per_step):
     rows = [l.strip().split(',') for l in open(csv_path)][1:]
     # seq, stream, Cout, nhalves, K, M, kh, chain, cfg, start, end  (10 ns ticks)
     recs = [(int(r[0]), r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]), int(r[9]), int(r[10])) for r in rows if int(r[9]) > 0 and int(r[10]) > 0]
+    # share of the GEMM FLOPs (2 Cout nhalves K M per launch) that ran on the bf16x6 kernel (configuration 9, conv_gemm.hip K17)
+    fl = [(2.0 * int(r[2]) * int(r[3]) * int(r[4]) * int(r[5]), int(r[8])) for r in rows]
+    split_share = sum(f for f, c in fl if c == 9) / max(sum(f for f, _ in fl), 1.0)
+    split_launches = sum(1 for _, c in fl if c == 9) / float(steps + 2)
     per_step = len(rows) // (steps + 2)
     # window: from the end of recorded step 0 to the end of recorded step `steps` -- exactly `steps` step periods (the forwards of
     # a step run under the previous step's sweep, so a step's own launches span about two periods)
@@ -74,7 +78,8 @@ def analyse_launch_log(csv_path, steps, flop_per_step):
            'avg_launch_ms_in_union': busy * 1e-5 / max(n_in, 1),
            'concurrent_launches_ms_per_step': {str(k): v * 1e-5 / steps for k, v in sorted(hist.items())},
            'achieved_over_union_TFLOPs': flop_per_step / (busy * 1e-8 / steps) / 1e12,
-           'achieved_over_step_TFLOPs': flop_per_step / (span * 1e-8 / steps) / 1e12, 'streams': []}
+           'achieved_over_step_TFLOPs': flop_per_step / (span * 1e-8 / steps) / 1e12, 'streams': [],
+           'split_flop_share': split_share, 'split_launches_per_step': split_launches}
     streams = collections.OrderedDict()
     for r in inside:
         streams.setdefault(r[1], []).append(r)
