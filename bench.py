@@ -483,11 +483,13 @@ def roofline_object(W, step, ms_step, dev, reps=2, launch_log_out=None):
         mixed = 1.0 / (share / (PEAK_BF16_MFMA / 6e12) + (1.0 - share) / peak)
         roof.update({'peak': mixed, 'frac': achieved / mixed, 'frac_vs_fp32_mfma_peak': achieved / peak, 'bf16x6_flop_share': share,
                      'bf16x6_launches_per_step': tl.get('split_launches_per_step'),
-                     'peak_note': 'harmonic mix of the fp32 MFMA peak (%.1f) and the bf16x6 ceiling (%.1f fp32-equivalent TFLOP/s) by FLOP share' % (peak, PEAK_BF16_MFMA / 6e12)})
+                     'frac_timed': roof['achieved_timed'] / mixed, 'frac_serial': roof['achieved_serial'] / mixed,
+                     'peak_note': 'harmonic mix of the fp32 MFMA peak (%.1f) and the bf16x6 ceiling (%.1f fp32-equivalent TFLOP/s = the bf16 MFMA peak / 6) by FLOP '
+                                  'share; every frac* of this object is against it' % (peak, PEAK_BF16_MFMA / 6e12)})
     if clk:
         # 157.3 TFLOP/s is the peak at the nominal 2.4 GHz; what the chip can do at the clock it actually held
         roof['shader_clock_GHz'] = clk
-        roof['peak_sustained'] = 64 * 1024 * clk['p50'] * 1e9 / 1e12
+        roof['peak_sustained'] = roof['peak'] * clk['p50'] / 2.4       # the roofline above at the clock actually held (nominal 2.4 GHz)
         roof['frac_of_sustained'] = achieved / roof['peak_sustained']
     if W.pmc_tag is not None:
         roof.update(pmc_traffic(ROOT, W.pmc_tag))
@@ -516,7 +518,7 @@ def run_secondary(model, dev, steps, warmup, chain_before):
     roof, _, alg_step = roofline_object(W, W.step, ms_step, dev, reps=1)
     n_launch = roof['launches_per_step']
     out = {'model': model, 'metric': W.metric, 'workload': W.work, 'value': W.B * steps / r['dt'], 'unit': 'maps/s', 'ms_per_step': ms_step,
-           'steps': steps, 'warmup': warmup, 'frac_timed': alg_step / (ms_step * 1e-3) / PEAK_F32_MFMA,
+           'steps': steps, 'warmup': warmup, 'frac_timed': roof['frac_timed'],
            'algorithmic_flop_per_step': alg_step, 'gemm_launches_per_step': n_launch,
            'outputs_ok': ok, 'row0_cosine_vs_reference': row0, 'interpreted_chain_launches': interp, 'roofline': roof}
     W.eng.close()
@@ -630,7 +632,7 @@ def main():
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
     ap.add_argument('--inpainting-game', action='store_true', help='only the BASELINE.json configs[4] job mix (one GPU): print its object and exit')
     ap.add_argument('--no-split-leg', action='store_true', help='skip the experimental bf16x6 measurement that rides on the line (experimental_bf16x6)')
-    ap.add_argument('--split-gemm', action='store_true', help='xfr_engine_set_split_gemm(1): bf16x6 GEMMs for the deep-K layers (experimental; A/B against the fp32 MFMA kernels)')
+    ap.add_argument('--split-gemm', type=int, default=None, help='xfr_engine_set_split_gemm(MODE): 0 fp32 MFMA kernels everywhere, 1 bf16x6 forward convolutions of the deep-K layers (the default), 3 the backward-data GEMMs too (experimental)')
     ap.add_argument('--no-lean', action='store_true', help='xfr_engine_set_lean(0): the literal hook operands in every sweep (A/B against the default lean schedule)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
     ap.add_argument('--bind', action='store_true', help='pin every rank to its own CPU set (the GPU\'s NUMA node split among the ranks that share it): 8 launch threads of ~500 launches per step each do not migrate or share cores')
@@ -716,8 +718,8 @@ def run(args, comm):
         eng.set_epilogue_fusion(args.fusion)
     if args.no_lean:
         eng.set_lean(False)
-    if args.split_gemm:
-        eng.set_split_gemm(True)
+    if args.split_gemm is not None:
+        eng.set_split_gemm(args.split_gemm)
     if not args.no_pipeline and not args.serial:
         eng.set_pipeline(_pipe_level(W.pipeline))      # inputs are resident and never modified: the pipelining contract holds
     step = W.step
@@ -803,29 +805,29 @@ def run(args, comm):
             eng.set_epilogue_fusion(True)
             after = chain_stats()
             unfused_leg = {'compiled_launches': after[0] - before[0], 'interpreted_launches': after[1] - before[1]}
-            roof['unfused_epilogues_serial'] = {'achieved': alg_step * reps / (u_ms * 1e-3) / 1e12, 'frac': alg_step * reps / (u_ms * 1e-3) / PEAK_F32_MFMA,
+            roof['unfused_epilogues_serial'] = {'achieved': alg_step * reps / (u_ms * 1e-3) / 1e12, 'frac': alg_step * reps / (u_ms * 1e-3) / (roof['peak'] * 1e12),
                                                 'gemm_ms_per_step': u_ms / reps, 'avg_launch_ms': u_ms / max(u_n, 1)}
 
-    # the same step with the deep-K convolutions on the bf16 matrix pipe (xfr_engine_set_split_gemm, conv_gemm.hip K17: every fp32 operand as three bf16
-    # pieces, six exact piece products, fp32 accumulation).  EXPERIMENTAL and never `value`: its GEMMs are 1.5-3x noisier than the fp32 MFMA kernels' (rms
-    # against float64), which the ill-conditioned contrast of the fixture triplet shows -- reported with the same output checks as the headline.
+    # the same step in the other two modes of xfr_engine_set_split_gemm (conv_gemm.hip K17; the headline runs the default, mode 1: the FORWARD convolutions of
+    # the deep-K layers as bf16x6 on the bf16 matrix pipe).  mode 0: fp32 MFMA kernels everywhere.  mode 3: the sweep's backward-data GEMMs as bf16x6 too --
+    # experimental: their noise (rms 1.5-3x the fp32 kernels' against float64) is what an ill-conditioned contrast amplifies.  Same output checks as the headline.
     split_leg = None
-    if rank == 0 and world == 1 and not args.serial and not args.split_gemm and not args.no_split_leg:
-        try:
-            before = eng.split_gemm_launches()
-            eng.set_split_gemm(True)
-            rs = timed_loop(W, args.steps, max(args.warmup, 3), barrier, world, dev, comm)
-            n_split = (eng.split_gemm_launches() - before) / float(args.steps + max(args.warmup, 3))
-            row0s = fixture_cosine(rs['sal'][0], W.fixture) if W.fixture else None
-            split_leg = {'maps_s': B * args.steps / rs['dt'], 'ms_per_step': 1e3 * rs['dt'] / args.steps, 'bf16x6_launches_per_step': n_split,
-                         'outputs_finite_and_normalised': bool(rs['ok']), 'row0_cosine_vs_reference': row0s,
-                         'row0_check_passes': (row0s is not None and row0s >= ROW0_COS) if W.fixture else None,
-                         'what': 'xfr_engine_set_split_gemm(1): stride-1 convolutions with K >= 1024 (1x1) / K >= 1152 (KxK) on 14 x 14 and larger maps run as bf16x6 '
-                                 'on the bf16 MFMA pipe (six v_mfma_f32_32x32x16_bf16 per K = 16 instead of eight fp32 MFMAs per K = 16); off by default'}
-        except Exception as ex:      # the experimental leg never fails the line
-            split_leg = {'error': repr(ex)}
-        finally:
-            eng.set_split_gemm(False)
+    if rank == 0 and world == 1 and not args.serial and args.split_gemm is None and not args.no_split_leg:
+        split_leg = {}
+        for name, mode in (('fp32_mfma_only', 0), ('experimental_bf16x6_backward_too', 3)):
+            try:
+                before = eng.split_gemm_launches()
+                eng.set_split_gemm(mode)
+                rs = timed_loop(W, args.steps, max(args.warmup, 3), barrier, world, dev, comm)
+                n_split = (eng.split_gemm_launches() - before) / float(args.steps + max(args.warmup, 3))
+                row0s = fixture_cosine(rs['sal'][0], W.fixture) if W.fixture else None
+                split_leg[name] = {'mode': mode, 'maps_s': B * args.steps / rs['dt'], 'ms_per_step': 1e3 * rs['dt'] / args.steps, 'bf16x6_launches_per_step': n_split,
+                                   'outputs_finite_and_normalised': bool(rs['ok']), 'row0_cosine_vs_reference': row0s,
+                                   'row0_check_passes': (row0s is not None and row0s >= ROW0_COS) if W.fixture else None}
+            except Exception as ex:      # these legs never fail the line
+                split_leg[name] = {'mode': mode, 'error': repr(ex)}
+            finally:
+                eng.set_split_gemm(1)
 
     secondary = None
     if rank == 0 and world == 1 and args.model == 'resnet101' and not args.no_secondary and not args.serial and args.batch is None and args.mode is None:
@@ -853,6 +855,9 @@ def run(args, comm):
             'metric': W.metric, 'value': value, 'unit': 'maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            'dtype_note': 'fp32 storage, operands and accumulation throughout.  GEMMs: v_mfma_f32_32x32x2_f32; the forward convolutions of the deep-K stride-1 layers '
+                          '(xfr_engine_set_split_gemm mode %s) as bf16x6 -- every fp32 operand as the exact sum of three bf16 pieces, six exact piece products, fp32 '
+                          'accumulation (conv_gemm.hip K17; split_gemm_modes.fp32_mfma_only is the same step on fp32 MFMAs alone)' % (args.split_gemm if args.split_gemm is not None else 1),
             'config': {'workload': W.work, 'units_per_gpu': B,
                        'parallelism': 'independent triplets, %d process(es), weights broadcast once' % world},
             'outputs_ok': ok, 'row0_cosine_vs_reference': row0,
@@ -872,7 +877,7 @@ def run(args, comm):
         if u8_e2e is not None:
             line['u8_end_to_end'] = u8_e2e
         if split_leg is not None:
-            line['experimental_bf16x6'] = split_leg
+            line['split_gemm_modes'] = split_leg
         if sustained is not None:
             line['sustained_maps_s'] = world * sustained['maps_s']
             line['sustained'] = sustained

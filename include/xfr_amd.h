@@ -298,13 +298,16 @@ xfr_status xfr_debug_u8_preprocess(xfr_engine* e, const uint8_t* x_u8_dev, int32
  * always run literal, so a sample's map can differ in its last digits between a batch of 32 and a batch of 1: callers that need batch-invariant
  * arithmetic switch this off together with xfr_engine_set_tail_balance. */
 xfr_status xfr_engine_set_lean(xfr_engine* e, int32_t enable);
-/* bf16x6 GEMMs (off by default; ABI version 5; experimental).  The deep-K stride-1 convolutions of 14 x 14 and larger maps (K >= 1024 for 1x1,
- * K >= 1152 for KxK, 128 | Cout) run on the bf16 matrix pipe: every fp32 operand is the exact sum of three bf16 pieces, the six piece products of
- * order <= 2 are accumulated in fp32 (conv_gemm.hip K17).  Results differ from the fp32 MFMA kernels like a different summation order does (~1e-6 of
- * a launch's largest output; DESIGN.md section 4 K17 for the maps); the choice is a property of the layer, never of the batch.  The weight packs of
- * those layers get bf16 planes at their first launch (+1.5x their size); every entry point that changes the weights (or hands out the arena,
- * xfr_engine_weight_arena -- call it again after later writes) drops them.  XFR_SPLIT_GEMM=1 in the environment switches new engines on. */
-xfr_status xfr_engine_set_split_gemm(xfr_engine* e, int32_t enable);
+/* bf16x6 GEMMs (ABI version 5).  The deep-K stride-1 convolutions of 14 x 14 and larger maps (K >= 1024 for 1x1, K >= 1152 for KxK, 128 | Cout) can run
+ * on the bf16 matrix pipe: every fp32 operand is the exact sum of three bf16 pieces, the six piece products of order <= 2 are exact and are accumulated in
+ * fp32 (conv_gemm.hip K17).  A launch differs from the fp32 MFMA kernels like a different (somewhat noisier: rms 1.5-3x against float64) summation order.
+ * mode 1 (the default): the FORWARD convolutions of those layers -- golden maps as close to the reference as with the fp32 kernels (DESIGN.md section 4
+ * K17), ResNet-101 +9 % maps/s.  mode 3: the sweep's backward-data GEMMs too (+15 %; experimental: their noise is amplified by an ill-conditioned contrast,
+ * contrastive maps move by up to 1.5e-3 of their maximum).  mode 2: backward only (tuning).  mode 0: fp32 MFMA kernels everywhere.  The choice is a property of
+ * the layer and this setting, never of the batch.  The weight packs of the covered layers get bf16 planes at their first launch (+1.5x their size);
+ * every entry point that changes the weights (or hands out the arena: xfr_engine_weight_arena -- call it again after later writes through its pointer)
+ * drops them.  XFR_SPLIT_GEMM=<mode> in the environment sets the mode of new engines. */
+xfr_status xfr_engine_set_split_gemm(xfr_engine* e, int32_t mode);
 /* Launches of the bf16x6 kernel so far, process-wide. */
 xfr_status xfr_engine_split_gemm_stats(xfr_engine* e, int64_t* launches);
 

@@ -256,8 +256,9 @@ def test_golden_contrastive_cases_on_the_lean_schedule(gpu_device, arch, mode):
 
 @pytest.mark.parametrize('arch,mode', [('stresnet101', 'affineonly_with_prior'), ('stresnet101', 'norelu'), ('resnet50_128', 'norelu')])
 def test_golden_cases_on_the_split_gemm(gpu_device, arch, mode):
-    """xfr_engine_set_split_gemm(1): the deep-K convolutions on the bf16 matrix pipe (bf16x6, conv_gemm.hip K17).  The golden cases of the ResNets once
-    more with it on -- same vectors from the real reference, same tolerances as the fp32 MFMA kernels are held to; the kernel's launches are counted."""
+    """xfr_engine_set_split_gemm(3): forward convolutions AND the sweep's backward-data GEMMs of the deep-K layers on the bf16 matrix pipe (bf16x6,
+    conv_gemm.hip K17; the default, mode 1, covers the forward convolutions only and is what every other golden test runs).  The golden cases of the
+    ResNets once more in that experimental mode -- same vectors from the real reference, same tolerances; the kernel's launches are counted."""
     if arch == 'stresnet101':
         gold, cases = GC.golden('golden_r101'), GC.r101_cases(mode)
         bb, sd = make_backbone(arch, seed=0, num_classes=65359)
@@ -266,7 +267,7 @@ def test_golden_cases_on_the_split_gemm(gpu_device, arch, mode):
         bb, sd = make_backbone(arch, seed=0)
     subj = GC.engine_subject(arch, bb, mode)
     eng = subj.wb._engine(1)
-    eng.set_split_gemm(True)
+    eng.set_split_gemm(3)
     before = eng.split_gemm_launches()
     inner = _check_factory()
 
@@ -284,7 +285,8 @@ def test_golden_cases_on_the_split_gemm(gpu_device, arch, mode):
 
 @pytest.mark.parametrize('arch,mode', [('stresnet101', 'affineonly_with_prior'), ('resnet50_128', 'norelu')])
 def test_split_gemm_equals_fp32_kernels(gpu_device, arch, mode):
-    """The bf16x6 kernel against the fp32 MFMA kernels on the same engine, same inputs: every fp32 operand is the exact sum of three bf16 pieces and
+    """The bf16x6 kernel (mode 1: forward convolutions, the default; mode 3: backward-data GEMMs too) against the fp32 MFMA kernels (mode 0) on the same
+    engine, same inputs: every fp32 operand is the exact sum of three bf16 pieces and
     the six piece products of order <= 2 are exact in fp32; what differs is the bf16 MFMA's own summation (rms error against float64 1.5-3x the fp32
     kernels', tools/conv_error_probe.py; its one-sided part is cancelled by the kernel's sign phases).  Encodings 1e-5, plain-EBP maps 5e-5 of the
     maximum (measured 5e-7 .. 2e-5), contrastive maps (a difference of nearly equal tensors: parity_utils) LEAN_RTOL_CONTRAST (measured 5e-6 .. 1.5e-3)."""
@@ -299,29 +301,30 @@ def test_split_gemm_equals_fp32_kernels(gpu_device, arch, mode):
     subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
     eng = wb._engine(2 * n)
     res, launches = {}, {}
-    for split in (1, 0):
+    for split in (3, 1, 0):
         eng.set_split_gemm(split)
         before = eng.split_gemm_launches()
         res[split] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
                       wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone(),
                       torch.as_tensor(wb.ebp(x, torch.tensor([[1.0, 0.0]]))))
         launches[split] = eng.split_gemm_launches() - before
-    assert launches[1] > 0 and launches[0] == 0, launches
-    e1, e0 = res[1][0].float().cpu(), res[0][0].float().cpu()
-    assert float((e1 - e0).abs().max()) <= 1e-5 * float(e0.abs().max())
-    for what, a, b in zip(('contrastive (triplet entry)', 'truncated (triplet entry)', 'ebp'), res[1][1:], res[0][1:]):
-        a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
-        for i in range(a.shape[0]):
-            tag = '%s/%s bf16x6 against fp32: %s row %d' % (arch, mode, what, i)
-            rel, cos = map_metrics(a[i], b[i])
-            PARITY_REPORT['split-vs-fp32/' + tag] = {'max_abs_diff_over_max': float(rel), 'cosine': float(cos), 'criterion': 'against the fp32 kernels'}
-            if what == 'ebp':
-                assert_map_close(a[i], b[i], tag, rtol=5e-5)
-            elif what.startswith('truncated'):
-                assert_map_close_robust(a[i], b[i], tag, rtol=LEAN_RTOL_CONTRAST)
-            else:
-                assert_map_close(a[i], b[i], tag, rtol=LEAN_RTOL_CONTRAST)
-    eng.set_split_gemm(0)
+    eng.set_split_gemm(1)
+    assert launches[3] > launches[1] > 0 and launches[0] == 0, launches
+    for split in (3, 1):
+        e1, e0 = res[split][0].float().cpu(), res[0][0].float().cpu()
+        assert float((e1 - e0).abs().max()) <= 1e-5 * float(e0.abs().max())
+        for what, a, b in zip(('contrastive (triplet entry)', 'truncated (triplet entry)', 'ebp'), res[split][1:], res[0][1:]):
+            a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+            for i in range(a.shape[0]):
+                tag = '%s/%s bf16x6 mode %d against fp32: %s row %d' % (arch, mode, split, what, i)
+                rel, cos = map_metrics(a[i], b[i])
+                PARITY_REPORT['split-vs-fp32/' + tag] = {'max_abs_diff_over_max': float(rel), 'cosine': float(cos), 'criterion': 'against the fp32 kernels'}
+                if what == 'ebp':
+                    assert_map_close(a[i], b[i], tag, rtol=5e-5)
+                elif what.startswith('truncated'):
+                    assert_map_close_robust(a[i], b[i], tag, rtol=LEAN_RTOL_CONTRAST)
+                else:
+                    assert_map_close(a[i], b[i], tag, rtol=LEAN_RTOL_CONTRAST)
 
 
 # ---- oracle on fresh seeded inputs, batched ----------------------------------------------------------------------------
@@ -754,6 +757,8 @@ def test_lean_schedule_equals_literal(gpu_device, arch, mode, n):
     xn = (synth.unit_rows(n, D, seed=4) / 2500).to(gpu_device)
     subj.set_cls(xm[:1].cpu(), xn[:1].cpu())
     eng = wb._engine(2 * n)
+    eng.set_split_gemm(0)          # the lean transformation by itself: with bf16x6 forward convolutions (the default) the literal probe forward of a
+                                   # K = 1152 layer is a bf16x6 dual launch where the lean one is the fp32 two-accumulator launch -- another 2e-5
     res, launches = {}, {}
     for lean in (1, 0):
         eng.set_lean(lean)

@@ -273,6 +273,7 @@ struct ConvParams {
     int dualacc;        // 1 (nhalves == 1): every workgroup accumulates W AND relu(W) -- taken from the W fragment in registers, no second pack is read -- over the
                         // same staged input tile; the chain (compiled, first step EW_LEAN_Q) sees both.  The lean probe forward: bias_pos is the second bias
     int relu_in;        // clamp the gathered input at 0 (A = relu(input))
+    int bwd;            // 1: a backward-data GEMM of the sweep (bwd_conv_params); 0: a forward convolution
     int split_ok;       // 1: the launch may take the bf16x6 kernel (conv_gemm.hip K17) where the layer is one it covers (xfr_engine_set_split_gemm)
     int accumulate;     // out += result
     int out_H, out_W, out_stride;  // out_stride > 1: scatter the (OH,OW) grid into an (out_H,out_W) tensor

@@ -223,7 +223,8 @@ struct xfr_engine {
     bool u8_on = false;
     bool u8_set = false;
     U8Pre u8_pre;
-    bool split_gemm = false;           // xfr_engine_set_split_gemm: covered layers run the bf16x6 kernel (conv_gemm.hip K17)
+    int split_mask = 1;                // xfr_engine_set_split_gemm: which covered layers run the bf16x6 kernel (conv_gemm.hip K17) -- bit 0 the forward
+                                       // convolutions (default), bit 1 the sweep's backward-data GEMMs (experimental: their noise shows in contrastive maps)
     bool lean = true;                  // xfr_engine_set_lean: plain sweeps (no trace / prior / capture / stored firing, batch % 4 == 0) take the lean schedule
     const BwdPlan* lean_cur = nullptr; // the plan whose lean tables the running probe forward / sweep follow (null: literal)
     bool lean_decide = false;          // lean_prepare's dry run of the probe forward: decide per convolution, record in lean_q_run / lean_final_run
@@ -604,7 +605,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
     p.chain_interpret = e->interpret_chains ? 1 : 0;
-    p.split_ok = e->split_gemm ? 1 : 0;
+    p.split_ok = (e->split_mask & (p.bwd ? 2 : 1)) ? 1 : 0;
     p.tail_force = 1;
     if (e->tail_balance) {
         p.tail_force = 0;
@@ -2144,6 +2145,7 @@ void bwd_conv_params(xfr_engine* e, const BwdPlan& plan, const BwdStep& st, int 
         if (e->pair_tiles && SBa == 2 * B) p.pair_m = B * p.OH * p.OW;     // the two streams' tiles of one position side by side (ConvParams::pair_m)
     }
     p.chain_interpret = e->interpret_chains ? 1 : 0;
+    p.bwd = 1;
 }
 
 // The fan-out schedule (plan.fused_gemm: MaxFeatureMap VJPs inside GEMM epilogues) only runs where every such epilogue is COMPILED --
@@ -2412,7 +2414,7 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     if (st == XFR_OK) st = layout_arena(e);
     if (st == XFR_OK) st = allocate(e);
     if (st != XFR_OK) { xfr_engine_destroy(e); return st; }
-    if (const char* v = getenv("XFR_SPLIT_GEMM")) e->split_gemm = atoi(v) != 0;      // A/B runs; the API is xfr_engine_set_split_gemm
+    if (const char* v = getenv("XFR_SPLIT_GEMM")) e->split_mask = atoi(v) & 3;      // A/B runs: the mode of xfr_engine_set_split_gemm for new engines
     *out = e;
     return XFR_OK;
 }
@@ -2895,10 +2897,11 @@ xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable)
     return XFR_OK;
 }
 
-xfr_status xfr_engine_set_split_gemm(xfr_engine* e, int32_t enable)
+xfr_status xfr_engine_set_split_gemm(xfr_engine* e, int32_t mode)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
-    e->split_gemm = enable != 0;
+    if (mode < 0 || mode > 3) return fail(XFR_INVALID_ARG, "xfr_engine_set_split_gemm: mode 0 (off), 1 (forward convolutions), 2 (backward-data GEMMs), 3 (both)");
+    e->split_mask = mode;
     e->held_x = nullptr;
     return XFR_OK;
 }

@@ -276,10 +276,12 @@ class Engine(object):
         _lib.check(self.lib.xfr_engine_set_lean(self._h, int(bool(on))))
         self.options['lean'] = bool(on)
 
-    def set_split_gemm(self, on):
-        """bf16x6 GEMMs for the deep-K stride-1 convolutions (default off; experimental; include/xfr_amd.h, conv_gemm.hip K17)."""
-        _lib.check(self.lib.xfr_engine_set_split_gemm(self._h, int(bool(on))))
-        self.options['split_gemm'] = bool(on)
+    def set_split_gemm(self, mode):
+        """bf16x6 GEMMs for the deep-K stride-1 convolutions (include/xfr_amd.h, conv_gemm.hip K17): 0 / False off, 1 / True the forward convolutions
+        (the default), 2 the sweep's backward-data GEMMs, 3 both (experimental)."""
+        mode = int(mode)
+        _lib.check(self.lib.xfr_engine_set_split_gemm(self._h, mode))
+        self.options['split_gemm'] = mode
 
     def split_gemm_launches(self):
         """Launches of the bf16x6 kernel so far (process-wide)."""
