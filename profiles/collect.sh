@@ -73,6 +73,12 @@ python profiles/frac_from_launch_log.py $P/launch_log_r50.csv --alg-gflop 2961.4
 for rep in 1 2; do for m in resnet101 resnet50_128; do for f in "" "--no-lean"; do
   python bench.py --model $m $f --no-cpu-baseline --no-secondary --no-sustained --no-profile --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m [$f]', round(d['value'],1), 'maps/s', round(d['ms_per_step'],3), 'ms')"
 done; done; done > $P/lean_ab.txt
+# bf16x6 modes (xfr_engine_set_split_gemm; 1 = the default: forward convolutions) on this box, alternating; GEMM error of the kernels against float64
+for rep in 1 2; do for m in resnet101 resnet50_128; do for f in "--split-gemm 0" "" "--split-gemm 3"; do
+  python bench.py --model $m $f --no-split-leg --no-cpu-baseline --no-secondary --no-sustained --no-profile --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m [$f]', round(d['value'],1), 'maps/s', round(d['ms_per_step'],3), 'ms', 'outputs_ok', d['outputs_ok'], '1-cos(row 0)', 1-d['row0_cosine_vs_reference'])"
+done; done; done > $P/split_gemm_ab.txt
+python tools/conv_error_probe.py 2> /dev/null | grep -v amdgpu > $P/conv_error_probe.txt
+python tools/conv_sweep.py --cfgs 7,4,9 --reps 200 --only 0,1,3,10 2> /dev/null | grep -v amdgpu > $P/conv_sweep_bf16x6.txt
 python bench.py --inpainting-game > $P/bench_inpainting_game.json 2> /dev/null
 python tools/subtree_probe.py --log 2> /dev/null | grep -v amdgpu > $P/weighted_subtree_probe.txt
 rocprofv3 $ST -d $D/subtree -o $R -- python tools/subtree_probe.py --reps 5 > /dev/null 2> $D/subtree.err

@@ -1155,6 +1155,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
+    stamp(p, wave, lane, 0, 2);       // tuning stamps / the launch log's span record, like K1
 
     const int lid = xcd_remap(blockIdx.x, n_co_tiles * n_m_tiles);
     const int tile_m = lid / n_co_tiles;
@@ -1243,12 +1244,11 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
     };
     // Sign phases.  The bf16 MFMA does not round its sum to nearest like the fp32 MFMA (an fmaf chain) does: measured against float64, every output of a
     // bf16x6 GEMM sits ~4e-9 of its sum of magnitudes BELOW the exact value (fp32 kernels: 2e-11, either sign) -- 0.1 of the rms error, but of one sign in
-    // every element of every layer, which a contrastive map amplifies.  So every SP_PHASE K-steps the sum changes sign: X pieces are stored negated (one
-    // XOR per word) and the accumulators are negated in place (exact); the hardware's downward error then pushes the true sum UP, and the two cancel.
-    constexpr int SP_PHASE = 4;
-    auto phase_neg = [](int kt) { return ((kt / SP_PHASE) & 1) != 0; };
+    // every element of every layer, which a contrastive map amplifies.  So the sum changes sign with every pass of the loop below (three K-steps): X pieces
+    // are stored negated (one XOR per word), the accumulators negated in place (exact); the hardware's downward error then pushes the true sum UP, and the
+    // two cancel.  `flip`: the sign-bit mask of the phase the step's X slab (step kt+1) belongs to.
     // one K-step; ST = kt % 3 (static), xcur = X(kt+1) registers (split here), xnew = registers that receive X(kt+3)
-    auto step = [&](int kt, auto ST, float (&xcur)[8], float (&xnew)[8]) {
+    auto step = [&](int kt, auto ST, float (&xcur)[8], float (&xnew)[8], unsigned flip) {
         constexpr int st = decltype(ST)::value, st1 = (st + 1) % 3, st2 = (st + 2) % 3;
         load_w(kt + 2, st2);
         load_x(kt + 3, xnew);
@@ -1271,17 +1271,17 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], acc[i][j], 0, 0, 0);
-        store_x(xcur, st1, phase_neg(kt + 1) ? 0x80008000u : 0u);
-        if (phase_neg(kt + 1) != phase_neg(kt)) {       // wave-uniform, every SP_PHASE steps: the accumulators change sign with the products
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
-        }
+        store_x(xcur, st1, flip);
         // W(kt+1) (issued during step kt-1) has landed when at most X(kt+2), W(kt+2), X(kt+3) are outstanding: 8 + 3 + 8
         asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    auto negate_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
     };
     float x0[8], x1[8], x2[8];
     load_w(0, 0);
@@ -1291,22 +1291,21 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
     load_x(1, x0);
     load_x(2, x1);
     asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // W(0) and the split of X(0) are in LDS
+    stamp(p, wave, lane, 1);
     std::integral_constant<int, 0> S0; std::integral_constant<int, 1> S1; std::integral_constant<int, 2> S2;
+    unsigned flip = 0u;                         // the current pass's phase
     for (int kt = 0; kt < nk; kt += 3) {        // up to two steps past the end multiply zeros: no branch on kt inside the body
-        step(kt, S0, x0, x2);
-        step(kt + 1, S1, x1, x0);
-        step(kt + 2, S2, x2, x1);
+        step(kt, S0, x0, x2, flip);
+        step(kt + 1, S1, x1, x0, flip);
+        flip ^= 0x80008000u;
+        step(kt + 2, S2, x2, x1, flip);         // its X slab is the next pass's first
+        negate_acc();
     }
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (phase_neg(((nk + 2) / 3) * 3)) {        // the phase the loop ended in (the last step already switched to the phase of the step after it)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
-    }
+    if (flip) negate_acc();                     // an odd number of passes
+    stamp(p, wave, lane, 2);
+    stamp(p, wave, lane, 3);
 
     // the four 64 x 64 sub-tiles leave through the epilogues of K1 (each starts with a workgroup barrier before it reuses the LDS).  A REAL loop -- one
     // epilogue instance in the code, not four (the compiled-chain family is 86 signatures) -- over a fixed register tile: the other three shift down.
@@ -1319,6 +1318,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
         acc[0][1] = acc[1][0];
         acc[1][0] = acc[1][1];
     }
+    stamp(p, wave, lane, 4);
 }
 
 // W[k][ldw] fp32 (k rows, output channel = column) -> bf16 planes [cout / 128][K / 16][piece][k half][128][8]
