@@ -1327,18 +1327,12 @@ __global__ void split_pack_kernel(const float* __restrict__ w, uint16_t* __restr
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)K * cout) return;
     const int k = (int)(idx / cout), co = (int)(idx - (long)k * cout);
-    unsigned h[3], dummy = 0;
-    {
-        const float v = w[(long)k * ldw + co];
-        unsigned q0, q1, q2;
-        split_pair(v, 0.f, q0, q1, q2);          // the value in the low half
-        h[0] = q0 & 0xffffu; h[1] = q1 & 0xffffu; h[2] = q2 & 0xffffu;
-        (void)dummy;
-    }
+    unsigned h[3];
+    split_pair(w[(long)k * ldw + co], 0.f, h[0], h[1], h[2]);          // the value's pieces in the low halves
     const int rt = co / SP_T, r = co - rt * SP_T, kt = k / SP_BK, kk = k - kt * SP_BK, nk = K / SP_BK;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-        planes[((((long)(rt * nk + kt) * 3 + q) * 2 + kk / 8) * SP_T + r) * 8 + kk % 8] = (uint16_t)h[q];
+        planes[((((long)(rt * nk + kt) * 3 + q) * 2 + kk / 8) * SP_T + r) * 8 + kk % 8] = (uint16_t)(h[q] & 0xffffu);
 }
 
 int num_cus()
@@ -1559,7 +1553,12 @@ const uint16_t* split_planes(const float* w, int K, int cout, int ldw, hipStream
     auto it = g_split.find(w);
     if (it != g_split.end()) return (it->second.K == K && it->second.cout == cout && it->second.ldw == ldw) ? it->second.planes : nullptr;
     SplitPack sp{nullptr, K, cout, ldw};
-    if (hipMalloc(&sp.planes, (size_t)K * cout * 3 * sizeof(uint16_t)) != hipSuccess) return nullptr;
+    if (hipMalloc(&sp.planes, (size_t)K * cout * 3 * sizeof(uint16_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        sp.planes = nullptr;
+        g_split[w] = sp;                 // no memory for the planes: this pack stays on the fp32 kernels (until conv_gemm_forget_split) instead of retrying per launch
+        return nullptr;
+    }
     const long n = (long)K * cout;
     hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, sp.planes, K, cout, ldw);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(sp.planes); return nullptr; }
@@ -1570,10 +1569,15 @@ const uint16_t* split_planes(const float* w, int K, int cout, int ldw, hipStream
 template <bool RELU, int CHAIN>
 void launch_split_inst(const ConvParams& q, const uint16_t* w0, const uint16_t* w1, int grid, int n_co, int n_m, hipStream_t s)
 {
-    static const bool attr = [] {      // once per instantiation: the kernel's 72 KB of dynamic LDS exceed the default limit
-        return hipFuncSetAttribute((const void*)conv_gemm_split_kernel<RELU, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_LDS) == hipSuccess;
-    }();
-    (void)attr;
+    // once per instantiation AND device: the kernel's 72 KB of dynamic LDS exceed the default limit
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<RELU, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_LDS);
+        done.fetch_or(bit);
+    }
     hipLaunchKernelGGL((conv_gemm_split_kernel<RELU, CHAIN>), dim3(grid), dim3(NT), SP_LDS, s, q, w0, w1, n_co, n_m);
 }
 
