@@ -298,8 +298,8 @@ void conv_gemm_set_stamps(unsigned long long* dev_ptr, int capacity_workgroups);
 void conv_gemm_set_log(unsigned long long* log_dev, int capacity);
 int conv_gemm_dump_log(const char* path);   // every later launch_conv_gemm records into dev_ptr (nullptr: stop)
 
-constexpr int XFR_TAIL_MAX_TILES = 256;
-constexpr size_t XFR_TAIL_WS_BYTES = (size_t)16 << 20;
+constexpr int XFR_TAIL_MAX_TILES = 2048;        // arrival counters per stream: K1's tail tiles (<= the CU count) and K17's stream-K tiles
+constexpr size_t XFR_TAIL_WS_BYTES = (size_t)32 << 20;      // K17 stream-K: two parked 128 x 128 parts per CU (256 x 2 x 64 KB)
 // false: nothing was launched -- a dual (W / relu(W)) launch carries a chain for which no compiled epilogue exists
 bool launch_conv_gemm(const ConvParams& p, hipStream_t s);
 // 0 if launch_conv_gemm will accept p's fused chain, else why not (text: conv_gemm_refusal): 1 = dual launch without a compiled epilogue,

@@ -37,458 +37,12 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "conv_epilogue.h"
+#include "conv_gemm_dev.h"
+#include "conv_gemm_host.h"
+
+std::atomic<long> g_conv_chain_launches[2];
 
 namespace {
-
-constexpr int NT = 256;
-std::atomic<long> g_chain_launches[2];   // GEMM launches with a fused chain: [0] compiled epilogue, [1] interpreted (engines may run on several host threads)
-
-enum { MODE_VEC = 0, MODE_TAP = 1, MODE_GEN = 2, MODE_TAP4 = 3 };
-
-// Epilogue of one wave's 32x32 accumulator tile for a chain with signature SIG.  A lane owns, for each of the four 8-channel
-// groups hf, one float4 piece (channel hf*8 + lane/8, positions 4*(lane%8)..+3).  The operand loads of groups 0 and 1 are
-// issued first -- before the accumulators are turned through LDS -- and those of group hf+2 right after group hf's have been
-// consumed, so two groups' worth of HBM requests are in flight per lane instead of one dependent round trip per group.
-// Lean probe-forward signatures (sig_is_dual): accp is the wave's relu(W) accumulator tile of the same quadrant; it is turned through the same LDS
-// tile first and kept as four pieces (+ bias_pos) in registers.
-template <int SIG>
-__device__ __forceinline__ void chain_epilogue(const ConvParams& p, const v16f& acc, const v16f* accp, float* tile, int lane, int l31, int lhi,
-                                               int co_base, int m, float* __restrict__ osel, const float* __restrict__ bsel)
-{
-    constexpr int LD = 36;
-    const int ohw = p.OH * p.OW;
-    // piece (float4) indices fit 32 bits: every tensor is smaller than 2 GiB (checked when the workspace is laid out)
-    const unsigned row4 = (unsigned)(p.out_nb * ohw) / 4u, arow4 = (unsigned)(p.chain_B * ohw) / 4u;
-    const int mq = (lane & 7) * 4;
-    const bool m_ok = m < p.M;
-    const int mm = m_ok ? m : 0;
-    const unsigned acol4 = (unsigned)(mm % (p.chain_B * ohw)) / 4u;      // forward-side column of this piece: sample sb % B, same position
-    EpiOps ops[4];
-    unsigned idx4[4], aidx4[4];
-    int cos[4];
-    bool ok[4];
-#pragma unroll
-    for (int hf = 0; hf < 4; ++hf) {
-        cos[hf] = co_base + hf * 8 + (lane >> 3);
-        ok[hf] = cos[hf] < p.CoutTot && m_ok;
-        const int cc = ok[hf] ? out_row(p, cos[hf]) : 0;
-        idx4[hf] = (unsigned)cc * row4 + (unsigned)mm / 4u;
-        aidx4[hf] = (unsigned)cc * arow4 + acol4;
-    }
-    // channel groups in flight: two for chains with at most two operand tensors, one otherwise -- measured on MI355X: 1 and 2
-    // groups time the same (26.5 ms per step), 4 cost occupancy (27.4 ms); one group for the wide chains keeps the kernel at
-    // 64-65 VGPRs (5-6 waves per SIMD)
-    constexpr unsigned live_slots = sig_live_slots<SIG>();
-    constexpr int n_live = __builtin_popcount(live_slots);
-    constexpr int DEPTH = n_live >= 3 ? 1 : 2;
-#pragma unroll
-    for (int hf = 0; hf < DEPTH; ++hf) epi_load<SIG>(ops[hf], p, idx4[hf], aidx4[hf], ok[hf] ? cos[hf] : 0);
-    // every wave is done reading the ring (its LDS reads fed MFMAs that have retired); a raw barrier, not
-    // __syncthreads(): that one would first drain the operand loads just issued
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    float4 gpv[4];
-    if constexpr (sig_is_dual<SIG>()) {
-        // the tile is this wave's own: its LDS operations execute in order, the waits only keep the compiler from moving them
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = (*accp)[r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int hf = 0; hf < 4; ++hf) {
-            gpv[hf] = *reinterpret_cast<const float4*>(tile + (hf * 8 + (lane >> 3)) * LD + mq);
-            if (p.bias_pos && ok[hf]) { const float b = p.bias_pos[cos[hf]]; gpv[hf].x += b; gpv[hf].y += b; gpv[hf].z += b; gpv[hf].w += b; }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = acc[r];
-    float4* out4 = reinterpret_cast<float4*>(osel);
-#pragma unroll
-    for (int hf = 0; hf < 4; ++hf) {
-        const int cl = hf * 8 + (lane >> 3);
-        const float4 gv = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
-        float g[4] = {gv.x, gv.y, gv.z, gv.w};
-        LeanRegs lr;
-        if constexpr (sig_is_dual<SIG>()) { lr.gp[0] = gpv[hf].x; lr.gp[1] = gpv[hf].y; lr.gp[2] = gpv[hf].z; lr.gp[3] = gpv[hf].w; }
-        if (bsel && ok[hf]) { const float b = bsel[cos[hf]]; g[0] += b; g[1] += b; g[2] += b; g[3] += b; }
-        if constexpr (sig_has_maxpair<SIG>()) {
-            float4 w = *reinterpret_cast<const float4*>(tile + (cl ^ 1) * LD + mq);
-            if (bsel && ok[hf]) { const float b = bsel[cos[hf] ^ 1]; w.x += b; w.y += b; w.z += b; w.w += b; }
-            ops[hf].partner = w;
-            ops[hf].co_idx4 = (cos[hf] & 1) ? ~0u : (unsigned)(cos[hf] >> 1) * row4 + (unsigned)mm / 4u;
-        }
-        if constexpr (sig_has_fanout<SIG>()) { ops[hf].out4 = out4; ops[hf].row4 = row4; ops[hf].arow4 = arow4; }
-        if (ok[hf]) {
-            float sv[4] = {0.f, 0.f, 0.f, 0.f};
-            epi_steps<SIG, 0>(g, sv, lr, ops[hf], p.chain, idx4[hf], aidx4[hf], p.chain_eps);
-            if constexpr (sig_has_fanout<SIG>()) {
-                // stored by the fan-out
-            } else if constexpr (sig_has_maxpair<SIG>()) {
-                // both rows of a pair hold the maximum now; the even row stores it as channel cos / 2 of the Co-channel output
-                if ((cos[hf] & 1) == 0) out4[(unsigned)(cos[hf] >> 1) * row4 + (unsigned)mm / 4u] = make_float4(g[0], g[1], g[2], g[3]);
-            } else {
-                out4[idx4[hf]] = make_float4(g[0], g[1], g[2], g[3]);
-            }
-        }
-        if (hf + DEPTH < 4) epi_load<SIG>(ops[hf + DEPTH], p, idx4[hf + DEPTH], aidx4[hf + DEPTH], ok[hf + DEPTH] ? cos[hf + DEPTH] : 0);
-    }
-}
-
-// Dense output rows without a chain: turn the wave's 32x32 accumulator tile through LDS (the ring is free) so that a lane holds
-// four consecutive m of one channel and the tile leaves in 4 dwordx4 stores per lane instead of 16 dword stores (8 x 128-byte
-// rows per store instruction instead of 2).
-__device__ __forceinline__ void dense_epilogue(const ConvParams& p, const v16f& acc, float* tile, int lane, int l31, int lhi, int co_base,
-                                               int m, float* __restrict__ osel, const float* __restrict__ bsel)
-{
-    constexpr int LD = 36;                                   // row pitch in floats: 16-byte aligned rows, no bank clash
-    __syncthreads();                                         // every wave is done reading the ring
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = acc[r];
-    const long row_stride = (long)p.out_nb * p.OH * p.OW;
-    const int mq = (lane & 7) * 4;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int cl = it * 8 + (lane >> 3);
-        const int co = co_base + cl;
-        float4 v = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
-        if (co < p.CoutTot && m < p.M) {
-            float4* dst = reinterpret_cast<float4*>(osel + (long)out_row(p, co) * row_stride + m);
-            if (bsel) { const float b = bsel[co]; v.x += b; v.y += b; v.z += b; v.w += b; }
-            if (p.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            *dst = v;
-        }
-    }
-}
-
-// The compiled epilogues live in two kernel families: the MaxFeatureMap signatures (pair maximum, fan-out VJP: two more operand
-// loads and a chain tail that runs twice) need ~10 registers more than the rest, and a kernel's register count -- hence how many
-// workgroups share a CU -- is the maximum over everything it contains.  MFM = false: every other signature (all ResNet chains).
-
-// ... FAM 2: the lean probe-forward signatures, which need the second accumulator tile (kernels compiled with CHAIN == 4)
-template <int SIG>
-constexpr int sig_family() { return sig_is_dual<SIG>() ? 2 : (sig_is_mfm<SIG>() ? 1 : 0); }
-
-template <int SIG, int FAM>
-__device__ __forceinline__ void chain_epilogue_dispatch(int sig, const ConvParams& p, const v16f& acc, const v16f* accp, float* tile, int lane, int l31,
-                                                        int lhi, int co_base, int m, float* __restrict__ osel, const float* __restrict__ bsel)
-{
-    if constexpr (SIG < kNumChainSigs) {
-        if constexpr (sig_family<SIG>() == FAM) {
-            if (sig == SIG) { chain_epilogue<SIG>(p, acc, accp, tile, lane, l31, lhi, co_base, m, osel, bsel); return; }
-        }
-        chain_epilogue_dispatch<SIG + 1, FAM>(sig, p, acc, accp, tile, lane, l31, lhi, co_base, m, osel, bsel);
-    }
-}
-
-// Everything after the K loop of a 64x64 block tile whose wave (wrow, wcol) holds the 32x32 quadrant acc[0][0]: the exchange of a
-// tail tile's K-parts, then the epilogue.  Shared by the two kernels below.  CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue
-// (p.chain_sig), 2 = interpreted chain epilogue; LDS_OK: the workgroup's LDS holds the four 32 x 36 transposition tiles.
-// ROW: the four waves lie side by side along m (a 32 x 128 block tile) instead of 2 x 2 (64 x 64); either way a wave holds one 32 x 32 quadrant.
-template <int CHAIN, bool LDS_OK, bool ROW = false>
-__device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[1][1], float* smem, const int tid, const int lane, const int wave,
-                                               const int co0, const int m0, const int half, const int tail_t, const int part, const int nparts,
-                                               float* __restrict__ osel, const float* __restrict__ bsel, v16f* accp = nullptr)
-{
-    constexpr int MI = 1, NJ = 1, TCO = 64, TM = 64;         // (TCO / 2, TM / 2 below = the 32 rows / columns of a wave's quadrant in both layouts)
-    const int wrow = ROW ? 0 : wave >> 1, wcol = ROW ? wave : wave & 1;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    if (tail_t >= 0) {
-        // K-part of a tail tile: park the accumulators, count arrivals; the last part to arrive sums all parts in
-        // part order (deterministic) and runs the normal epilogue.  Agent-scope stores / loads: the parts ran on
-        // different XCDs, whose L2s are not coherent for plain accesses.
-        constexpr int TILE_FLOATS = TCO * TM * (CHAIN == 4 ? 2 : 1);       // a dual-accumulator launch parks both tiles
-        float* __restrict__ slab = p.tail_ws + (long)(tail_t * nparts + part) * TILE_FLOATS;
-        if constexpr (CHAIN == 4) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) __hip_atomic_store(slab + (16 + r) * NT + tid, (*accp)[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __hip_atomic_store(slab + ((i * NJ + j) * 16 + r) * NT + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // write-through (agent-scope) stores, then only wait for them: a full __threadfence() would write back AND
-        // invalidate this XCD's whole L2 under the other resident workgroups (measured: 37 us per launch at 256 parts)
-        wait_vmcnt<0>();
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            const unsigned old = atomicAdd(p.tail_cnt + tail_t, 1u);
-            const int last = (old == (unsigned)(nparts - 1));
-            if (last) atomicExch(p.tail_cnt + tail_t, 0u);     // ready for the next launch on this stream
-            *flag = last;
-        }
-        __syncthreads();
-        if (!*flag) return;
-        const float* base = p.tail_ws + (long)tail_t * nparts * TILE_FLOATS;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float sum = 0.f;
-                    for (int q = 0; q < nparts; ++q)
-                        sum += __hip_atomic_load(base + (long)q * TILE_FLOATS + ((i * NJ + j) * 16 + r) * NT + tid,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc[i][j][r] = sum;
-                }
-        if constexpr (CHAIN == 4) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sum = 0.f;
-                for (int q = 0; q < nparts; ++q)
-                    sum += __hip_atomic_load(base + (long)q * TILE_FLOATS + (16 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                (*accp)[r] = sum;
-            }
-        }
-    }
-
-    // ---- epilogue: D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]
-    // Optional fused micro-program (half 0 only): forward = bias -> [store raw] -> BatchNorm -> [+residual] -> ReLU;
-    // backward = [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP -> next GEMM's input.
-    if constexpr (CHAIN == 4) {
-        // lean probe forward: the wave holds the W and the relu(W) tile of its quadrant; the compiled chain stores what the sweep needs of them
-        if constexpr (MI == 1 && NJ == 1)
-            chain_epilogue_dispatch<0, 2>(p.chain_sig, p, acc[0][0], accp, smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
-                                          m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
-    } else if constexpr (CHAIN == 1 || CHAIN == 3) {
-        // compiled chain epilogue (CHAIN 3: the MaxFeatureMap signatures); launch_one only selects this instantiation when the float4 layout conditions hold.  The chain
-        // belongs to half 0; the relu(W) half of a dual launch (positive activations) leaves as plain dense rows.
-        if constexpr (MI == 1 && NJ == 1) {
-            if (half == 0)
-                chain_epilogue_dispatch<0, CHAIN == 3 ? 1 : 0>(p.chain_sig, p, acc[0][0], nullptr, smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32,
-                                           m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
-            else
-                dense_epilogue(p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32, m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
-        }
-    } else if constexpr (CHAIN == 2) {
-        // Epilogue with a fused micro-program (backward: [+fan-in gradient] -> tensor hooks / ReLU mask / BatchNorm VJP ->
-        // the next GEMM's input).  The 16 accumulator registers of a 32x32 tile are 4 groups of 4 consecutive output
-        // channels; they are processed group by group, and all per-element operands of a group (plan in
-        // p.chain_ld, <= 4 distinct tensors) are in flight together before the steps are interpreted: every workgroup of
-        // a launch reaches its epilogue at the same time, so a chain of dependent loads here is paid in full.
-        const EwLoads& ld = p.chain_ld;
-        // float4 pieces need rows whose length is a multiple of 4 on both sides (gradient rows of out_nb images, forward
-        // rows of chain_B images); a piece may then straddle two samples (7x7 maps) but never a row
-        const bool vec_ok = MI == 1 && NJ == 1 && LDS_OK && (p.M & 3) == 0 &&
-                            ((p.chain_B * p.OH * p.OW) & 3) == 0 && ((p.out_nb * p.OH * p.OW) & 3) == 0;
-        if (vec_ok) {
-            // vector path: the tile is turned through LDS like in the plain epilogue, a lane then owns float4 pieces
-            // (one channel, four consecutive positions of one sample) and runs the same float4 interpreter as the
-            // stand-alone chain kernel, operands fetched as 16-byte loads
-            constexpr int LD = 36;
-            __syncthreads();
-            float* tile = smem + wave * (32 * LD);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + l31] = acc[0][0][r];
-            const int ohw = p.OH * p.OW;
-            const long row4 = (long)p.out_nb * ohw / 4, arow4 = (long)p.chain_B * ohw / 4;
-            const int mq = (lane & 7) * 4;
-            const int m = m0 + wcol * 32 + mq;
-            const int mm = m < p.M ? m : 0;
-            const int sb = mm / ohw;
-            const long acol4 = (mm % (p.chain_B * ohw)) / 4;
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4* out4 = reinterpret_cast<float4*>(osel);
-#pragma unroll
-            for (int hf = 0; hf < 4; ++hf) {
-                float4 g[1], od[1], v0[1], v1[1], v2[1], v3[1];
-                long idx4[1], aidx4[1];
-                bool ok[1];
-                int cos[1];
-#pragma unroll
-                for (int u = 0; u < 1; ++u) {
-                    const int cl = (hf + u) * 8 + (lane >> 3);
-                    cos[u] = co0 + wrow * 32 + cl;
-                    ok[u] = cos[u] < p.CoutTot && m < p.M;
-                    const int cc = ok[u] ? out_row(p, cos[u]) : 0;
-                    idx4[u] = (long)cc * row4 + mm / 4;
-                    aidx4[u] = (long)cc * arow4 + acol4;
-                    g[u] = *reinterpret_cast<const float4*>(tile + cl * LD + mq);
-                    v0[u] = v1[u] = v2[u] = v3[u] = od[u] = z4;
-                    if (ld.lp[0]) v0[u] = reinterpret_cast<const float4*>(ld.lp[0])[aidx4[u]];
-                    if (ld.lp[1]) v1[u] = reinterpret_cast<const float4*>(ld.lp[1])[aidx4[u]];
-                    if (ld.lp[2]) v2[u] = reinterpret_cast<const float4*>(ld.lp[2])[aidx4[u]];
-                    if (ld.lp[3]) v3[u] = reinterpret_cast<const float4*>(ld.lp[3])[idx4[u]];
-                    if (p.accumulate) od[u] = out4[idx4[u]];
-                    if (bsel && ok[u]) { const float b = bsel[cos[u]]; g[u].x += b; g[u].y += b; g[u].z += b; g[u].w += b; }
-                }
-#pragma unroll
-                for (int u = 0; u < 1; ++u)
-                    ew_interpret<false>(ok[u], idx4[u], aidx4[u], sb, 0, g[u], od[u], v0[u], v1[u], v2[u], v3[u], out4, p.accumulate,
-                                        p.chain, cos[u], p.chain_eps);
-            }
-        } else
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
-            if (m >= p.M) continue;
-            const int ohw = p.OH * p.OW;
-            const long col = m;                                   // chains are only fused into dense (out_stride 1) launches
-            const long row_stride = (long)p.out_nb * ohw;
-            const int sb = m / ohw;
-            const int hw = m - sb * ohw;
-            const long acol = (long)(sb % p.chain_B) * ohw + hw;
-            const long arow = (long)p.chain_B * ohw;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int hf = 0; hf < 4; ++hf) {
-                    float g[4], pv0[4], pv1[4], pv2[4], pv3[4], sv[4] = {0.f, 0.f, 0.f, 0.f};
-                    int gi[4], ai[4];
-                    bool ok[4];
-#pragma unroll
-                    for (int e8 = 0; e8 < 4; ++e8) {
-                        const int rg = hf, q = e8;
-                        const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
-                        ok[e8] = co < p.CoutTot;
-                        const int cc = ok[e8] ? out_row(p, co) : 0;
-                        gi[e8] = (int)((long)cc * row_stride + col);
-                        ai[e8] = (int)((long)cc * arow + acol);
-                        pv0[e8] = pv1[e8] = pv2[e8] = pv3[e8] = 0.f;
-                    }
-#pragma unroll
-                    for (int e8 = 0; e8 < 4; ++e8) {
-                        if (ld.lp[0]) pv0[e8] = ld.lp[0][ld.lk[0] ? gi[e8] : ai[e8]];
-                        if (ld.lp[1]) pv1[e8] = ld.lp[1][ld.lk[1] ? gi[e8] : ai[e8]];
-                        if (ld.lp[2]) pv2[e8] = ld.lp[2][ld.lk[2] ? gi[e8] : ai[e8]];
-                        if (ld.lp[3]) pv3[e8] = ld.lp[3][ld.lk[3] ? gi[e8] : ai[e8]];
-                    }
-#pragma unroll
-                    for (int e8 = 0; e8 < 4; ++e8) {
-                        const int rg = hf, q = e8;
-                        const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * rg + q;
-                        float v = acc[i][j][rg * 4 + q];
-                        if (ok[e8]) {
-                            if (bsel) v += bsel[co];
-                            if (p.accumulate) v += osel[gi[e8]];
-                        }
-                        g[e8] = v;
-                    }
-#pragma unroll 1
-                    for (int sidx = 0; sidx < p.chain.n; ++sidx) {
-                        const EwStep& st = p.chain.s[sidx];
-                        const int type = st.type, s0 = st.ls0, s1 = st.ls1;
-                        if (type == EW_HOOK) {
-                            if (s0 == -2) {                      // p is not observed: relu(g) or the identity
-                                if (st.action == HOOK_RELU) {
-#pragma unroll
-                                    for (int e8 = 0; e8 < 4; ++e8) g[e8] = fmaxf(g[e8], 0.f);
-                                }
-                                continue;
-                            }
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                if (!ok[e8]) continue;
-                                const float a_raw = s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]];
-                                const float a = fmaxf(a_raw, 0.f);
-                                const float zh = fmaxf(g[e8], 0.f);
-                                if (st.action >= HOOK_Q) {      // lean hooks (common.h)
-                                    g[e8] = st.action == HOOK_Q ? zh * fabsf(a_raw)
-                                                                : (st.action == HOOK_GATE ? (a_raw > 0.f ? zh : 0.f) : ((__float_as_uint(a_raw) >> 31) ? 0.f : zh));
-                                    continue;
-                                }
-                                const float pp = a * zh;
-                                if (st.pstore) st.pstore[gi[e8]] = pp;
-                                if (st.action == HOOK_DIV) {
-                                    const float x = st.p1 ? fmaxf(s1 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s1) : st.p1[ai[e8]], 0.f) : a;
-                                    g[e8] = __fdiv_rn(pp, x + p.chain_eps);
-                                } else if (st.action == HOOK_RELU) {
-                                    g[e8] = zh;
-                                }
-                            }
-                        } else if (type == EW_MASK) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                if (!ok[e8]) continue;
-                                const float t = s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[ai[e8]];
-                                g[e8] = (st.action == 1 ? (__float_as_uint(t) >> 31) == 0u : t > 0.f) ? g[e8] : 0.f;
-                            }
-                        } else if (type == EW_SCALE_C) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8)
-                                if (ok[e8]) g[e8] *= st.p0[co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8];
-                        } else if (type == EW_SCALE) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) g[e8] *= st.f;
-                        } else if (type == EW_STORE) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                if (st.action == 1) { sv[e8] = g[e8]; continue; }
-                                if (ok[e8]) st.pstore[gi[e8]] = g[e8];
-                                if (st.action == 2) g[e8] = sv[e8];
-                            }
-                        } else if (type == EW_ADDP) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8)
-                                if (ok[e8]) g[e8] += s0 >= 0 ? pick4(pv0[e8], pv1[e8], pv2[e8], pv3[e8], s0) : st.p0[gi[e8]];
-                        } else if (type == EW_AFFINE_C) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
-                                if (ok[e8]) g[e8] = __fadd_rn(__fmul_rn(g[e8], st.p0[co]), st.p1[co]);
-                            }
-                        } else if (type == EW_RELU) {
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) g[e8] = fmaxf(g[e8], 0.f);
-                        } else {   // EW_FORK_POSBN
-#pragma unroll
-                            for (int e8 = 0; e8 < 4; ++e8) {
-                                const int co = co0 + wrow * (TCO / 2) + i * 32 + 4 * lhi + 8 * hf + e8;
-                                if (!ok[e8]) continue;
-                                float v = __fadd_rn(__fmul_rn(fmaxf(g[e8], 0.f), st.p0[co]), st.p1[co]);
-                                if (st.p2) v = __fadd_rn((st.action & 1) ? fmaxf(st.p2[gi[e8]], 0.f) : st.p2[gi[e8]], v);
-                                st.pstore[gi[e8]] = v;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int e8 = 0; e8 < 4; ++e8)
-                        if (ok[e8]) osel[gi[e8]] = g[e8];
-                }
-            }
-        }
-    } else if (MI == 1 && NJ == 1 && LDS_OK && p.out_stride == 1 && (p.M & 3) == 0 && ((p.out_nb * p.OH * p.OW) & 3) == 0) {
-        if constexpr (MI == 1 && NJ == 1)
-            dense_epilogue(p, acc[0][0], smem + wave * (32 * 36), lane, l31, lhi, co0 + wrow * 32, m0 + wcol * 32 + (lane & 7) * 4, osel, bsel);
-    } else {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int m = m0 + wcol * (TM / 2) + j * 32 + l31;
-            if (m >= p.M) continue;
-            long col;
-            long row_stride;
-            const int ohw = p.OH * p.OW;
-            if (p.out_stride == 1) {
-                col = m;
-                row_stride = (long)p.out_nb * ohw;
-            } else {
-                const int n = m / ohw;
-                const int r = m - n * ohw;
-                const int oh = r / p.OW;
-                const int ow = r - oh * p.OW;
-                col = ((long)n * p.out_H + (long)oh * p.out_stride) * p.out_W + (long)ow * p.out_stride;
-                row_stride = (long)p.out_nb * p.out_H * p.out_W;
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wrow * (TCO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (co >= p.CoutTot) continue;
-                    const long gi = (long)out_row(p, co) * row_stride + col;
-                    float v = acc[i][j][r];
-                    if (bsel) v += bsel[co];
-                    if (p.accumulate) v += osel[gi];
-                    osel[gi] = v;
-                }
-        }
-    }
-}
 
 // CHAIN: 0 = plain epilogue, 1 = compiled chain epilogue (p.chain_sig), 2 = interpreted chain epilogue, 3 = compiled, MaxFeatureMap family,
 // 4 = DUAL: compiled lean probe-forward epilogue over two accumulator tiles per wave -- W and relu(W), the latter multiplied from the clamped W
@@ -1103,237 +657,6 @@ __global__ __launch_bounds__(NT, CHAIN == 4 ? XFR_KS_DUAL_WAVES : 5) void conv_g
     stamp(p, wave, lane, 4);
 }
 
-// ---- K17: conv_gemm_split_kernel -- fp32-accurate GEMM on the bf16 MFMA pipe ("bf16x6") ---------------------------------------------------------------
-// An fp32 value is EXACTLY the sum of three bf16 pieces (8 + 8 + 8 significant bits, each piece the round-to-nearest bf16 of what is left); a bf16 x
-// bf16 product is exact in fp32; the six products (i, j) with i + j <= 2, accumulated in fp32 smallest first, reproduce the fp32 product to ~2^-23 -- the
-// maps cannot tell it from a re-ordered fp32 sum (tests/precision/split_probe.py, profiles/r5/experiments/bf16_split.txt).  Six
-// v_mfma_f32_32x32x16_bf16 take 6 x 32 cycles where the sixteen fp32 MFMAs of the same K = 16 take 8 x 64.
-//   * W: split once per pack (conv_gemm_register_split) into three bf16 planes, tiled [128-row tile][K step][piece][k half][128][8]: a K-step of a row
-//     tile is one contiguous 12 KB block that goes global -> LDS without registers (three LDS stages, two steps ahead);
-//   * X: fp32 as the producing epilogues left it; the workgroup's 256 lanes gather a 16 x 128 slab three steps ahead into registers (the tap-major
-//     gather of K2: per-lane shifted offset per filter tap, channels as the scalar offset, padding / m tails / steps past the end out of the buffer's
-//     range = 0), split every value once and write the three planes to LDS in fragment order (ds_write as inline asm: a compiler-visible ds_write after a
-//     buffer_load...lds is ordered with s_waitcnt vmcnt(0), which would drain exactly that prefetch);
-//   * 128 x 128 block tile, wave (wr, wc) holds the quadrants (wr, wc) of the four 64 x 64 sub-tiles -- so each sub-tile is laid out exactly like the
-//     block tile of K1 / K2 and runs their epilogues (block_epilogue) unchanged;
-//   * the loop is unrolled by three (stage and register-set indices are static; up to two steps past the end multiply zeros), one counted wait and one
-//     raw barrier per step.
-// Layers: stride-1 convolutions (1x1 and tap-major KxK) with Cin % 16 == 0, 128 | Cout, no dual-accumulator launch, dense output.
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-constexpr int SP_T = 128, SP_BK = 16;
-constexpr int SP_A_BYTES = 3 * 2 * SP_T * 16, SP_B_BYTES = 3 * 2 * SP_T * 16;
-constexpr size_t SP_LDS = 3 * (size_t)(SP_A_BYTES + SP_B_BYTES);
-
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-typedef __bf16 v2bf_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)      // v_cvt_pk_bf16_f32: two round-to-nearest-even conversions, lo in the low half
-{
-    const v2f_t t = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, v2bf_t));
-}
-// Round-to-nearest split of a PAIR (even k in the low half): v = p0 + p1 + p2 exactly, every piece at most half a bf16 ulp of the one before, so the three
-// dropped products of order 3 are ~2^-25 of the product and of either sign.  (A truncating split -- one AND per piece -- leaves remainders of up to a
-// whole ulp, all of the value's sign: dropped terms ~2^-21 that add up along K instead of averaging out.  Measured in round 5: golden maps 4x further
-// from the reference than with the fp32 kernels; with this split they are where the fp32 kernels are.)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2)
-{
-    p0 = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);       // exact
-    p1 = cvt_pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);     // exact, <= 8 significant bits
-    p2 = cvt_pk_bf16(sa, sb);
-}
-
-template <bool RELU, int CHAIN>
-__global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams p, const uint16_t* __restrict__ ws0, const uint16_t* __restrict__ ws1,
-                                                            const int n_co_tiles, const int n_m_tiles)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
-    constexpr int XBASE = 3 * SP_A_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    stamp(p, wave, lane, 0, 2);       // tuning stamps / the launch log's span record, like K1
-
-    const int lid = xcd_remap(blockIdx.x, n_co_tiles * n_m_tiles);
-    const int tile_m = lid / n_co_tiles;
-    const int tile_co_all = lid - tile_m * n_co_tiles;
-    const int n_co_half = n_co_tiles / p.nhalves;
-    const int half = tile_co_all / n_co_half;
-    const int tile_co = tile_co_all - half * n_co_half;
-    const int co0 = tile_co * SP_T, m0 = tile_m * SP_T;
-    const uint16_t* __restrict__ wsel = half ? ws1 : ws0;
-    const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
-    float* __restrict__ osel = half ? p.out1 : p.out0;
-    const int nk = p.K / SP_BK;
-    const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, n_co_half * nk * SP_A_BYTES, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-
-    // staging role: column m0 + (tid & 127), k-half wave >> 1 (wave-uniform)
-    const int sm = tid & 127, skh = wave >> 1;
-    int base_m = 0;
-    unsigned long long tapmask = 0ull;
-    {
-        const int m = m0 + sm;
-        const bool m_ok = m < p.M;
-        const int mm = m_ok ? m : 0;
-        const int ohw = p.OH * p.OW;
-        const int n = mm / ohw;
-        const int r = mm - n * ohw;
-        const int oh = r / p.OW;
-        const int ow = r - oh * p.OW;
-        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-        base_m = n * p.H * p.W + ih0 * p.W + iw0;
-        if (m_ok) {
-            unsigned long long vw = 0ull;
-            for (int dw = 0; dw < p.kw; ++dw)
-                if ((unsigned)(iw0 + dw) < (unsigned)p.W) vw |= 1ull << dw;
-            for (int dh = 0; dh < p.kh; ++dh)
-                if ((unsigned)(ih0 + dh) < (unsigned)p.H) tapmask |= vw << (dh * p.kw);
-        }
-    }
-    const unsigned xs_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds) + XBASE + (skh * SP_T + sm) * 16;   // this lane's LDS slot
-
-    v16f acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto load_w = [&](int kt, int stage) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b)      // steps past the end: out of range, the hardware writes zeros
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(lds + stage * SP_A_BYTES + (b * 4 + wave) * 1024), 16,
-                                                     ((b * 4 + wave) * 1024 + lane * 16) | (kt < nk ? 0u : OOB), (tile_co * nk + kt) * SP_A_BYTES, 0, 0);
-    };
-    // the X loads walk the K-steps in order: (tap, first channel) of the next step to be loaded, and that tap's per-lane offset
-    int ld_tap = 0, ld_ci0 = 0;
-    unsigned ld_voff = (tapmask & 1ull) ? (unsigned)base_m * 4u : OOB;
-    auto load_x = [&](int kt, float (&v)[8]) {
-        const unsigned voff = ld_voff | (kt < nk ? 0u : OOB);
-        const unsigned so = (unsigned)(ld_ci0 + skh * 8) * chan_bytes;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rIn, voff, so + (unsigned)i * chan_bytes, 0));
-        ld_ci0 += SP_BK;
-        if (ld_ci0 >= p.Cin) {          // wave-uniform: next filter tap => new per-lane shifted offset
-            ld_ci0 = 0;
-            ld_tap += 1;
-            const int dh = ld_tap / p.kw, dw = ld_tap - dh * p.kw;
-            ld_voff = (ld_tap < p.kh * p.kw && ((tapmask >> ld_tap) & 1ull)) ? (unsigned)(base_m + dh * p.W + dw) * 4u : OOB;
-        }
-    };
-    auto write_piece = [&](v4u q, int stage, int piece) {
-        asm volatile("ds_write_b128 %0, %1" :: "v"(xs_addr + stage * SP_B_BYTES + piece * 2 * SP_T * 16), "v"(q));
-    };
-    // `flip`: 0x80008000 for a K-step of a NEGATED phase (below), else 0 -- the sign bits of both bf16 of a word
-    auto store_x = [&](const float (&v)[8], int stage, unsigned flip) {
-        v4u p0, p1, p2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a = RELU ? fmaxf(v[2 * i], 0.f) : v[2 * i], b = RELU ? fmaxf(v[2 * i + 1], 0.f) : v[2 * i + 1];
-            unsigned q0, q1, q2;
-            split_pair(a, b, q0, q1, q2);
-            p0[i] = q0 ^ flip; p1[i] = q1 ^ flip; p2[i] = q2 ^ flip;
-        }
-        write_piece(p0, stage, 0); write_piece(p1, stage, 1); write_piece(p2, stage, 2);
-    };
-    // Sign phases.  The bf16 MFMA does not round its sum to nearest like the fp32 MFMA (an fmaf chain) does: measured against float64, every output of a
-    // bf16x6 GEMM sits ~4e-9 of its sum of magnitudes BELOW the exact value (fp32 kernels: 2e-11, either sign) -- 0.1 of the rms error, but of one sign in
-    // every element of every layer, which a contrastive map amplifies.  So the sum changes sign with every pass of the loop below (three K-steps): X pieces
-    // are stored negated (one XOR per word), the accumulators negated in place (exact); the hardware's downward error then pushes the true sum UP, and the
-    // two cancel.  `flip`: the sign-bit mask of the phase the step's X slab (step kt+1) belongs to.
-    // one K-step; ST = kt % 3 (static), xcur = X(kt+1) registers (split here), xnew = registers that receive X(kt+3)
-    auto step = [&](int kt, auto ST, float (&xcur)[8], float (&xnew)[8], unsigned flip) {
-        constexpr int st = decltype(ST)::value, st1 = (st + 1) % 3, st2 = (st + 2) % 3;
-        load_w(kt + 2, st2);
-        load_x(kt + 3, xnew);
-        const unsigned char* As = lds + st * SP_A_BYTES;
-        const unsigned char* Bs = lds + XBASE + st * SP_B_BYTES;
-        v8bf af[3][2], bf[3][2];
-        // quadrant (wr, wc) of sub-tile (i, j): rows i * 64 + wr * 32, columns j * 64 + wc * 32
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[pc][i] = *(const v8bf*)(As + ((pc * 2 + lhi) * SP_T + i * 64 + wr * 32 + l31) * 16);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[pc][j] = *(const v8bf*)(Bs + ((pc * 2 + lhi) * SP_T + j * 64 + wc * 32 + l31) * 16);
-        }
-        // (piece of W, piece of X), smallest products first
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], acc[i][j], 0, 0, 0);
-        store_x(xcur, st1, flip);
-        // W(kt+1) (issued during step kt-1) has landed when at most X(kt+2), W(kt+2), X(kt+3) are outstanding: 8 + 3 + 8
-        asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    };
-    auto negate_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
-    };
-    float x0[8], x1[8], x2[8];
-    load_w(0, 0);
-    load_x(0, x0);
-    store_x(x0, 0, 0u);
-    load_w(1, 1);
-    load_x(1, x0);
-    load_x(2, x1);
-    asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // W(0) and the split of X(0) are in LDS
-    stamp(p, wave, lane, 1);
-    std::integral_constant<int, 0> S0; std::integral_constant<int, 1> S1; std::integral_constant<int, 2> S2;
-    unsigned flip = 0u;                         // the current pass's phase
-    for (int kt = 0; kt < nk; kt += 3) {        // up to two steps past the end multiply zeros: no branch on kt inside the body
-        step(kt, S0, x0, x2, flip);
-        step(kt + 1, S1, x1, x0, flip);
-        flip ^= 0x80008000u;
-        step(kt + 2, S2, x2, x1, flip);         // its X slab is the next pass's first
-        negate_acc();
-    }
-    wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (flip) negate_acc();                     // an odd number of passes
-    stamp(p, wave, lane, 2);
-    stamp(p, wave, lane, 3);
-
-    // the four 64 x 64 sub-tiles leave through the epilogues of K1 (each starts with a workgroup barrier before it reuses the LDS).  A REAL loop -- one
-    // epilogue instance in the code, not four (the compiled-chain family is 86 signatures) -- over a fixed register tile: the other three shift down.
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        v16f t[1][1];
-        t[0][0] = acc[0][0];
-        block_epilogue<CHAIN, true>(p, t, smem, tid, lane, wave, co0 + (q >> 1) * 64, m0 + (q & 1) * 64, half, -1, 0, 1, osel, bsel, nullptr);
-        acc[0][0] = acc[0][1];
-        acc[0][1] = acc[1][0];
-        acc[1][0] = acc[1][1];
-    }
-    stamp(p, wave, lane, 4);
-}
-
-// W[k][ldw] fp32 (k rows, output channel = column) -> bf16 planes [cout / 128][K / 16][piece][k half][128][8]
-__global__ void split_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ planes, int K, int cout, int ldw)
-{
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)K * cout) return;
-    const int k = (int)(idx / cout), co = (int)(idx - (long)k * cout);
-    unsigned h[3];
-    split_pair(w[(long)k * ldw + co], 0.f, h[0], h[1], h[2]);          // the value's pieces in the low halves
-    const int rt = co / SP_T, r = co - rt * SP_T, kt = k / SP_BK, kk = k - kt * SP_BK, nk = K / SP_BK;
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-        planes[((((long)(rt * nk + kt) * 3 + q) * 2 + kk / 8) * SP_T + r) * 8 + kk % 8] = (uint16_t)(h[q] & 0xffffu);
-}
 
 int num_cus()
 {
@@ -1438,7 +761,7 @@ bool launch_one(const ConvParams& p, hipStream_t s)
     if constexpr ((TCO == 64 && TM == 64) || (TCO == 32 && TM == 128)) {
         if (q.chain.n > 0) {      // fused micro-program (no relu_in)
             if (plan_chain(q)) return false;
-            g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
+            g_conv_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
             if (q.chain_sig < 0) warn_interpreted(q);
             if constexpr (TCO == 64 && MODE != MODE_TAP4 && MODE != MODE_GEN) {
                 if (q.dualacc) {
@@ -1488,7 +811,7 @@ bool launch_one_ks(const ConvParams& p, hipStream_t s)
     if (p.dualacc && (q.chain.n == 0 || p.nhalves != 1 || p.relu_in)) return false;
     if (q.chain.n > 0) {
         if (plan_chain(q)) return false;
-        g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
+        g_conv_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
         if (q.chain_sig < 0) warn_interpreted(q);
         if (q.dualacc) {
             hipLaunchKernelGGL((conv_gemm_ks_kernel<BK, NST, MODE, false, 4>), dim3(grid), dim3(NT), lds, s, q, n_co, n_m);
@@ -1529,86 +852,6 @@ bool launch_cfg_ks(const ConvParams& p, hipStream_t s)
     return launch_one_ks<BK, NST, MODE_TAP>(p, s);
 }
 
-// ---- the bf16x6 kernel's host side: a registry of split packs (fp32 pack pointer -> bf16 planes), filled by the engine for the layers it covers
-struct SplitPack { uint16_t* planes; int K, cout, ldw; };
-static std::mutex g_split_mu;
-static std::unordered_map<const float*, SplitPack> g_split;
-
-bool split_layer_ok(const ConvParams& p)
-{
-    if (p.dualacc || p.out_stride != 1 || p.as_strided || p.co_pair > 0 || p.stride != 1) return false;
-    if ((p.Cin % SP_BK) != 0 || (p.K % SP_BK) != 0 || (p.CoutTot % SP_T) != 0) return false;
-    if (p.OH * p.OW < 196) return false;       // 7 x 7 maps: 25 column tiles per 64 images leave most CUs idle (68 against 111 TFLOP/s on layer 4)
-    if (p.kh == 1 && p.kw == 1) return p.pad == 0 && p.K >= 1024;
-    return p.tap_major == 1 && p.kh * p.kw <= 64 && p.K >= 1152;
-}
-
-static std::atomic<long> g_split_launches{0};
-
-// the planes of pack w, split now if this is its first launch: the split runs on the launch's stream, which is drained before the entry becomes visible
-// (another stream's launch of the same layer may follow at once)
-const uint16_t* split_planes(const float* w, int K, int cout, int ldw, hipStream_t s)
-{
-    std::lock_guard<std::mutex> lk(g_split_mu);
-    auto it = g_split.find(w);
-    if (it != g_split.end()) return (it->second.K == K && it->second.cout == cout && it->second.ldw == ldw) ? it->second.planes : nullptr;
-    SplitPack sp{nullptr, K, cout, ldw};
-    if (hipMalloc(&sp.planes, (size_t)K * cout * 3 * sizeof(uint16_t)) != hipSuccess) {
-        (void)hipGetLastError();
-        sp.planes = nullptr;
-        g_split[w] = sp;                 // no memory for the planes: this pack stays on the fp32 kernels (until conv_gemm_forget_split) instead of retrying per launch
-        return nullptr;
-    }
-    const long n = (long)K * cout;
-    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, sp.planes, K, cout, ldw);
-    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(sp.planes); return nullptr; }
-    g_split[w] = sp;
-    return sp.planes;
-}
-
-template <bool RELU, int CHAIN>
-void launch_split_inst(const ConvParams& q, const uint16_t* w0, const uint16_t* w1, int grid, int n_co, int n_m, hipStream_t s)
-{
-    // once per instantiation AND device: the kernel's 72 KB of dynamic LDS exceed the default limit
-    static std::atomic<unsigned long long> done{0ull};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<RELU, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_LDS);
-        done.fetch_or(bit);
-    }
-    hipLaunchKernelGGL((conv_gemm_split_kernel<RELU, CHAIN>), dim3(grid), dim3(NT), SP_LDS, s, q, w0, w1, n_co, n_m);
-}
-
-// false: the launch is not one the split kernel covers (or its pack is not registered) -- the caller takes the fp32 kernel the rules give
-bool launch_split(const ConvParams& p, hipStream_t s)
-{
-    if (!split_layer_ok(p)) return false;
-    if (p.chain.n > 0 && p.relu_in) return false;
-    const uint16_t* w0 = split_planes(p.w, p.K, p.CoutTot, p.ldw, s);
-    const uint16_t* w1 = p.nhalves == 2 ? split_planes(p.w_pos, p.K, p.CoutTot, p.ldw, s) : nullptr;
-    if (!w0 || (p.nhalves == 2 && !w1)) return false;
-    g_split_launches++;
-    const int n_co = (p.CoutTot / SP_T) * p.nhalves;
-    const int n_m = (p.M + SP_T - 1) / SP_T;
-    ConvParams q = p;
-    q.tail_q = 0;
-    q.tail_s = 1;
-    if (q.chain.n > 0) {
-        if (plan_chain(q)) return false;
-        if (q.chain_sig >= 0 && chain_sig_is_dual(q.chain_sig)) return false;      // (only ever with dualacc, which the layer test excludes)
-        g_chain_launches[q.chain_sig >= 0 ? 0 : 1]++;
-        if (q.chain_sig < 0) warn_interpreted(q);
-        if (q.chain_sig >= 0 && chain_sig_is_mfm(q.chain_sig)) launch_split_inst<false, 3>(q, w0, w1, n_co * n_m, n_co, n_m, s);
-        else if (q.chain_sig >= 0) launch_split_inst<false, 1>(q, w0, w1, n_co * n_m, n_co, n_m, s);
-        else launch_split_inst<false, 2>(q, w0, w1, n_co * n_m, n_co, n_m, s);
-        return true;
-    }
-    if (p.relu_in) launch_split_inst<true, 0>(q, w0, w1, n_co * n_m, n_co, n_m, s);
-    else launch_split_inst<false, 0>(q, w0, w1, n_co * n_m, n_co, n_m, s);
-    return true;
-}
 
 template <int TCO, int TM, int BK, int NST>
 bool launch_cfg(const ConvParams& p_in, hipStream_t s)
@@ -1627,6 +870,10 @@ bool launch_cfg(const ConvParams& p_in, hipStream_t s)
 
 }  // namespace
 
+int conv_gemm_num_cus() { return num_cus(); }
+int conv_gemm_plan_chain(ConvParams& q) { return plan_chain(q); }
+void conv_gemm_warn_interpreted(const ConvParams& q) { warn_interpreted(q); }
+
 // host side of the signature table: exact match of the code sequence
 int conv_gemm_chain_sig(const EwChain& ch)
 {
@@ -1641,22 +888,6 @@ int conv_gemm_chain_sig(const EwChain& ch)
     return -1;
 }
 int conv_gemm_num_chain_sigs() { return kNumChainSigs; }
-
-// bf16x6 split packs (K17): drop the planes of every pack inside [lo, lo + bytes) -- its contents changed, or its memory goes away
-void conv_gemm_forget_split(const void* lo, size_t bytes)
-{
-    std::lock_guard<std::mutex> lk(g_split_mu);
-    const char* a = static_cast<const char*>(lo);
-    for (auto it = g_split.begin(); it != g_split.end();) {
-        const char* w = reinterpret_cast<const char*>(it->first);
-        if (w >= a && w < a + bytes) {
-            if (it->second.planes) (void)hipFree(it->second.planes);     // hipFree waits for the device: no launch still reads them
-            it = g_split.erase(it);
-        } else ++it;
-    }
-}
-int conv_gemm_split_covers(const ConvParams& p) { return split_layer_ok(p) ? 1 : 0; }
-long conv_gemm_split_launches() { return g_split_launches.load(); }
 
 int conv_gemm_cannot_launch(const ConvParams& p)
 {
@@ -1677,8 +908,8 @@ const char* conv_gemm_refusal(int why)
 
 void conv_gemm_chain_launch_counts(long* compiled, long* interpreted)
 {
-    if (compiled) *compiled = g_chain_launches[0].load();
-    if (interpreted) *interpreted = g_chain_launches[1].load();
+    if (compiled) *compiled = g_conv_chain_launches[0].load();
+    if (interpreted) *interpreted = g_conv_chain_launches[1].load();
 }
 
 static int pick_cfg_impl(const ConvParams& p_in, bool allow_split);
@@ -1697,7 +928,7 @@ static int pick_cfg_impl(const ConvParams& p_in, bool allow_split)
     // Channel counts that leave the last 64-row tile at most half full (Light-CNN: 96 = 64 + 32): the 32 x 128 block tile wastes no MFMA row.
     // A property of the layer; K order of the 64 x 64 tile, so the bits do not move where that one ran before.
     // bf16x6 (K17): a property of the LAYER and of the engine's setting, never of the batch
-    if (allow_split && p.split_ok && split_layer_ok(p)) return 9;
+    if (allow_split && p.split_ok && conv_gemm_split_layer_ok(p)) return 9;
     {
         const int rem = p.CoutTot % 64;
 #ifndef XFR_NO_ROW_TILE      /* A/B builds only (profiles/r4/experiments/row_tile_ab.txt) */
@@ -1815,7 +1046,7 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     // cfg 6 / 7: the intra-workgroup split-K kernel, (BK, ring stages) = (8, 3): 48 KB of LDS, three workgroups per CU; (4, 4): 32 KB, five.
     // Round 3 sweep (tools/conv_sweep.py): (4, 5) and (4, 6) tie with (4, 4), (16, 3) -- one workgroup per CU -- loses 15 %.
     if (cfg == 9) {
-        if (launch_split(p, s)) return true;
+        if (conv_gemm_launch_split(p, s)) return true;
         cfg = pick_cfg_impl(p, false);     // not covered (a chain family without a split instantiation, an unregistered pack): the fp32 rules
     }
     if (cfg == 6 && ks_ok<8>(p)) return launch_cfg_ks<8, 3>(p, s);
