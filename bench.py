@@ -193,7 +193,7 @@ def pmc_traffic(root, tag):
             for name in ('FETCH_SIZE', 'WRITE_SIZE'):
                 n, v = 0, 0.0
                 for ln in open(os.path.join(d, 'pmc_%s%s.txt' % (name, tag))):
-                    m = re.match(r'conv_gemm(?:_ks)?_kernel\s+dispatches\s+(\d+)\s+.*%s=([0-9.e+]+)' % name, ln)
+                    m = re.match(r'conv_gemm(?:_ks|_split)?_kernel\s+dispatches\s+(\d+)\s+.*%s=([0-9.e+]+)' % name, ln)
                     if m:
                         n += int(m.group(1))
                         v += float(m.group(2))
@@ -206,6 +206,61 @@ def pmc_traffic(root, tag):
         except (OSError, KeyError, ValueError):
             continue
     return {}
+
+
+def pmc_mfma(root, tag, launches_per_step, ms_step, clk_ghz):
+    """MFMA-pipe utilisation of the GEMM kernels from the committed PMC pass of this same command (profiles/rNN/pmc_mfma<tag>.txt, one-stream schedule under
+    rocprofv3): sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), all GEMM kernels and per kernel -- and what the same busy
+    cycles per step are of the TIMED step (busy cycles do not depend on the schedule; the step's cycles = its duration x the shader clock it held)."""
+    import glob
+    import re
+    for d in reversed(sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9]*')))):
+        try:
+            rows = {}
+            for ln in open(os.path.join(d, 'pmc_mfma%s.txt' % tag)):
+                m = re.match(r'(conv_gemm(?:_ks|_split)?_kernel)\s+dispatches\s+(\d+)\s+(.*)', ln)
+                if m:
+                    kv = dict(t.split('=') for t in m.group(3).split())
+                    rows[m.group(1)] = (int(m.group(2)), float(kv['SQ_VALU_MFMA_BUSY_CYCLES']), float(kv['GRBM_GUI_ACTIVE']))
+            if not rows:
+                continue
+            n = sum(r[0] for r in rows.values())
+            busy = sum(r[1] for r in rows.values())
+            act = sum(r[2] for r in rows.values())
+            out = {'mfma_util_serial_pmc': busy / (act / 8.0 * 1024.0),
+                   'mfma_util_serial_pmc_by_kernel': {k: r[1] / (r[2] / 8.0 * 1024.0) for k, r in sorted(rows.items())},
+                   'mfma_util_source': '%s/pmc_mfma%s.txt (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024), one-stream schedule under rocprofv3)' % (os.path.relpath(d, root), tag)}
+            if launches_per_step and ms_step and clk_ghz:
+                steps = n / float(launches_per_step)
+                out['mfma_util_timed_estimate'] = (busy / steps) / (ms_step * 1e-3 * clk_ghz * 1e9 * 1024.0)
+                out['mfma_util_timed_how'] = ('the PMC pass\'s MFMA busy cycles per step (%d dispatches / %.0f launches per step = %.1f steps) over the timed step\'s '
+                                              'cycles (%.3f ms x %.2f GHz x 1024 SIMDs)' % (n, launches_per_step, steps, ms_step, clk_ghz))
+            return out
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}
+
+
+def one_triplet_latency(W, reps=30):
+    """The reference's API is one image per call (Whitebox.contrastive_ebp(img), whitebox.py:506-527; demo/test_whitebox.py:124-133 brings one triplet at a
+    time): wall time of ONE triplet through the same entry point -- two encodes and the contrastive sweep, batch 1, the device synchronised after every
+    call, fresh (not resident-declared) inputs, every library default.  Median and p90 over `reps` calls after 5 warm-up calls."""
+    import torch
+    if getattr(W, 'one', None) is None:
+        return None
+    for _ in range(5):
+        W.one()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        s = W.one()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    ts.sort()
+    ok = bool(torch.isfinite(s).all().item()) and abs(float(s.sum().item()) - 1.0) < 1e-3
+    return {'ms_median': ts[len(ts) // 2], 'ms_p90': ts[int(0.9 * (len(ts) - 1))], 'calls': reps, 'outputs_ok': ok,
+            'what': 'one triplet per call (2 encodes + contrastive EBP), device synchronised after each call, library defaults'}
 
 
 def chain_stats():
@@ -222,18 +277,23 @@ class Workload(object):
 
 
 def make_u8_step(eng, imgs, mean, B, enc_t, pct, dev):
-    """The same triplet step fed the way a caller holding decoded crops would feed it (xfr_triplet_contrastive_u8): the 3B images as uint8 H x W x 3
-    in PINNED host memory, the host-to-device copy and the on-device preprocessing inside the step.  imgs: the bench's fp32 images (mean
-    subtracted); their uint8 versions are round(img + mean)."""
+    """The same triplet step fed the way a caller holding decoded crops would feed it (xfr_triplet_contrastive_u8_host): the 3B images as uint8 H x W x 3
+    in PINNED host memory, two buffers used alternately (a real caller decodes the next batch into the one the engine is done copying), the
+    host-to-device copy and the on-device preprocessing inside the step -- on the engine's own copy stream and staging buffers, so that they overlap
+    the previous step's sweep without any residency promise.  imgs: the bench's fp32 images (mean subtracted); their uint8 versions are round(img + mean)."""
     import torch
     m = torch.tensor(mean, dtype=torch.float32).reshape(1, 3, 1, 1)
-    u8 = (imgs + m).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().pin_memory()
+    u8 = (imgs + m).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    bufs = [(u8[2 * B:].clone().pin_memory(), u8[:2 * B].clone().pin_memory()) for _ in range(2)]
     eng.set_u8_preprocess('sub_mean', 3, tuple(float(v) for v in mean), None)
-    dev_buf = torch.empty_like(u8, device=dev)
+    state = {'i': 0}
 
     def step():
-        dev_buf.copy_(u8, non_blocking=True)
-        return eng.triplet_contrastive_u8(dev_buf[2 * B:], dev_buf[:2 * B], enc_t, 1.0 / 2500.0, pct, inputs_ready=False)
+        p, g = bufs[state['i'] & 1]
+        state['i'] += 1
+        if state['i'] > 2:
+            eng.wait_inputs_copied()          # the buffer about to be "refilled" (used two calls ago) has been copied: copies run in order
+        return eng.triplet_contrastive_u8_host(p, g, enc_t, 1.0 / 2500.0, pct)
     return step
 
 
@@ -262,6 +322,8 @@ def make_workload(args, dev, rank, cpu_only=False, comm=None):
             W.pipeline = 1
             W.step = lambda ready=True: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, None, inputs_ready=ready)   # noqa: E731
             W.u8_step = make_u8_step(eng, imgs, resnet.MEAN_RGB, B, enc_t, None, dev)
+            g1, p1 = torch.stack((gallery[0], gallery[B])).contiguous(), probes[:1].contiguous()
+            W.one = lambda: eng.triplet_contrastive(p1, g1, enc_t, 1.0 / 2500.0, None)   # noqa: E731
         W.flop_per_unit = 6 * F_FWD['resnet101']           # 2 encodes + true fwd + relu(W) fwd + 2 backward-data sweeps = 86.51 GFLOP
         W.metric = 'triplet-contrastive-EBP saliency maps/sec, ResNet-101 224x224'
         W.work = ('ResNet-101 triplet contrastive EBP, batch=%d synthetic 224x224 triplets per GPU (2 encodes + contrastive_ebp per '
@@ -294,6 +356,8 @@ def make_workload(args, dev, rank, cpu_only=False, comm=None):
             W.pipeline = 1
             W.step = lambda ready=True: eng.triplet_contrastive(probes, gallery, enc_t, 1.0 / 2500.0, 20.0, inputs_ready=ready)   # noqa: E731
             W.u8_step = make_u8_step(eng, imgs, (131.0912, 103.8827, 91.4953), B, enc_t, 20.0, dev)
+            g1, p1 = torch.stack((gallery[0], gallery[B])).contiguous(), probes[:1].contiguous()
+            W.one = lambda: eng.triplet_contrastive(p1, g1, enc_t, 1.0 / 2500.0, 20.0)   # noqa: E731
         W.flop_per_unit = 6 * F_FWD['resnet50_128']
         W.metric = 'triplet truncated-contrastive-EBP (20 %) saliency maps/sec, VGGFace2 ResNet-50-128d 224x224'
         W.work = 'ResNet-50-128d truncated contrastive EBP, batch=%d synthetic triplets per GPU, mode %s' % (B, W.mode)
@@ -394,7 +458,7 @@ def rank_report(eng, comm, binding=None):
     if binding is not None:
         me['cpu_binding'] = binding
     sys.stderr.write('bench.py rank %d/%d: %s\n' % (rank, world, json.dumps(me)))
-    return comm.gather_objects(me, 'rank_report')
+    return comm.gather_objects(me, comm.next_tag('rank_report'))
 
 
 def _pipe_level(level):
@@ -434,10 +498,15 @@ def executed_flops(W, reps=2):
     eng = W.eng
     eng.set_profile(True)
     s_ms, s_n, s_fl = 0.0, 0, 0.0
+    fam = {'fp32': [0.0, 0, 0.0], 'bf16x6': [0.0, 0, 0.0]}
     for _ in range(reps):
         W.step(False)
         ms, n, fl = eng.get_profile(); s_ms += ms; s_n += n; s_fl += fl
+        for k, v in eng.get_profile_by_kernel().items():
+            for i in range(3):
+                fam[k][i] += v[i]
     eng.set_profile(False)
+    W.by_family_serial = {k: (v[0] / reps, v[1] / float(reps), v[2] / reps) for k, v in fam.items()}
     return s_ms / reps, s_n / reps, s_fl / reps
 
 
@@ -475,7 +544,7 @@ def roofline_object(W, step, ms_step, dev, reps=2, launch_log_out=None):
             'frac_serial': alg_step / (s_ms * 1e-3) / PEAK_F32_MFMA, 'achieved_serial': alg_step / (s_ms * 1e-3) / 1e12,
             'gemm_ms_per_step_serial': s_ms, 'avg_launch_ms_serial': s_ms / max(s_n, 1),
             'executed_flop_per_step': s_fl, 'algorithmic_flop_per_step': W.flop_per_unit * B, 'flop_per_step_used': alg_step,
-            'mfma_util_source': 'profiles/rNN/pmc_mfma%s.txt (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024), serial schedule)' % (W.pmc_tag or '')}
+            }
     share = tl.get('split_flop_share', 0.0)
     if share > 0:
         # --split-gemm: part of the FLOPs ran as bf16x6 on the bf16 pipe (2516.6 / 6 = 419.4 TFLOP/s fp32-equivalent).  The roofline is then the
@@ -486,6 +555,17 @@ def roofline_object(W, step, ms_step, dev, reps=2, launch_log_out=None):
                      'frac_timed': roof['achieved_timed'] / mixed, 'frac_serial': roof['achieved_serial'] / mixed,
                      'peak_note': 'harmonic mix of the fp32 MFMA peak (%.1f) and the bf16x6 ceiling (%.1f fp32-equivalent TFLOP/s = the bf16 MFMA peak / 6) by FLOP '
                                   'share; every frac* of this object is against it' % (peak, PEAK_BF16_MFMA / 6e12)})
+    # every kernel family against ITS OWN ceiling, one-stream schedule (HIP events around every launch: what rocprofv3 --kernel-trace reproduces) -- a slow
+    # kernel cannot hide in the mixed figure above
+    fams = {}
+    for k, pk in (('fp32', peak), ('bf16x6', PEAK_BF16_MFMA / 6e12)):
+        ms_f, n_f, fl_f = W.by_family_serial.get(k, (0.0, 0, 0.0))
+        if n_f > 0:
+            fams[k] = {'launches_per_step': n_f, 'executed_flop_per_step': fl_f, 'gemm_ms_per_step_serial': ms_f, 'achieved_serial': fl_f / (ms_f * 1e-3) / 1e12,
+                       'peak': pk, 'frac_serial': fl_f / (ms_f * 1e-3) / 1e12 / pk, 'mfma_pipe_ms_at_peak': fl_f / (pk * 1e12) * 1e3}
+    roof['by_family'] = fams
+    roof['by_family_note'] = ('fp32: v_mfma_f32_32x32x2_f32 kernels against 157.3 TFLOP/s; bf16x6: conv_gemm_split_kernel against 419.4 fp32-equivalent TFLOP/s '
+                              '(bf16 MFMA peak / 6 products); mfma_pipe_ms_at_peak = the matrix-pipe time the family\'s FLOPs need at that peak')
     if clk:
         # 157.3 TFLOP/s is the peak at the nominal 2.4 GHz; what the chip can do at the clock it actually held
         roof['shader_clock_GHz'] = clk
@@ -493,6 +573,7 @@ def roofline_object(W, step, ms_step, dev, reps=2, launch_log_out=None):
         roof['frac_of_sustained'] = achieved / roof['peak_sustained']
     if W.pmc_tag is not None:
         roof.update(pmc_traffic(ROOT, W.pmc_tag))
+        roof.update(pmc_mfma(ROOT, W.pmc_tag, tl['launches_per_step'], ms_step, clk['p50'] if clk else None))
     return roof, tl, alg_step
 
 
@@ -549,10 +630,7 @@ def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=653
     wbn._engine_key = (str(bb.device), id(bb))
     wbn._engine.load_weights(synth.synth_state_dict(bb, seed=0))
     wbn._engine.loaded_version = bb.version
-    # groups of `group` jobs: forwards of 8-64 images, i.e. 13-100 column tiles of the bf16x6 kernel's 128-wide tile on 256 CUs (measured with it: encodes 1.45 ->
-    # 2.06 ms per job, contrastive 1.15 -> 1.55, job mix 88.7 -> 84 jobs/s).  The kernel choice is a property of the layer, never of the batch, so a caller with
-    # small batches switches it off -- like it picks the batch
-    wbn._engine.set_split_gemm(0)
+    # (no kernel knobs here: launches of fewer than 128 tiles leave the bf16x6 kernel by the library's own rule -- round 5 switched it off by hand)
     k = mates
     pool = [synth.synth_smooth_images(2 * k + 1, (3, 224, 224), seed=10000 + j, mean=resnet.MEAN_RGB).to(dev) for j in range(8)]
 
@@ -610,6 +688,37 @@ def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=653
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (same command line, the environment torch.distributed.run would give them,
+    a free rendezvous port on 127.0.0.1), pass rank 0's stdout through -- its ONE JSON line -- and return the largest exit code.  Fewer visible GPUs than
+    ranks (a one-GPU box): the ranks share the devices round-robin over gloo -- RCCL cannot put two ranks on one device -- and the line says so."""
+    import socket
+    import subprocess
+    import torch
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ndev = torch.cuda.device_count()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', XFR_LAUNCHER='bench.py itself (%d ranks spawned, %d device(s) visible)' % (n, ndev))
+        if ndev < n:
+            env.update(XFR_FORCE_DEVICE=str(r % max(ndev, 1)), XFR_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.time() + 120.0            # a rank failed: the others report it (shard.Comm) and leave; do not wait for ever
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    return max(abs(p.returncode or 0) for p in procs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -635,8 +744,8 @@ def main():
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
     ap.add_argument('--inpainting-game', action='store_true', help='only the BASELINE.json configs[4] job mix (one GPU): print its object and exit')
-    ap.add_argument('--no-split-leg', action='store_true', help='skip the experimental bf16x6 measurement that rides on the line (experimental_bf16x6)')
-    ap.add_argument('--split-gemm', type=int, default=None, help='xfr_engine_set_split_gemm(MODE): 0 fp32 MFMA kernels everywhere, 1 bf16x6 forward convolutions of the deep-K layers (the default), 3 the backward-data GEMMs too (experimental)')
+    ap.add_argument('--no-split-leg', action='store_true', help='skip the two other xfr_engine_set_split_gemm modes that ride on the line (split_gemm_modes)')
+    ap.add_argument('--split-gemm', type=int, default=None, help='xfr_engine_set_split_gemm(MODE): 0 fp32 MFMA kernels everywhere, 1 bf16x6 forward convolutions of the deep-K layers, 3 the backward-data GEMMs too (the default); + 4: whatever the grid')
     ap.add_argument('--no-lean', action='store_true', help='xfr_engine_set_lean(0): the literal hook operands in every sweep (A/B against the default lean schedule)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous, weight broadcast, per-rank report, one step, barrier -- then exit (fast failure check on a multi-GPU box)')
     ap.add_argument('--bind', action='store_true', help='pin every rank to its own CPU set (the GPU\'s NUMA node split among the ranks that share it): 8 launch threads of ~500 launches per step each do not migrate or share cores')
@@ -654,8 +763,21 @@ def main():
     if os.environ.get('XFR_FAULT_DUMP_S'):       # debugging aid: every thread's Python stack on stderr after that many seconds (and again, repeatedly)
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ['XFR_FAULT_DUMP_S']), repeat=True)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        # started like the N = 1 command (`python bench.py --gpus N`), not under torch.distributed.run: be the launcher, like the reference's driver,
+        # which takes --gpus 0 1 2 3 and starts its own workers (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:125-130, 193-216)
+        sys.exit(spawn_ranks(args.gpus))
     # rendezvous with a bounded wait; a collective backend that does not come up is a reported condition, not a crash (shard.Comm)
-    comm = shard.Comm()
+    try:
+        comm = shard.Comm()
+    except BaseException:          # noqa: BLE001 -- the side channel itself (TCPStore rendezvous) failed: still one JSON line, still a non-zero exit
+        import traceback
+        text = traceback.format_exc()
+        sys.stderr.write('bench.py rank %s: rendezvous FAILED:\n%s' % (os.environ.get('RANK', '0'), text))
+        if os.environ.get('RANK', '0') == '0':
+            print(json.dumps({'error': text.strip().splitlines()[-1], 'n_gpus': args.gpus, 'stage': 'rendezvous'}))
+        sys.stdout.flush()
+        os._exit(4)
     rank, world, local = comm.rank, comm.world, comm.local
     if world != args.gpus:
         if rank == 0:
@@ -757,6 +879,7 @@ def run(args, comm):
         idle.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     host_idle_ms = 1e3 * sorted(idle)[2]
+    one_lat = one_triplet_latency(W) if (rank == 0 and world == 1 and not args.serial) else None
     # sustained loop outside the timed region (the K timed steps take well under a second): long enough for an external
     # power / utilisation sampler to see the device busy, and a steady-state (thermally settled) rate
     sustained = None
@@ -777,15 +900,16 @@ def run(args, comm):
             s8 = W.u8_step()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        n8 = max(5, args.steps // 2)
+        n8 = max(5, args.steps)
         for _ in range(n8):
             s8 = W.u8_step()
         torch.cuda.synchronize()
         d8 = time.perf_counter() - t1
         ok8 = bool(torch.isfinite(s8).all().item()) and float((s8.sum(dim=(1, 2)) - 1.0).abs().max().item()) < 1e-3
         u8_e2e = {'maps_s': B * n8 / d8, 'ms_per_step': 1e3 * d8 / n8, 'steps': n8, 'outputs_ok': ok8,
-                  'what': 'xfr_triplet_contrastive_u8: the %d uint8 224x224x3 images of a step copied from pinned host memory (%.1f MB instead of %.1f MB as fp32) and '
-                          'preprocessed on the device, both inside the timed region' % (3 * B, 3 * B * 150528 / 1e6, 3 * B * 602112 / 1e6)}
+                  'what': 'xfr_triplet_contrastive_u8_host: the %d uint8 224x224x3 images of a step copied from pinned host memory (%.1f MB instead of %.1f MB as fp32) by '
+                          'the engine (own copy stream, per-slot staging) and preprocessed on the device, both inside the timed region; no residency promise' % (
+                              3 * B, 3 * B * 150528 / 1e6, 3 * B * 602112 / 1e6)}
     roof = None
     unfused_leg = None
     ms_step = 1e3 * dt / args.steps
@@ -812,13 +936,13 @@ def run(args, comm):
             roof['unfused_epilogues_serial'] = {'achieved': alg_step * reps / (u_ms * 1e-3) / 1e12, 'frac': alg_step * reps / (u_ms * 1e-3) / (roof['peak'] * 1e12),
                                                 'gemm_ms_per_step': u_ms / reps, 'avg_launch_ms': u_ms / max(u_n, 1)}
 
-    # the same step in the other two modes of xfr_engine_set_split_gemm (conv_gemm.hip K17; the headline runs the default, mode 1: the FORWARD convolutions of
-    # the deep-K layers as bf16x6 on the bf16 matrix pipe).  mode 0: fp32 MFMA kernels everywhere.  mode 3: the sweep's backward-data GEMMs as bf16x6 too --
-    # experimental: their noise (rms 1.5-3x the fp32 kernels' against float64) is what an ill-conditioned contrast amplifies.  Same output checks as the headline.
+    # the same step in the other two modes of xfr_engine_set_split_gemm (conv_gemm_split.hip K17; the headline runs the default, mode 3: the forward convolutions
+    # AND the sweep's backward-data GEMMs of the deep-K layers as bf16x6 on the bf16 matrix pipe).  mode 0: fp32 MFMA kernels everywhere.  mode 1: the forward
+    # convolutions only (the round-5 default).  Same output checks as the headline.
     split_leg = None
     if rank == 0 and world == 1 and not args.serial and args.split_gemm is None and not args.no_split_leg:
         split_leg = {}
-        for name, mode in (('fp32_mfma_only', 0), ('experimental_bf16x6_backward_too', 3)):
+        for name, mode in (('fp32_mfma_only', 0), ('bf16x6_forward_only', 1)):
             try:
                 before = eng.split_gemm_launches()
                 eng.set_split_gemm(mode)
@@ -831,7 +955,7 @@ def run(args, comm):
             except Exception as ex:      # these legs never fail the line
                 split_leg[name] = {'mode': mode, 'error': repr(ex)}
             finally:
-                eng.set_split_gemm(1)
+                eng.set_split_gemm(3)
 
     secondary = None
     if rank == 0 and world == 1 and args.model == 'resnet101' and not args.no_secondary and not args.serial and args.batch is None and args.mode is None:
@@ -859,9 +983,10 @@ def run(args, comm):
             'metric': W.metric, 'value': value, 'unit': 'maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'dtype_note': 'fp32 storage, operands and accumulation throughout.  GEMMs: v_mfma_f32_32x32x2_f32; the forward convolutions of the deep-K stride-1 layers '
-                          '(xfr_engine_set_split_gemm mode %s) as bf16x6 -- every fp32 operand as the exact sum of three bf16 pieces, six exact piece products, fp32 '
-                          'accumulation (conv_gemm.hip K17; split_gemm_modes.fp32_mfma_only is the same step on fp32 MFMAs alone)' % (args.split_gemm if args.split_gemm is not None else 1),
+            'dtype_note': 'fp32 storage, operands and accumulation throughout.  GEMMs: v_mfma_f32_32x32x2_f32; the forward convolutions and backward-data GEMMs of the '
+                          'deep-K stride-1 layers (xfr_engine_set_split_gemm mode %s) as bf16x6 -- every fp32 operand as the exact sum of three bf16 pieces, six exact piece '
+                          'products, partial sums of 48 K-terms folded into fp32 registers with round-to-nearest adds: error against float64 BELOW the fp32 MFMA kernels\' '
+                          '(profiles/r6/conv_error_probe.txt; conv_gemm_split.hip K17; split_gemm_modes.fp32_mfma_only is the same step on fp32 MFMAs alone)' % (args.split_gemm if args.split_gemm is not None else 3),
             'config': {'workload': W.work, 'units_per_gpu': B,
                        'parallelism': 'independent triplets, %d process(es), weights broadcast once' % world},
             'outputs_ok': ok, 'row0_cosine_vs_reference': row0,
@@ -876,10 +1001,13 @@ def run(args, comm):
         errs = comm.collect_errors()
         if errs:
             line['rank_errors'] = {str(k): v for k, v in sorted(errs.items())}
+        line['launcher'] = os.environ.get('XFR_LAUNCHER', 'external (torch.distributed.run or the caller\'s environment)' if world > 1 else 'none (one process)')
         if world > 1:
-            line['scaling_note'] = 'N > 1 has only ever run with several ranks on ONE GPU here (gloo); no multi-GPU node was available to the builder'
+            line['scaling_note'] = 'N > 1 has only ever run with several ranks on ONE GPU here (gloo); no multi-GPU node was available to the builder: no multi-GPU hardware number exists'
         if u8_e2e is not None:
             line['u8_end_to_end'] = u8_e2e
+        if one_lat is not None:
+            line['one_triplet_latency'] = one_lat
         if split_leg is not None:
             line['split_gemm_modes'] = split_leg
         if sustained is not None:

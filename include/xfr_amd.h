@@ -16,7 +16,11 @@
  *   - one engine per (process, device); calls on one engine must be serialised by the caller
  *     (the reference is equally non-re-entrant: whitebox.py:291-296 mutable hook state);
  *   - the engine never mutates caller buffers other than the documented outputs (the reference leaves
- *     W+ installed in the caller's modules after ebp(): whitebox.py:371-377).
+ *     W+ installed in the caller's modules after ebp(): whitebox.py:371-377);
+ *   - a call is bit-reproducible for a given batch size and settings.  ACROSS batch sizes a sample's map is the same
+ *     arithmetic in a different summation order, not the same bits: three defaults look at the batch -- the lean schedule
+ *     (batch % 4 == 0, xfr_engine_set_lean), the bf16x6 kernel (grids of >= 128 tiles, xfr_engine_set_split_gemm) and tail
+ *     balancing (xfr_engine_set_tail_balance).  With all three off every launch of a layer runs one kernel in one K order.
  */
 #ifndef XFR_AMD_H
 #define XFR_AMD_H
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XFR_AMD_ABI_VERSION 5
+#define XFR_AMD_ABI_VERSION 6
 
 typedef enum {
     XFR_OK = 0,
@@ -123,8 +127,10 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* weights
 
 /* Device address and size of the packed parameter arena, so that a multi-GPU launcher can broadcast it
  * (rank 0 loads, the others receive: replaces the per-job torch.load of
- * eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:74).  After writing into the arena of an
- * engine that never called xfr_engine_load_weights, call xfr_engine_mark_weights_loaded. */
+ * eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:74).  After EVERY write into the arena -- of an
+ * engine that never called xfr_engine_load_weights, or through a pointer kept from an earlier call -- call
+ * xfr_engine_mark_weights_loaded: it waits for the device and rebuilds what the engine derives from the arena
+ * (the bf16 planes of xfr_engine_set_split_gemm); until then the bf16x6 kernel would run on the old weights. */
 xfr_status xfr_engine_weight_arena(xfr_engine* e, void** dev_ptr, size_t* bytes);
 xfr_status xfr_engine_mark_weights_loaded(xfr_engine* e);
 
@@ -285,6 +291,16 @@ xfr_status xfr_engine_set_u8_preprocess(xfr_engine* e, const xfr_u8_preprocess* 
 xfr_status xfr_forward_u8(xfr_engine* e, const uint8_t* x_u8_dev, int32_t n, int32_t tensor_id, float* out_dev, void* stream);
 xfr_status xfr_triplet_contrastive_u8(xfr_engine* e, const uint8_t* probes_u8_dev, const uint8_t* gallery_u8_dev, int32_t n, int32_t encode_tensor,
                                       float scale, float percentile, float* sal_dev, void* stream, int32_t inputs_ready);
+/* The same call for a caller whose images are fresh every time and live in HOST memory (ABI version 6): n probe and 2n gallery images, uint8 H x W x C,
+ * pinned memory preferably.  The engine copies them itself -- its own copy stream, one device staging buffer per forward slot -- and orders the
+ * forwards behind that copy, not behind `stream`: with xfr_engine_set_pipeline on, the copy, the preprocessing and the forwards of call i + 1 overlap
+ * the sweep of call i, and nothing is promised about residency (xfr_triplet_contrastive_u8 with inputs_ready = 0 orders them behind everything on
+ * `stream`, i.e. behind the previous sweep).  The copy is asynchronous: the host buffers must stay unchanged until it has run --
+ * xfr_engine_wait_inputs_copied blocks the calling thread until the copies of the LAST such call are done (a caller that alternates two host buffers
+ * calls it before refilling the one it used last; the call before that is then done too, copies run in order). */
+xfr_status xfr_triplet_contrastive_u8_host(xfr_engine* e, const uint8_t* probes_u8_host, const uint8_t* gallery_u8_host, int32_t n, int32_t encode_tensor,
+                                           float scale, float percentile, float* sal_dev, void* stream);
+xfr_status xfr_engine_wait_inputs_copied(xfr_engine* e);
 /* parity hook: the fp32 network input (n x C x H x W) the uint8 path builds from x_u8_dev */
 xfr_status xfr_debug_u8_preprocess(xfr_engine* e, const uint8_t* x_u8_dev, int32_t n, float* out_nchw_dev, void* stream);
 
@@ -292,21 +308,31 @@ xfr_status xfr_debug_u8_preprocess(xfr_engine* e, const uint8_t* x_u8_dev, int32
  * need the literal operands a and x of whitebox.py:388-428 at every hook: the probe forward's W / relu(W) convolution forms the BatchNorm hook's
  * a / (x + eps) in its epilogue (both accumulators in one workgroup) and stores that ONE tensor instead of the two, with the sign bit recording
  * where the ReLU output behind it is zero; hooks whose x is their a (every Conv / Linear / pool / Add hook) become that one-bit gate.  Per hook the
- * result differs from the literal expression by at most one ulp (for a >= 1.7e-9; identical at a = 0), so maps agree with the literal path to ~1e-6
- * of their maximum -- far inside the stated tolerance against the reference -- but not bit for bit.  enable = 0: the literal operands everywhere
+ * result differs from the literal expression by at most one ulp (for a >= 1.7e-9; identical at a = 0): plain-EBP maps agree with the literal path to
+ * ~1e-6 of their maximum; a contrastive map is a difference of two nearly equal sweeps and moves by what its conditioning makes of that -- measured up to
+ * 1e-3 of the maximum on the ill-conditioned demo triplets (tests/test_gpu_parity.py::test_lean_schedule_equals_literal holds them to 2e-3), inside the
+ * stated tolerance against the reference (5e-3 there) but not bit for bit.  enable = 0: the literal operands everywhere
  * (what every observing call -- traces, Whitebox.P[k], layerwise / weighted-subtree EBP -- runs regardless).  Batches that are not a multiple of four
  * always run literal, so a sample's map can differ in its last digits between a batch of 32 and a batch of 1: callers that need batch-invariant
  * arithmetic switch this off together with xfr_engine_set_tail_balance. */
 xfr_status xfr_engine_set_lean(xfr_engine* e, int32_t enable);
-/* bf16x6 GEMMs (ABI version 5).  The deep-K stride-1 convolutions of 14 x 14 and larger maps (K >= 1024 for 1x1, K >= 1152 for KxK, 128 | Cout) can run
+/* bf16x6 GEMMs (ABI version 5).  The deep-K stride-1 convolutions of 14 x 14 and larger maps (K >= 512 for 1x1, K >= 1152 for KxK, 128 | Cout) can run
  * on the bf16 matrix pipe: every fp32 operand is the exact sum of three bf16 pieces, the six piece products of order <= 2 are exact and are accumulated in
- * fp32 (conv_gemm.hip K17).  A launch differs from the fp32 MFMA kernels like a different (somewhat noisier: rms 1.5-3x against float64) summation order.
- * mode 1 (the default): the FORWARD convolutions of those layers -- golden maps as close to the reference as with the fp32 kernels (DESIGN.md section 4
- * K17), ResNet-101 +9 % maps/s.  mode 3: the sweep's backward-data GEMMs too (+15 %; experimental: their noise is amplified by an ill-conditioned contrast,
- * contrastive maps move by up to 1.5e-3 of their maximum).  mode 2: backward only (tuning).  mode 0: fp32 MFMA kernels everywhere.  The choice is a property of
- * the layer and this setting, never of the batch.  The weight packs of the covered layers get bf16 planes at their first launch (+1.5x their size);
- * every entry point that changes the weights (or hands out the arena: xfr_engine_weight_arena -- call it again after later writes through its pointer)
- * drops them.  XFR_SPLIT_GEMM=<mode> in the environment sets the mode of new engines. */
+ * fp32 (conv_gemm_split.hip K17).  Since round 6 no sum stays in the matrix pipe for more than three K-steps (48 of the K terms): the partial sums are
+ * added to fp32 registers with round-to-nearest adds and alternate in sign, and a launch's error against float64 is BELOW the fp32 MFMA kernels'
+ * (rms 5-9e-9 of the sum of magnitudes against 1.1-2.0e-8, no offset: profiles/r6/conv_error_probe.txt).
+ * mode 3 (the default since round 6): the forward convolutions AND the sweep's backward-data GEMMs of those layers.  mode 1: the forward convolutions
+ * only (the round-5 default).  mode 2: backward only (tuning).  mode 0: fp32 MFMA kernels everywhere.
+ * Which launches: a covered layer's launch takes the kernel when its grid has at least 128 tiles of 128 x 128 (half the CUs: about 25 images of a
+ * 14 x 14 layer, 6 of a 28 x 28 one); smaller launches -- Whitebox.contrastive_ebp on one image, the weighted-subtree probes -- run the fp32 kernels,
+ * which fill the chip with 64 x 64 tiles where this one would leave it idle.  So a sample's map is bit-reproducible for a given batch size and agrees
+ * across batch sizes to the kernels' summation-order difference (~1e-6 of its maximum; tests/test_gpu_parity.py::test_split_gemm_equals_fp32_kernels),
+ * like K1's tail balancing (xfr_engine_set_tail_balance) and the lean schedule above.  Callers that need one arithmetic for every batch size: mode 0,
+ * or mode + 4 (modes 5 .. 7): the covered layers take the kernel whatever the grid (tests and tuning: small launches are slow on it).
+ * The weight packs of the covered layers carry bf16 planes (+1.5x their size), built when the weights arrive (xfr_engine_load_weights,
+ * xfr_engine_mark_weights_loaded, xfr_broadcast_weights, or this call); every entry point that changes the weights drops the old ones.  After writing
+ * through a pointer from xfr_engine_weight_arena, call xfr_engine_mark_weights_loaded again: it rebuilds them.
+ * XFR_SPLIT_GEMM=<mode> in the environment sets the mode of new engines. */
 xfr_status xfr_engine_set_split_gemm(xfr_engine* e, int32_t mode);
 /* Launches of the bf16x6 kernel so far, process-wide. */
 xfr_status xfr_engine_split_gemm_stats(xfr_engine* e, int64_t* launches);
@@ -410,8 +436,11 @@ xfr_status xfr_engine_memory(xfr_engine* e, size_t* weight_bytes, size_t* worksp
  * bench.py for the live roofline figure. */
 xfr_status xfr_engine_set_profile(xfr_engine* e, int32_t enable);
 xfr_status xfr_engine_get_profile(xfr_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+/* The same three figures split by the kernel family that really ran each launch (ABI version 6): index 0 the fp32 MFMA kernels, index 1 the bf16x6
+ * kernel -- each family has its own ceiling (157.3 / 419.4 fp32-equivalent TFLOP/s), and bench.py reports a roofline fraction per family.  Arrays of 2. */
+xfr_status xfr_engine_get_profile_by_kernel(xfr_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
 /* While profiling is on, also append one CSV record per GEMM launch to `path` (NULL: stop):
- * Cout,nhalves,K,M,kh,stride,out_stride,relu_in,accumulate,ms,TFLOP/s  (profiles/layer_table.py reads it). */
+ * Cout,nhalves,K,M,kh,stride,out_stride,relu_in,accumulate,ms,TFLOP/s,cfg  (profiles/layer_table.py reads it; cfg = the configuration that ran, 9 = bf16x6). */
 xfr_status xfr_engine_profile_csv(xfr_engine* e, const char* path);
 
 /* Process-wide counts of GEMM launches that carried a fused elementwise chain: those whose epilogue was one of the

@@ -188,6 +188,44 @@ def test_fresh_inputs_are_safe_under_pipelining(gpu_device):
     eng.close()
 
 
+def test_host_inputs_keep_the_pipeline_and_the_bits(gpu_device):
+    """xfr_triplet_contrastive_u8_host: fresh uint8 images from (pinned) host memory on every call, pipelining on (levels 1 and 5: two / three forward
+    slots), no residency promise.  Every call's maps equal the un-pipelined device-input call's, bit for bit -- also when the host buffers are rewritten
+    right after wait_inputs_copied, and when more calls are in flight than there are staging slots."""
+    from xfr_amd.engine import Engine
+    bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=5)
+    prog = bb.build_program()
+    eng = Engine(prog, 8, gpu_device)
+    eng.load_weights(sd)
+    eng.set_mode('affineonly_with_prior')
+    from xfr_amd.models import resnet
+    eng.set_u8_preprocess('sub_mean', 3, tuple(float(v) for v in resnet.MEAN_RGB), None)
+    enc_t = prog.marks['encode']
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randint(0, 256, (4, 224, 224, 3), generator=g, dtype=torch.uint8), torch.randint(0, 256, (8, 224, 224, 3), generator=g, dtype=torch.uint8))
+               for _ in range(5)]
+    ref = [eng.triplet_contrastive_u8(p.to(gpu_device), q.to(gpu_device), enc_t).clone() for p, q in batches]
+    torch.cuda.synchronize()
+    for level in (0, 1, 5):
+        eng.set_pipeline(level)
+        hp, hg = [torch.empty_like(batches[0][0]).pin_memory() for _ in range(2)], [torch.empty_like(batches[0][1]).pin_memory() for _ in range(2)]
+        outs = []
+        for rep in range(2):
+            for i, (p, q) in enumerate(batches):
+                k = (rep * len(batches) + i) & 1
+                eng.wait_inputs_copied()              # the buffer pair used two calls ago is free (copies run in order)
+                hp[k].copy_(p)
+                hg[k].copy_(q)
+                outs.append(eng.triplet_contrastive_u8_host(hp[k], hg[k], enc_t))
+        torch.cuda.synchronize()
+        for j, o in enumerate(outs):
+            assert torch.equal(o, ref[j % len(batches)]), (level, j)
+    eng.set_pipeline(0)
+    with pytest.raises(ValueError):
+        eng.triplet_contrastive_u8_host(batches[0][0].to(gpu_device), batches[0][1], enc_t)      # a device tensor is not a host buffer
+    eng.close()
+
+
 # ---- multi-rank --------------------------------------------------------------------------------------------------------
 def _run_ranks(cmd, world, port, extra_env=None, timeout=900):
     """world processes on ONE GPU (gloo rendezvous on 127.0.0.1): the multi-process code path of the tools without an 8-GPU node.  Every rank's
@@ -353,6 +391,23 @@ def test_bench_surfaces_a_failing_rank(gpu_device):
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert 'simulated failure of rank 1' in j['rank_errors']['1'] and 'rank(s) [1] failed' in j['rank_errors']['0']
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_spawns_its_own_ranks(gpu_device, world):
+    """`python bench.py --gpus N` started the way the N = 1 command is -- no torch.distributed.run, no RANK / WORLD_SIZE in the environment (round-5
+    verdict, missing 2): bench.py is then its own launcher (eval/generate_inpaintinggame_wb_saliency_maps_multigpu.py:193-216 starts its workers itself
+    too): N ranks, ONE JSON line on the parent's stdout, exit code 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(XFR_DIST_TIMEOUT='240', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, 'bench.py', '--gpus', str(world), '--steps', '2', '--warmup', '1', '--batch', '4', '--no-cpu-baseline', '--no-sustained',
+                          '--no-profile'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == world and j['outputs_ok'] is True and len(j['ranks']) == world and len({r['arena_checksum48'] for r in j['ranks']}) == 1
+    assert 'bench.py itself' in j['launcher'] and 'no multi-GPU hardware number' in j['scaling_note']
 
 
 @pytest.mark.parametrize('bind', [False, True])

@@ -267,7 +267,7 @@ def test_golden_cases_on_the_split_gemm(gpu_device, arch, mode):
         bb, sd = make_backbone(arch, seed=0)
     subj = GC.engine_subject(arch, bb, mode)
     eng = subj.wb._engine(1)
-    eng.set_split_gemm(3)
+    eng.set_split_gemm(3 | 4)      # + 4: whatever the grid (these replays run batches of one and four; by default such launches stay on the fp32 kernels)
     before = eng.split_gemm_launches()
     inner = _check_factory()
 
@@ -302,13 +302,13 @@ def test_split_gemm_equals_fp32_kernels(gpu_device, arch, mode):
     eng = wb._engine(2 * n)
     res, launches = {}, {}
     for split in (3, 1, 0):
-        eng.set_split_gemm(split)
+        eng.set_split_gemm(split | 4 if split else 0)       # + 4: small grids too (four images; the default rule would leave them on the fp32 kernels)
         before = eng.split_gemm_launches()
         res[split] = (wb.encode(x).clone(), wb.contrastive_triplet_ebp_batch(x, xm, xn).clone(),
                       wb.contrastive_triplet_ebp_batch(x, xm, xn, percentile=20).clone(),
                       torch.as_tensor(wb.ebp(x, torch.tensor([[1.0, 0.0]]))))
         launches[split] = eng.split_gemm_launches() - before
-    eng.set_split_gemm(1)
+    eng.set_split_gemm(3)
     assert launches[3] > launches[1] > 0 and launches[0] == 0, launches
     for split in (3, 1):
         e1, e0 = res[split][0].float().cpu(), res[0][0].float().cpu()
@@ -325,6 +325,35 @@ def test_split_gemm_equals_fp32_kernels(gpu_device, arch, mode):
                     assert_map_close_robust(a[i], b[i], tag, rtol=LEAN_RTOL_CONTRAST)
                 else:
                     assert_map_close(a[i], b[i], tag, rtol=LEAN_RTOL_CONTRAST)
+
+
+def test_bf16_planes_follow_the_weights(gpu_device):
+    """Round-5 verdict, weak 6: a caller keeps the arena view, runs a forward (the bf16x6 planes of the covered packs exist), writes NEW weights through
+    the view and calls mark_weights_loaded.  The bf16x6 forward must then run on the new weights like the fp32 kernels do -- stale planes would leave the
+    deep-K convolutions on the old ones, silently."""
+    arch, mode = 'resnet50_128', 'norelu'
+    bb, _ = make_backbone(arch, seed=6)
+    bb2, _ = make_backbone(arch, seed=9)
+    subj, subj2 = GC.engine_subject(arch, bb, mode), GC.engine_subject(arch, bb2, mode)
+    x = make_images(arch, 2, seed=5, smooth=True).to(gpu_device)
+    eng, eng2 = subj.wb._engine(4), subj2.wb._engine(4)
+    enc = subj.wb.net._program.marks['encode']
+    eng.set_split_gemm(3 | 4)
+    view = eng.weight_arena()                       # the retained pointer
+    before = eng.split_gemm_launches()
+    old = eng.forward(x, enc).clone()               # planes are (re)built for this forward
+    assert eng.split_gemm_launches() > before
+    view.copy_(eng2.weight_arena())
+    eng.mark_weights_loaded()
+    got = eng.forward(x, enc).clone()
+    eng.set_split_gemm(0)
+    want = eng.forward(x, enc).clone()
+    eng2.set_split_gemm(0)
+    ref = eng2.forward(x, enc)
+    assert torch.equal(want, ref)                   # the fp32 kernels read the arena itself
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-5 * scale, 'bf16x6 forward ran on stale planes'
+    assert float((old - want).abs().max()) > 1e-2 * scale      # (the two weight sets do differ)
 
 
 # ---- oracle on fresh seeded inputs, batched ----------------------------------------------------------------------------
@@ -441,10 +470,11 @@ def test_truncation_tail_equals_reference_formula_on_engine_P(gpu_device):
 # ---- full BASELINE.json size: properties that do not need the (slow) CPU path --------------------------------------------
 def test_resnet101_batch32_properties(gpu_device):
     """ResNet-101, 32 triplets (BASELINE.json configs[1]): every map is finite, non-negative and sums to 1; samples
-    are independent (a sample computed alone gives the same map); the batch is permutation-equivariant.  With GEMM
-    tail balancing off the arithmetic is batch-invariant and both hold to fp32 noise of the final normalisation; with
-    it on (the default) K is summed in a different order for the tiles that are cut, so they hold to the contrastive
-    tolerance (parity_utils.MAP_RTOL_CONTRAST)."""
+    are independent (a sample computed alone gives the same map); the batch is permutation-equivariant.  With the three
+    batch-dependent defaults off (GEMM tail balancing, the lean schedule, the bf16x6 kernel: include/xfr_amd.h, Conventions) the
+    arithmetic is batch-invariant and both hold to fp32 noise of the final normalisation; with them on K is summed in a
+    different order (cut tiles, another kernel for the small grid), so they hold to the contrastive tolerance
+    (parity_utils.MAP_RTOL_CONTRAST)."""
     bb, sd = make_backbone('stresnet101', seed=0, num_classes=2)
     subj = GC.engine_subject('stresnet101', bb, 'affineonly_with_prior')
     wb = subj.wb
@@ -461,6 +491,8 @@ def test_resnet101_batch32_properties(gpu_device):
         # batch-invariant arithmetic also needs ONE form of the hooks for every batch size: the lean schedule applies to batches that are a
         # multiple of four (32 yes, 1 no), so the strict leg runs the literal schedule; the default leg compares lean (32) with literal (1)
         wb._engine(B).set_lean(balanced)
+        # ... and ONE kernel per layer: by default the bf16x6 kernel takes a covered layer's launch only when its grid is large enough (32 images yes, 1 no)
+        wb._engine(B).set_split_gemm(3 if balanced else 0)
         sal = wb.contrastive_triplet_ebp_batch(probes, em, en)
         assert tuple(sal.shape) == (B, 112, 112)
         assert bool(torch.isfinite(sal).all()) and float(sal.min()) >= 0.0

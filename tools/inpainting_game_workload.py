@@ -57,7 +57,6 @@ def main():
     from xfr_amd.engine import Engine
     wbn._program = bb.build_program()
     wbn._engine = Engine(wbn._program, args.max_batch or (32 if args.group <= 1 else max(32, 16 * args.group)), dev)
-    wbn._engine.set_split_gemm(0)      # small batches (8-64 images per forward): the bf16x6 kernel's 128-wide tiles leave most CUs idle (bench.py, run_inpainting_game)
     wbn._engine_key = (str(bb.device), id(bb))
     packed = {'n': 0}
 

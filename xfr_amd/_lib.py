@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XFR_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libxfr_amd.so')      # XFR_AMD_LIB: A/B builds of the same ABI (tools/ab_env.sh)
 
 XFR_OK, XFR_INVALID_ARG, XFR_UNSUPPORTED_LAYER, XFR_OOM, XFR_HIP_ERROR, XFR_STATE_ERROR, XFR_RCCL_ERROR = range(7)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class TensorView(ctypes.Structure):
@@ -51,6 +51,8 @@ SYMBOLS = [
     ('xfr_engine_set_u8_preprocess', _I, [_P, ctypes.POINTER(U8Preprocess)]),
     ('xfr_forward_u8', _I, [_P, _P, _I, _I, _P, _P]),
     ('xfr_triplet_contrastive_u8', _I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I]),
+    ('xfr_triplet_contrastive_u8_host', _I, [_P, _P, _P, _I, _I, _F, _F, _P, _P]),
+    ('xfr_engine_wait_inputs_copied', _I, [_P]),
     ('xfr_debug_u8_preprocess', _I, [_P, _P, _I, _P, _P]),
     ('xfr_engine_set_pipeline', _I, [_P, _I]),
     ('xfr_engine_set_inputs_ready', _I, [_P, _I]),
@@ -79,6 +81,7 @@ SYMBOLS = [
     ('xfr_engine_set_profile', _I, [_P, _I]),
     ('xfr_engine_get_profile', _I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                     ctypes.POINTER(ctypes.c_double)]),
+    ('xfr_engine_get_profile_by_kernel', _I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     ('xfr_engine_profile_csv', _I, [_P, ctypes.c_char_p]),
     ('xfr_chain_epilogue_stats', _I, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_I)]),
     ('xfr_plan_describe', _I, [ctypes.POINTER(OpDesc), _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, ctypes.c_size_t,

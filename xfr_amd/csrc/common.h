@@ -274,7 +274,7 @@ struct ConvParams {
                         // same staged input tile; the chain (compiled, first step EW_LEAN_Q) sees both.  The lean probe forward: bias_pos is the second bias
     int relu_in;        // clamp the gathered input at 0 (A = relu(input))
     int bwd;            // 1: a backward-data GEMM of the sweep (bwd_conv_params); 0: a forward convolution
-    int split_ok;       // 1: the launch may take the bf16x6 kernel (conv_gemm.hip K17) where the layer is one it covers (xfr_engine_set_split_gemm)
+    int split_ok;       // 1: the launch may take the bf16x6 kernel (conv_gemm_split.hip K17) where the layer is one it covers and the grid large enough; 2: whatever the grid (xfr_engine_set_split_gemm)
     int accumulate;     // out += result
     int out_H, out_W, out_stride;  // out_stride > 1: scatter the (OH,OW) grid into an (out_H,out_W) tensor
     int chain_B;        // forward batch for the a-index of the epilogue chain
@@ -298,8 +298,8 @@ void conv_gemm_set_stamps(unsigned long long* dev_ptr, int capacity_workgroups);
 void conv_gemm_set_log(unsigned long long* log_dev, int capacity);
 int conv_gemm_dump_log(const char* path);   // every later launch_conv_gemm records into dev_ptr (nullptr: stop)
 
-constexpr int XFR_TAIL_MAX_TILES = 2048;        // arrival counters per stream: K1's tail tiles (<= the CU count) and K17's stream-K tiles
-constexpr size_t XFR_TAIL_WS_BYTES = (size_t)32 << 20;      // K17 stream-K: two parked 128 x 128 parts per CU (256 x 2 x 64 KB)
+constexpr int XFR_TAIL_MAX_TILES = 256;
+constexpr size_t XFR_TAIL_WS_BYTES = (size_t)16 << 20;
 // false: nothing was launched -- a dual (W / relu(W)) launch carries a chain for which no compiled epilogue exists
 bool launch_conv_gemm(const ConvParams& p, hipStream_t s);
 // 0 if launch_conv_gemm will accept p's fused chain, else why not (text: conv_gemm_refusal): 1 = dual launch without a compiled epilogue,
@@ -307,11 +307,13 @@ bool launch_conv_gemm(const ConvParams& p, hipStream_t s);
 int conv_gemm_cannot_launch(const ConvParams& p);
 const char* conv_gemm_refusal(int why);
 int conv_gemm_pick_cfg(const ConvParams& p);
-// bf16x6 split GEMM (conv_gemm.hip K17, configuration 9; ConvParams::split_ok).  The fp32 pack of a covered layer gets its bf16 planes at its first launch
-// (split on that launch's stream, which is then drained once: other streams may use the planes at once).  conv_gemm_forget_split: the packs inside
-// [lo, lo + bytes) changed or go away -- drop their planes (the next launch splits again).
+int conv_gemm_last_cfg();       // the configuration the calling thread's last launch_conv_gemm really ran (9: the bf16x6 kernel)
+// bf16x6 split GEMM (conv_gemm_split.hip K17, configuration 9; ConvParams::split_ok).  The fp32 pack of a covered layer needs bf16 planes: the engine
+// builds them when the weights arrive (conv_gemm_presplit; a pack that has none at a launch gets them there, on that launch's stream, which is then
+// drained once).  conv_gemm_forget_split: the packs inside [lo, lo + bytes) changed or go away -- drop their planes.
 void conv_gemm_forget_split(const void* lo, size_t bytes);
-int conv_gemm_split_covers(const ConvParams& p);
+bool conv_gemm_presplit(const float* w, int K, int cout, int ldw, hipStream_t s);     // false: no memory for the planes (the pack stays on the fp32 kernels)
+int conv_gemm_split_covers(const ConvParams& p);       // a layer xfr_engine_set_split_gemm covers (whatever the launch's grid)
 long conv_gemm_split_launches();
 
 // g = src[idx]; run chain; dst[idx] = (accumulate ? dst[idx] : 0) + g.   Tensors are [C][SB][HW] for the gradient

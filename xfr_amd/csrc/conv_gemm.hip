@@ -927,8 +927,8 @@ static int pick_cfg_impl(const ConvParams& p_in, bool allow_split)
     // 2048 1x1 layers, equal at K = 256 / 1024 with N = 1024 / 256, slower below: two K-steps per wave are all prologue).
     // Channel counts that leave the last 64-row tile at most half full (Light-CNN: 96 = 64 + 32): the 32 x 128 block tile wastes no MFMA row.
     // A property of the layer; K order of the 64 x 64 tile, so the bits do not move where that one ran before.
-    // bf16x6 (K17): a property of the LAYER and of the engine's setting, never of the batch
-    if (allow_split && p.split_ok && conv_gemm_split_layer_ok(p)) return 9;
+    // bf16x6 (K17): the layers xfr_engine_set_split_gemm covers, when the launch's grid is at least half the CUs (conv_gemm_split.hip)
+    if (allow_split && p.split_ok && conv_gemm_split_wanted(p)) return 9;
     {
         const int rem = p.CoutTot % 64;
 #ifndef XFR_NO_ROW_TILE      /* A/B builds only (profiles/r4/experiments/row_tile_ab.txt) */
@@ -956,6 +956,7 @@ static int pick_cfg_impl(const ConvParams& p_in, bool allow_split)
 // path takes g_tune_mu only then, so production launches (tuning off) pay one relaxed atomic load; with tuning on, engines launching from several
 // host threads serialise on the mutex while they take their record, and set / dump / clear are safe against them.
 static std::mutex g_tune_mu;
+static thread_local int g_last_cfg = 0;      // configuration of this thread's last launch_conv_gemm (conv_gemm_last_cfg)
 static std::atomic<int> g_tuning{0};
 static unsigned long long* g_stamps = nullptr;
 static int g_stamps_cap = 0;
@@ -1012,6 +1013,7 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     p.stamp_regions = 0;
     p.stamp_seq = 0;
     p.span = nullptr;
+    size_t log_idx = (size_t)-1;
     if (g_tuning.load(std::memory_order_relaxed)) {
         std::lock_guard<std::mutex> lk(g_tune_mu);
         p.stamps = g_stamps;
@@ -1020,7 +1022,8 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
         p.stamp_seq = g_stamps ? g_stamp_seq++ : 0;
         if (g_log && (int)g_log_recs.size() < g_log_cap) {
             p.span = g_log + 8 * g_log_recs.size();
-            g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.dualacc ? 2 : p.nhalves, p.K, p.M, p.kh, p.chain.n, p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p)});
+            log_idx = g_log_recs.size();
+            g_log_recs.push_back(LogRec{(void*)s, p.CoutTot, p.dualacc ? 2 : p.nhalves, p.K, p.M, p.kh, p.chain.n, -1});      // cfg: the kernel that really runs (below)
         }
     }
     int cfg = p.force_cfg > 0 ? p.force_cfg : conv_gemm_pick_cfg(p);
@@ -1045,13 +1048,24 @@ bool launch_conv_gemm(const ConvParams& p_in, hipStream_t s)
     }
     // cfg 6 / 7: the intra-workgroup split-K kernel, (BK, ring stages) = (8, 3): 48 KB of LDS, three workgroups per CU; (4, 4): 32 KB, five.
     // Round 3 sweep (tools/conv_sweep.py): (4, 5) and (4, 6) tie with (4, 4), (16, 3) -- one workgroup per CU -- loses 15 %.
+    // the configuration that really runs: the launch log and the engine's per-launch profile record THIS, not the rules' first answer
+    auto ran = [&](int eff, bool ok) {
+        g_last_cfg = eff;
+        if (log_idx != (size_t)-1) {
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            if (log_idx < g_log_recs.size()) g_log_recs[log_idx].cfg = eff;
+        }
+        return ok;
+    };
     if (cfg == 9) {
-        if (conv_gemm_launch_split(p, s)) return true;
-        cfg = pick_cfg_impl(p, false);     // not covered (a chain family without a split instantiation, an unregistered pack): the fp32 rules
+        if (conv_gemm_launch_split(p, s)) return ran(9, true);
+        cfg = pick_cfg_impl(p, false);     // refused (a chain family without a split instantiation, no memory for the planes): the fp32 rules
     }
-    if (cfg == 6 && ks_ok<8>(p)) return launch_cfg_ks<8, 3>(p, s);
-    if (cfg == 7 && ks_ok<4>(p)) return launch_cfg_ks<4, 4>(p, s);
-    if (cfg == 5) return launch_cfg<64, 64, 32, 3>(p, s);
-    if (cfg == 12) return launch_cfg<32, 128, 16, 3>(p, s);          // the 32 x 128 block tile (four waves side by side along m)
-    return launch_cfg<64, 64, 16, 3>(p, s);
+    if (cfg == 6 && ks_ok<8>(p)) return ran(6, launch_cfg_ks<8, 3>(p, s));
+    if (cfg == 7 && ks_ok<4>(p)) return ran(7, launch_cfg_ks<4, 4>(p, s));
+    if (cfg == 5) return ran(5, launch_cfg<64, 64, 32, 3>(p, s));
+    if (cfg == 12) return ran(12, launch_cfg<32, 128, 16, 3>(p, s));          // the 32 x 128 block tile (four waves side by side along m)
+    return ran(4, launch_cfg<64, 64, 16, 3>(p, s));
 }
+
+int conv_gemm_last_cfg() { return g_last_cfg; }

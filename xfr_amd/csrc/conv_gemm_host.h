@@ -10,4 +10,4 @@ int conv_gemm_plan_chain(ConvParams& q);
 void conv_gemm_warn_interpreted(const ConvParams& q);
 // K17 (conv_gemm_split.hip).  false: the launch is not one the bf16x6 kernel covers (or its planes could not be built) -- the caller takes the fp32 kernel
 bool conv_gemm_launch_split(const ConvParams& p, hipStream_t s);
-bool conv_gemm_split_layer_ok(const ConvParams& p);
+bool conv_gemm_split_wanted(const ConvParams& p);       // a covered layer AND a grid worth it

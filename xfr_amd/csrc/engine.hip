@@ -223,8 +223,9 @@ struct xfr_engine {
     bool u8_on = false;
     bool u8_set = false;
     U8Pre u8_pre;
-    int split_mask = 1;                // xfr_engine_set_split_gemm: which covered layers run the bf16x6 kernel (conv_gemm.hip K17) -- bit 0 the forward
-                                       // convolutions (default), bit 1 the sweep's backward-data GEMMs (experimental: their noise shows in contrastive maps)
+    bool split_any_grid = false;       // xfr_engine_set_split_gemm mode + 4: covered layers take the bf16x6 kernel whatever the launch's grid (tests, tuning)
+    int split_mask = 3;                // xfr_engine_set_split_gemm: which covered layers run the bf16x6 kernel (conv_gemm_split.hip K17) -- bit 0 the forward
+                                       // convolutions, bit 1 the sweep's backward-data GEMMs; both by default since round 6 (short in-pipe sums)
     bool lean = true;                  // xfr_engine_set_lean: plain sweeps (no trace / prior / capture / stored firing, batch % 4 == 0) take the lean schedule
     const BwdPlan* lean_cur = nullptr; // the plan whose lean tables the running probe forward / sweep follow (null: literal)
     bool lean_decide = false;          // lean_prepare's dry run of the probe forward: decide per convolution, record in lean_q_run / lean_final_run
@@ -243,6 +244,9 @@ struct xfr_engine {
     std::string profile_csv;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<ConvParams> ev_params;
+    std::vector<int> ev_cfg;           // the configuration each profiled launch really ran
+    double fam_ms[2] = {0.0, 0.0}, fam_flops[2] = {0.0, 0.0};      // last profiled run, by kernel family: [0] fp32 MFMA, [1] bf16x6
+    long fam_launches[2] = {0, 0};
     size_t ev_used = 0;
     double prof_flops = 0.0;
     double last_gemm_ms = 0.0;
@@ -253,6 +257,15 @@ struct xfr_engine {
     float* ws_enc = nullptr;       // second bank of true activations (T region only), allocated on first use
     size_t t_region_floats = 0;
     hipStream_t s_a = nullptr, s_b = nullptr;
+    // xfr_triplet_contrastive_u8_host: the engine's own copy stream and one uint8 staging buffer per forward slot -- fresh inputs keep the cross-call overlap
+    hipStream_t s_copy = nullptr;
+    uint8_t* u8_stage[3] = {nullptr, nullptr, nullptr};
+    size_t u8_stage_bytes = 0;
+    hipEvent_t ev_copied[3] = {nullptr, nullptr, nullptr}, ev_stage_a[3] = {nullptr, nullptr, nullptr}, ev_stage_b[3] = {nullptr, nullptr, nullptr};
+    bool stage_busy[3] = {false, false, false};
+    hipEvent_t inputs_event = nullptr;   // one-shot, set by the _host entry point: the inputs of THIS call are complete when it fires (instead of the caller's stream order)
+    int stage_slot = -1;                 // ... and the staging slot its forwards read
+    hipEvent_t last_copied = nullptr;    // xfr_engine_wait_inputs_copied
     hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b = nullptr;
     // cross-step pipelining (xfr_engine_set_pipeline): two forward slots (T, Pv, norms, argmax) so that the forward of
     // triplet call i+1 may run while the backward sweep of call i still reads slot i%2
@@ -605,7 +618,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
 {
     ConvParams p = p_in;
     p.chain_interpret = e->interpret_chains ? 1 : 0;
-    p.split_ok = (e->split_mask & (p.bwd ? 2 : 1)) ? 1 : 0;
+    p.split_ok = (e->split_mask & (p.bwd ? 2 : 1)) ? (e->split_any_grid ? 2 : 1) : 0;
     p.tail_force = 1;
     if (e->tail_balance) {
         p.tail_force = 0;
@@ -633,7 +646,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
             HIP_TRY(hipEventCreate(&b));
             e->ev_pool.emplace_back(a, b);
         }
-        if (e->ev_params.size() < e->ev_pool.size()) e->ev_params.resize(e->ev_pool.size());
+        if (e->ev_params.size() < e->ev_pool.size()) { e->ev_params.resize(e->ev_pool.size()); e->ev_cfg.resize(e->ev_pool.size()); }
         const int why = conv_gemm_cannot_launch(p);
         if (why) return fail(XFR_STATE_ERROR, "%s", conv_gemm_refusal(why));          // nothing launched: no event pair, no record
         // (HIP events misread the FIRST GEMM of a profiled run -- 0.87 ms for a 0.37 ms stem in round 3, 1.03 ms with a stream synchronise in
@@ -643,6 +656,7 @@ xfr_status run_conv(xfr_engine* e, const ConvParams& p_in, hipStream_t s)
         auto& ev = e->ev_pool[e->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, s));
         launch_conv_gemm(p, s);
+        e->ev_cfg[e->ev_used - 1] = conv_gemm_last_cfg();
         HIP_TRY(hipEventRecord(ev.second, s));
         e->prof_flops += 2.0 * (double)(p.K_logical ? p.K_logical : p.K) * (double)p.M * (double)p.CoutTot * (double)(p.dualacc ? 2 : p.nhalves);
     } else if (!launch_conv_gemm(p, s)) {
@@ -2311,17 +2325,18 @@ xfr_status prof_end(xfr_engine* e, hipStream_t s)
     HIP_TRY(hipStreamSynchronize(s));
     double ms = 0.0;
     FILE* f = e->profile_csv.empty() ? nullptr : fopen(e->profile_csv.c_str(), "a");   // per-launch GEMM records (xfr_engine_profile_csv)
+    for (int q = 0; q < 2; ++q) { e->fam_ms[q] = 0.0; e->fam_flops[q] = 0.0; e->fam_launches[q] = 0; }
     for (size_t i = 0; i < e->ev_used; ++i) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, e->ev_pool[i].first, e->ev_pool[i].second));
         ms += t;
-        if (f) {
-            const ConvParams& p = e->ev_params[i];
-            const int Kl = p.K_logical ? p.K_logical : p.K;
-            const double fl = 2.0 * Kl * (double)p.M * p.CoutTot * p.nhalves;
-            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", p.CoutTot, p.nhalves, Kl, p.M, p.kh, p.stride, p.out_stride,
-                    p.relu_in, p.accumulate, t, fl / (t * 1e-3) / 1e12);
-        }
+        const ConvParams& p = e->ev_params[i];
+        const int Kl = p.K_logical ? p.K_logical : p.K;
+        const double fl = 2.0 * Kl * (double)p.M * p.CoutTot * (p.dualacc ? 2 : p.nhalves);
+        const int fam = e->ev_cfg[i] == 9 ? 1 : 0;
+        e->fam_ms[fam] += t; e->fam_flops[fam] += fl; e->fam_launches[fam] += 1;
+        if (f) fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%d\n", p.CoutTot, p.nhalves, Kl, p.M, p.kh, p.stride, p.out_stride,
+                       p.relu_in, p.accumulate, t, fl / (t * 1e-3) / 1e12, e->ev_cfg[i]);
     }
     if (f) fclose(f);
     e->last_gemm_ms = ms;
@@ -2414,7 +2429,7 @@ xfr_status xfr_engine_create(const xfr_op_desc* ops, int32_t n_ops, int32_t n_we
     if (st == XFR_OK) st = layout_arena(e);
     if (st == XFR_OK) st = allocate(e);
     if (st != XFR_OK) { xfr_engine_destroy(e); return st; }
-    if (const char* v = getenv("XFR_SPLIT_GEMM")) e->split_mask = atoi(v) & 3;      // A/B runs: the mode of xfr_engine_set_split_gemm for new engines
+    if (const char* v = getenv("XFR_SPLIT_GEMM")) { e->split_mask = atoi(v) & 3; e->split_any_grid = (atoi(v) & 4) != 0; }      // A/B runs: the mode of xfr_engine_set_split_gemm for new engines
     *out = e;
     return XFR_OK;
 }
@@ -2447,6 +2462,13 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     if (e->idx_ws2) (void)hipFree(e->idx_ws2);
     if (e->idx_ws3) (void)hipFree(e->idx_ws3);
     for (int i = 0; i < 3; ++i) { if (e->seedbuf[i]) (void)hipFree(e->seedbuf[i]); if (e->ev_slot_done[i]) (void)hipEventDestroy(e->ev_slot_done[i]); }
+    for (int i = 0; i < 3; ++i) {
+        if (e->u8_stage[i]) (void)hipFree(e->u8_stage[i]);
+        if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
+        if (e->ev_stage_a[i]) (void)hipEventDestroy(e->ev_stage_a[i]);
+        if (e->ev_stage_b[i]) (void)hipEventDestroy(e->ev_stage_b[i]);
+    }
+    if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
     if (e->s_a) (void)hipStreamDestroy(e->s_a);
     if (e->s_b) (void)hipStreamDestroy(e->s_b);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -2456,6 +2478,8 @@ xfr_status xfr_engine_destroy(xfr_engine* e)
     delete e;
     return XFR_OK;
 }
+
+static void presplit_weights(xfr_engine* e);
 
 xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int32_t n_weights)
 {
@@ -2535,14 +2559,49 @@ xfr_status xfr_engine_load_weights(xfr_engine* e, const xfr_tensor_view* w, int3
     conv_gemm_forget_split(e->arena, e->arena_floats * sizeof(float));          // bf16 planes of the old weights (K17)
     HIP_TRY(hipMemcpy(e->arena, host.data(), e->arena_floats * sizeof(float), hipMemcpyHostToDevice));
     e->weights_loaded = true;
+    presplit_weights(e);
     return XFR_OK;
+}
+
+// bf16 planes (K17) of every pack the bf16x6 kernel may be asked to run, built when the weights arrive instead of at a pack's first launch (round 5:
+// the first step after a weight change stalled once per covered layer).  Layers, not launches: the geometry of one image decides.
+static void presplit_weights(xfr_engine* e)
+{
+    if (!e->arena || !e->weights_loaded || !e->split_mask) return;        // (packs that have their planes keep them)
+    for (size_t k = 0; k < e->ops.size(); ++k) {
+        const OpRec& o = e->ops[k];
+        const xfr_op_desc& d = o.d;
+        if (d.kind != XFR_OP_CONV && d.kind != XFR_OP_LINEAR) continue;
+        ConvParams p;
+        conv_geometry(e, (int)k, 1, p);
+        p.CoutTot = d.cout; p.nhalves = 1;
+        if ((e->split_mask & 1) && conv_gemm_split_covers(p)) {
+            (void)conv_gemm_presplit(e->arena + o.w_true, p.K, p.CoutTot, p.ldw, 0);
+            (void)conv_gemm_presplit(e->arena + o.w_pos, p.K, p.CoutTot, p.ldw, 0);
+        }
+        if ((e->split_mask & 2) && k != 0 && d.stride == 1) {
+            // the backward-data GEMM of a stride-1 convolution (bwd_conv_params): a convolution with the flipped, transposed pack
+            const Tensor& a = e->tens[d.in0];
+            const Tensor& t = e->tens[d.out];
+            ConvParams q;
+            memset(&q, 0, sizeof(q));
+            q.Cin = t.C; q.H = t.H; q.W = t.W;
+            q.kh = d.kh; q.kw = d.kw; q.stride = 1; q.pad = d.kh - 1 - d.pad;
+            q.OH = a.H; q.OW = a.W; q.out_stride = 1;
+            q.tap_major = o.tap_bwd ? 1 : 0;
+            q.CoutTot = a.C; q.nhalves = 1; q.ldw = o.ldb; q.K = o.Kb;
+            if (conv_gemm_split_covers(q)) {
+                (void)conv_gemm_presplit(e->arena + o.w_bwd, q.K, q.CoutTot, q.ldw, 0);
+                (void)conv_gemm_presplit(e->arena + o.w_bwd_true, q.K, q.CoutTot, q.ldw, 0);
+            }
+        }
+    }
 }
 
 xfr_status xfr_engine_weight_arena(xfr_engine* e, void** dev_ptr, size_t* bytes)
 {
     if (!e || !dev_ptr || !bytes) return fail(XFR_INVALID_ARG, "null argument");
-    conv_gemm_forget_split(e->arena, e->arena_floats * sizeof(float));          // the caller is about to write: bf16 planes (K17) are rebuilt at the next launch
-    *dev_ptr = e->arena;
+    *dev_ptr = e->arena;              // (a caller that writes through it ends with xfr_engine_mark_weights_loaded, which rebuilds the bf16 planes of K17)
     *bytes = e->arena_floats * sizeof(float);
     return XFR_OK;
 }
@@ -2552,6 +2611,11 @@ xfr_status xfr_engine_mark_weights_loaded(xfr_engine* e)
     if (e) e->held_x = nullptr;
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
     e->weights_loaded = true;
+    // the caller wrote the arena (through a pointer it may have held across forwards): planes built from the old contents are stale
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    conv_gemm_forget_split(e->arena, e->arena_floats * sizeof(float));
+    presplit_weights(e);
     return XFR_OK;
 }
 
@@ -2754,8 +2818,14 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
     struct SlotGuard { xfr_engine* e; ~SlotGuard() { e->cur_slot = 0; e->t_bank = nullptr; } } slot_guard{e};
     e->cur_slot = pipe ? (int)(e->seq++ % e->n_slots) : 0;
     const int slot = e->cur_slot;
+    // the engine's own staging (xfr_triplet_contrastive_u8_host): the inputs are complete when the copy's event fires -- nothing on the caller's stream
+    // concerns them, so the forwards of a pipelined call need not wait for it (one-shot: consumed here, whatever becomes of the call)
+    hipEvent_t in_ev = e->inputs_event;
+    const int stage_slot = e->stage_slot;
+    e->inputs_event = nullptr;
+    e->stage_slot = -1;
     if (fork) {
-        if (pipe && inputs_ready) {
+        if (pipe && (inputs_ready || in_ev)) {
             if (e->slot_pending[slot]) {       // the backward that last read this slot must be done
                 HIP_TRY(hipStreamWaitEvent(sa, e->ev_slot_done[slot], 0));
                 HIP_TRY(hipStreamWaitEvent(sb, e->ev_slot_done[slot], 0));
@@ -2765,7 +2835,11 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
             HIP_TRY(hipStreamWaitEvent(sa, e->ev_fork, 0));
             HIP_TRY(hipStreamWaitEvent(sb, e->ev_fork, 0));
         }
-    }
+        if (in_ev) {
+            HIP_TRY(hipStreamWaitEvent(sa, in_ev, 0));
+            HIP_TRY(hipStreamWaitEvent(sb, in_ev, 0));
+        }
+    } else if (in_ev) HIP_TRY(hipStreamWaitEvent(s, in_ev, 0));
     const Tensor& sd = e->tens[encode_tensor];
     float* seed_dst = pipe ? e->seedbuf[slot] : e->G(encode_tensor);
     e->t_bank = e->ws_enc;
@@ -2785,6 +2859,11 @@ xfr_status xfr_triplet_contrastive(xfr_engine* e, const float* probes_dev, const
         HIP_TRY(hipEventRecord(e->ev_b, sb));
         HIP_TRY(hipStreamWaitEvent(s, e->ev_a, 0));
         HIP_TRY(hipStreamWaitEvent(s, e->ev_b, 0));
+    }
+    if (stage_slot >= 0) {                     // the staging buffer may be overwritten once both forwards have read it
+        HIP_TRY(hipEventRecord(e->ev_stage_a[stage_slot], sa));
+        HIP_TRY(hipEventRecord(e->ev_stage_b[stage_slot], sb));
+        e->stage_busy[stage_slot] = true;
     }
     if (pipe) launch_copy_acc(seed_dst, e->G(encode_tensor), (long)sd.per_n() * 2 * n, 0, s);
     st = run_backward(e, *plan, n, 2, s);
@@ -2835,6 +2914,67 @@ xfr_status xfr_triplet_contrastive_u8(xfr_engine* e, const uint8_t* probes_u8_de
     U8Guard g(e);
     return xfr_triplet_contrastive(e, reinterpret_cast<const float*>(probes_u8_dev), reinterpret_cast<const float*>(gallery_u8_dev), n, encode_tensor, scale,
                                    percentile, sal_dev, stream, inputs_ready);
+}
+
+// Fresh uint8 images in HOST memory, every call (demo/test_whitebox.py:124-133: every call brings new images): the engine copies them itself -- its own
+// copy stream, one device staging buffer per forward slot -- and orders the forwards behind THAT copy instead of behind the caller's stream, so the
+// copy, the preprocessing and the forwards of call i + 1 overlap the sweep of call i without the caller promising anything about residency.
+xfr_status xfr_triplet_contrastive_u8_host(xfr_engine* e, const uint8_t* probes_u8_host, const uint8_t* gallery_u8_host, int32_t n, int32_t encode_tensor,
+                                           float scale, float percentile, float* sal_dev, void* stream)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    if (!e->u8_set) return fail(XFR_STATE_ERROR, "xfr_engine_set_u8_preprocess has not been called");
+    if (!probes_u8_host || !gallery_u8_host) return fail(XFR_INVALID_ARG, "null argument");
+    if (n < 1 || 2 * n > e->max_batch) return fail(XFR_INVALID_ARG, "triplet batch %d needs max_batch >= %d (the gallery forward runs 2n images)", n, 2 * n);
+    HIP_TRY(hipSetDevice(e->device));
+    {
+        xfr_status es = ensure_streams(e);
+        if (es != XFR_OK) return es;
+    }
+    const size_t img = (size_t)e->u8_pre.channels * e->tens[0].HW();
+    const size_t need = (size_t)(e->max_batch + e->max_batch / 2 + 1) * img;
+    if (!e->s_copy) HIP_TRY(hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking));
+    // the slot the call below will take (xfr_triplet_contrastive: seq % n_slots when pipelined)
+    const int slot = (e->pipeline && !e->profile_on) ? (int)(e->seq % e->n_slots) : 0;
+    if (!e->u8_stage[slot] || e->u8_stage_bytes < need) {
+        for (int i = 0; i < 3; ++i) {
+            if (e->u8_stage[i]) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(e->u8_stage[i]); e->u8_stage[i] = nullptr; e->stage_busy[i] = false; }
+        }
+        for (int i = 0; i < 3; ++i) {
+            HIP_TRY(hipMalloc(&e->u8_stage[i], need));
+            if (!e->ev_copied[i]) {
+                HIP_TRY(hipEventCreateWithFlags(&e->ev_copied[i], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&e->ev_stage_a[i], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&e->ev_stage_b[i], hipEventDisableTiming));
+            }
+        }
+        e->u8_stage_bytes = need;
+    }
+    if (e->stage_busy[slot]) {                 // the forwards that last read this staging buffer
+        HIP_TRY(hipStreamWaitEvent(e->s_copy, e->ev_stage_a[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(e->s_copy, e->ev_stage_b[slot], 0));
+    }
+    uint8_t* gal = e->u8_stage[slot];
+    uint8_t* pro = gal + (size_t)2 * n * img;
+    HIP_TRY(hipMemcpyAsync(gal, gallery_u8_host, (size_t)2 * n * img, hipMemcpyHostToDevice, e->s_copy));
+    HIP_TRY(hipMemcpyAsync(pro, probes_u8_host, (size_t)n * img, hipMemcpyHostToDevice, e->s_copy));
+    HIP_TRY(hipEventRecord(e->ev_copied[slot], e->s_copy));
+    e->last_copied = e->ev_copied[slot];
+    e->inputs_event = e->ev_copied[slot];
+    e->stage_slot = slot;
+    U8Guard g(e);
+    const xfr_status st = xfr_triplet_contrastive(e, reinterpret_cast<const float*>(pro), reinterpret_cast<const float*>(gal), n, encode_tensor, scale, percentile,
+                                                  sal_dev, stream, 0);
+    e->inputs_event = nullptr;                 // (an argument error returned before the call consumed them)
+    e->stage_slot = -1;
+    return st;
+}
+
+xfr_status xfr_engine_wait_inputs_copied(xfr_engine* e)
+{
+    if (!e) return fail(XFR_INVALID_ARG, "null engine");
+    if (e->last_copied) HIP_TRY(hipEventSynchronize(e->last_copied));
+    return XFR_OK;
 }
 
 xfr_status xfr_debug_u8_preprocess(xfr_engine* e, const uint8_t* x_u8_dev, int32_t n, float* out_nchw_dev, void* stream)
@@ -2900,9 +3040,11 @@ xfr_status xfr_engine_set_tail_balance(xfr_engine* e, int32_t enable)
 xfr_status xfr_engine_set_split_gemm(xfr_engine* e, int32_t mode)
 {
     if (!e) return fail(XFR_INVALID_ARG, "null engine");
-    if (mode < 0 || mode > 3) return fail(XFR_INVALID_ARG, "xfr_engine_set_split_gemm: mode 0 (off), 1 (forward convolutions), 2 (backward-data GEMMs), 3 (both)");
-    e->split_mask = mode;
+    if (mode < 0 || mode > 7) return fail(XFR_INVALID_ARG, "xfr_engine_set_split_gemm: mode 0 (off), 1 (forward convolutions), 2 (backward-data GEMMs), 3 (both); + 4: whatever the launch's grid");
+    e->split_mask = mode & 3;
+    e->split_any_grid = (mode & 4) != 0;
     e->held_x = nullptr;
+    presplit_weights(e);               // planes of the packs the new mode adds
     return XFR_OK;
 }
 
@@ -3496,6 +3638,7 @@ xfr_status xfr_broadcast_weights(xfr_engine* e, xfr_comm* c, int32_t root, void*
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     e->weights_loaded = true;
     e->held_x = nullptr;
+    presplit_weights(e);
     return XFR_OK;
 }
 
@@ -3712,6 +3855,13 @@ xfr_status xfr_engine_get_profile(xfr_engine* e, double* gemm_ms, int64_t* gemm_
     if (gemm_ms) *gemm_ms = e->last_gemm_ms;
     if (gemm_launches) *gemm_launches = e->last_gemm_launches;
     if (gemm_flops) *gemm_flops = e->last_gemm_flops;
+    return XFR_OK;
+}
+
+xfr_status xfr_engine_get_profile_by_kernel(xfr_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops)
+{
+    if (!e || !gemm_ms || !gemm_launches || !gemm_flops) return fail(XFR_INVALID_ARG, "null argument");
+    for (int q = 0; q < 2; ++q) { gemm_ms[q] = e->fam_ms[q]; gemm_launches[q] = e->fam_launches[q]; gemm_flops[q] = e->fam_flops[q]; }
     return XFR_OK;
 }
 

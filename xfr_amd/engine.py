@@ -241,6 +241,33 @@ class Engine(object):
                                                            sal.data_ptr(), _stream_ptr(self.device), 1 if (inputs_ready and not f1 and not f2) else 0))
         return sal
 
+    def triplet_contrastive_u8_host(self, probes, gallery, encode_tensor, scale=1.0 / 2500.0, percentile=None):
+        """triplet_contrastive on uint8 images in HOST memory (N x H x W x C probes, 2N gallery images; pinned tensors preferably): the engine copies them
+        on its own stream into its own staging buffers, so with set_pipeline on the copy and the forwards of this call overlap the previous call's sweep
+        (include/xfr_amd.h: xfr_triplet_contrastive_u8_host).  The copy is asynchronous: call wait_inputs_copied() before rewriting the host tensors."""
+        c, h, w = self.program.in_shape
+        ch = getattr(self, '_u8_channels', 3)
+        for x in (probes, gallery):
+            if x.is_cuda or x.dtype != torch.uint8 or x.dim() != 4 or tuple(x.shape[1:]) != (h, w, ch) or not x.is_contiguous():
+                raise ValueError('expected contiguous uint8 HOST images N x %d x %d x %d, got %s %s on %s' % (h, w, ch, x.dtype, tuple(x.shape), x.device))
+        n = probes.shape[0]
+        if gallery.shape[0] != 2 * n:
+            raise ValueError('gallery must hold %d images, got %d' % (2 * n, gallery.shape[0]))
+        if 2 * n > self.max_batch:
+            raise ValueError('batch %d exceeds the engine max_batch %d' % (2 * n, self.max_batch))
+        c1, h1, w1 = self.tensor_shape(1)
+        sal = torch.empty((n, h1, w1), device=self.device)
+        pct = -1.0 if percentile is None else float(percentile)
+        self._host_inputs = (probes, gallery)        # keep them alive until the next call replaces them (the copy is asynchronous)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.xfr_triplet_contrastive_u8_host(self._h, probes.data_ptr(), gallery.data_ptr(), n, int(encode_tensor), float(scale), pct,
+                                                                sal.data_ptr(), _stream_ptr(self.device)))
+        return sal
+
+    def wait_inputs_copied(self):
+        """Block until the host-to-device copies of the last triplet_contrastive_u8_host call are done (its host tensors may then be rewritten)."""
+        _lib.check(self.lib.xfr_engine_wait_inputs_copied(self._h))
+
     def set_pipeline(self, on):
         """Let the forward of triplet call i+1 overlap the backward of call i (see include/xfr_amd.h for the contract)."""
         _lib.check(self.lib.xfr_engine_set_pipeline(self._h, int(on)))     # 0 off, 1 triplet calls, 2 every run call; | 4: three forward slots
@@ -277,8 +304,9 @@ class Engine(object):
         self.options['lean'] = bool(on)
 
     def set_split_gemm(self, mode):
-        """bf16x6 GEMMs for the deep-K stride-1 convolutions (include/xfr_amd.h, conv_gemm.hip K17): 0 / False off, 1 / True the forward convolutions
-        (the default), 2 the sweep's backward-data GEMMs, 3 both (experimental)."""
+        """bf16x6 GEMMs for the deep-K stride-1 convolutions (include/xfr_amd.h, conv_gemm_split.hip K17): 0 / False off, 1 / True the forward
+        convolutions, 2 the sweep's backward-data GEMMs, 3 both (the default); + 4: whatever the launch's grid (by default launches of fewer than 128
+        tiles stay on the fp32 kernels)."""
         mode = int(mode)
         _lib.check(self.lib.xfr_engine_set_split_gemm(self._h, mode))
         self.options['split_gemm'] = mode
@@ -433,6 +461,12 @@ class Engine(object):
     def profile_csv(self, path):
         """Append one CSV record per GEMM launch to `path` while profiling is on (None: stop)."""
         _lib.check(self.lib.xfr_engine_profile_csv(self._h, path.encode() if path else None))
+
+    def get_profile_by_kernel(self):
+        """The last profiled run's GEMM launches by the kernel family that ran them: {'fp32': (ms, launches, flops), 'bf16x6': (...)}."""
+        ms, n, fl = (ctypes.c_double * 2)(), (ctypes.c_int64 * 2)(), (ctypes.c_double * 2)()
+        _lib.check(self.lib.xfr_engine_get_profile_by_kernel(self._h, ms, n, fl))
+        return {'fp32': (ms[0], n[0], fl[0]), 'bf16x6': (ms[1], n[1], fl[1])}
 
     def get_profile(self):
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()

@@ -16,13 +16,16 @@ NET_SIDE = 224          # utils.py:189 imgScale
 
 
 def imread(fn):
-    """Decoded pixels of an image file as the decoder stores them: uint8, H x W (grey) or H x W x C.  Supported: 8-bit grey, RGB and RGBA
-    files (PIL modes L / RGB / RGBA), for which PIL and the reference's imageio return the same array.  Anything else (palette, LA, 16-bit,
-    CMYK ...) raises: imageio would hand back the decoder's native dtype / channel count there and a silent conversion would diverge."""
+    """Decoded pixels of an image file as the reference's imageio.imread (utils.py:88,164,179) hands them over: uint8, H x W (grey) or H x W x C.
+    8-bit grey, RGB and RGBA files (PIL modes L / RGB / RGBA): the decoder's array, the same from PIL and imageio.  Palette files (mode P -- most small
+    PNGs): imageio's pillow plugin expands them, to RGBA when the file carries transparency and to RGB otherwise, and so does this.  Anything else (LA,
+    16-bit, CMYK ...) raises: imageio would hand back the decoder's native dtype / channel count there and a silent conversion would diverge."""
     import PIL.Image
     with PIL.Image.open(fn) as im:
+        if im.mode == 'P':
+            im = im.convert('RGBA' if 'transparency' in im.info else 'RGB')
         if im.mode not in ('L', 'RGB', 'RGBA'):
-            raise ValueError('%s: unsupported image mode %r (8-bit grey / RGB / RGBA files only)' % (fn, im.mode))
+            raise ValueError('%s: unsupported image mode %r (8-bit grey / RGB / RGBA / palette files only)' % (fn, im.mode))
         return np.asarray(im).copy()
 
 

@@ -107,6 +107,12 @@ class Comm(object):
             out.append(val)
         return out
 
+    def next_tag(self, name):
+        """A store tag no earlier gather of this communicator has used (every rank calls in the same order): keys are never deleted, so a second
+        gather under a fixed tag would read the first one's values at once."""
+        self._seq += 1
+        return '%s%d' % (name, self._seq)
+
     def agree(self, flag):
         """True iff every rank passed True (a rank that never answers counts as False)."""
         if self.world == 1:
@@ -136,7 +142,7 @@ class Comm(object):
                     raise RuntimeError('rank(s) %s failed: %s' % (sorted(errs), '; '.join(e.strip().splitlines()[-1] for e in errs.values())))
             if now - t0 > self.timeout_s:
                 raise RuntimeError('barrier timed out after %.0f s' % self.timeout_s)
-            time.sleep(0.0002)
+            time.sleep(0.002)          # (2 ms: the timed region that follows starts after a device synchronise on every rank anyway)
         if self.collective_ok:
             dist.barrier()
 
@@ -362,7 +368,7 @@ def gather_rank_rates(rate, device=None, comm=None):
     store, so that the figure exists even when the collective backend does not."""
     rates = [float(rate)]
     if comm is not None and comm.world > 1:
-        rates = [float(v) if not isinstance(v, dict) else float('nan') for v in comm.gather_objects(float(rate), 'rank_rate')]
+        rates = [float(v) if not isinstance(v, dict) else float('nan') for v in comm.gather_objects(float(rate), comm.next_tag('rank_rate'))]
     elif dist.is_initialized() and dist.get_world_size() > 1:
         t = torch.tensor([float(rate)], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
