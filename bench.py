@@ -608,14 +608,18 @@ def run_secondary(model, dev, steps, warmup, chain_before):
     return out
 
 
-def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=65359):
+def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=65359, workers=2):
     """BASELINE.json configs[4] on ONE GPU: the job mix of the reference's inpainting-game generator on ResNet-101 (eval/
     generate_inpaintinggame_wb_saliency_maps_multigpu.py:121-231; python/xfr/inpainting_game/generate_whitebox_saliency.py:79-214) -- per job meanEBP
     over the 65359-way hooked classifier, contrastive and truncated-contrastive triplet EBP from `mates` averaged mate / non-mate encodings, and
     weighted-subtree EBP top-32 ('norelu', whitebox.py:647-737) -- `group` jobs per batch through xfr_amd.inpainting_game.run_jobs_batched (what
-    tools/inpainting_game_workload.py --group 8 runs; that tool shards the jobs over ranks).  jobs/s over `jobs` jobs, ms per method (a second
-    pass, device synchronised between methods), and for the weighted subtree the GEMM FLOPs its launches executed per probe (in-kernel launch
-    log) over its wall time against the fp32 MFMA peak."""
+    tools/inpainting_game_workload.py --group 8 runs; that tool shards the jobs over ranks).  `workers` job groups are in flight at once: that many
+    engines, each on its own host thread and stream -- the reference runs a pool of workers too (one per GPU, ..._multigpu.py:193); here a second worker
+    on the SAME GPU fills the launch gaps and the four host synchronisation points per weighted-subtree call of the first (small batches: the device idles
+    two thirds of a call).  jobs/s over `jobs` jobs, ms per method (a second pass, ONE worker, device synchronised between methods), and for the weighted
+    subtree the GEMM FLOPs its launches executed per probe (in-kernel launch log) over its wall time against the fp32 MFMA peak -- one call at a time
+    and with all workers running it."""
+    import threading
     import numpy as np
     import torch
     from xfr_amd import inpainting_game as IG, synth, tuning
@@ -623,13 +627,18 @@ def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=653
     from xfr_amd.models import resnet, whitebox as WB
     bb = resnet.ResNet([3, 4, 23, 3], num_classes=num_classes)
     bb.to(dev)
-    wbn = WB.WhiteboxSTResnet(bb)
-    wb = WB.Whitebox(wbn, ebp_subtree_mode='norelu')            # eval/create_wbnet.py:51-52 default for resnetv4/v6
-    wbn._program = bb.build_program()
-    wbn._engine = Engine(wbn._program, max(32, 16 * group), dev)
-    wbn._engine_key = (str(bb.device), id(bb))
-    wbn._engine.load_weights(synth.synth_state_dict(bb, seed=0))
-    wbn._engine.loaded_version = bb.version
+    sd = synth.synth_state_dict(bb, seed=0)
+    wbs, streams = [], []
+    for _ in range(workers):
+        wbn = WB.WhiteboxSTResnet(bb)
+        wbs.append(WB.Whitebox(wbn, ebp_subtree_mode='norelu'))  # eval/create_wbnet.py:51-52 default for resnetv4/v6
+        wbn._program = bb.build_program()
+        wbn._engine = Engine(wbn._program, max(32, 16 * group), dev)
+        wbn._engine_key = (str(bb.device), id(bb))
+        wbn._engine.load_weights(sd)
+        wbn._engine.loaded_version = bb.version
+        streams.append(torch.cuda.Stream(device=dev))
+    wb = wbs[0]
     # (no kernel knobs here: launches of fewer than 128 tiles leave the bf16x6 kernel by the library's own rule -- round 5 switched it off by hand)
     k = mates
     pool = [synth.synth_smooth_images(2 * k + 1, (3, 224, 224), seed=10000 + j, mean=resnet.MEAN_RGB).to(dev) for j in range(8)]
@@ -637,24 +646,53 @@ def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=653
     def batch(g0):
         return [(list(pool[j % 8][1:1 + k]), list(pool[j % 8][1 + k:]), pool[j % 8][0]) for j in range(g0, min(jobs, g0 + group))]
 
-    def run_all(timings=None, methods=None):
+    def check(res):
         ok = True
-        for g0 in range(0, jobs, group):
-            res = IG.run_jobs_batched(wb, batch(g0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, timings=timings, methods=methods)
-            for maps in res.values():
-                for m in maps:
-                    m = np.asarray(m)
-                    ok = ok and m.shape == (112, 112) and bool(np.isfinite(m).all()) and abs(float(m.sum()) - 1.0) < 1e-3
+        for maps in res.values():
+            for m in maps:
+                m = np.asarray(m)
+                ok = ok and m.shape == (112, 112) and bool(np.isfinite(m).all()) and abs(float(m.sum()) - 1.0) < 1e-3
         return ok
+
+    def in_workers(fn):
+        """fn(w) on worker w's thread and stream; returns the results (an exception of a worker is re-raised here)"""
+        out, err = [None] * workers, []
+
+        def body(w):
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(streams[w]):
+                    out[w] = fn(w)
+                    streams[w].synchronize()
+            except BaseException as ex:      # noqa: BLE001
+                err.append(ex)
+        ts = [threading.Thread(target=body, args=(w,)) for w in range(workers)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    groups = list(range(0, jobs, group))
+
+    def run_all():
+        return all(in_workers(lambda w: all([check(IG.run_jobs_batched(wbs[w], batch(g0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk)) for g0 in groups[w::workers]])))
     run_all()                                                   # warm: plans, scratch, lazy code objects
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ok = run_all()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # one worker alone, same jobs: what the second worker adds
+    t0 = time.perf_counter()
+    ok1 = all([check(IG.run_jobs_batched(wb, batch(g0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk)) for g0 in groups])
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t0
     phase = {}
-    run_all(timings=phase)
-    # the weighted subtree alone: wall time and executed GEMM FLOPs of one group
+    for g0 in groups:
+        IG.run_jobs_batched(wb, batch(g0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, timings=phase)
+    # the weighted subtree alone: wall time and executed GEMM FLOPs of one group, one call at a time ...
     ws = ('weighted-subtree',)
     IG.run_jobs_batched(wb, batch(0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, methods=ws)
     torch.cuda.synchronize()
@@ -663,6 +701,13 @@ def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=653
         IG.run_jobs_batched(wb, batch(0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, methods=ws)
     torch.cuda.synchronize()
     t_ws = (time.perf_counter() - t1) / 3
+    # ... and with every worker running it (the job mix's schedule)
+    in_workers(lambda w: IG.run_jobs_batched(wbs[w], batch(0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, methods=ws))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    in_workers(lambda w: [IG.run_jobs_batched(wbs[w], batch(0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, methods=ws) for _ in range(3)])
+    torch.cuda.synchronize()
+    t_ws_conc = (time.perf_counter() - t1) / (3 * workers)
     csv = tuning.record_launch_log(lambda: IG.run_jobs_batched(wb, batch(0), 'resnetv4_pytorch', 'norelu', 6, dev, topk=topk, methods=ws), 0, dev,
                                    launches_per_step_cap=40000)
     fl, n_launch, busy = 0.0, 0, 0
@@ -676,14 +721,19 @@ def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=653
     fl, n_launch, busy_ms = fl / 2, n_launch / 2, busy * 1e-5 / 2           # the log holds two calls
     out = {'model': 'resnet101 inpainting-game job mix', 'metric': 'inpainting-game whitebox saliency jobs/sec, ResNet-101 (4 methods per job), 1 GPU',
            'workload': 'BASELINE.json configs[4] shape on one GPU: %d synthetic jobs, %d mates + %d non-mates per job, %d-way hooked classifier for meanEBP, '
-                       'weighted subtree top-%d, mode norelu, %d jobs per batch' % (jobs, k, k, num_classes, topk, group),
-           'value': jobs / dt, 'unit': 'jobs/s', 'seconds': dt, 'jobs': jobs, 'outputs_ok': bool(ok),
+                       'weighted subtree top-%d, mode norelu, %d jobs per batch, %d batches in flight (one engine, host thread and stream each)' % (
+                           jobs, k, k, num_classes, topk, group, workers),
+           'value': jobs / dt, 'unit': 'jobs/s', 'seconds': dt, 'jobs': jobs, 'workers': workers, 'outputs_ok': bool(ok and ok1),
+           'one_worker': {'jobs_s': jobs / dt1, 'seconds': dt1},
            'ms_per_job_by_method': {kk: round(1e3 * v / jobs, 3) for kk, v in phase.items()},
-           'weighted_subtree': {'ms_per_probe': 1e3 * t_ws / group, 'probes_per_call': group, 'gemm_launches_per_call': n_launch,
+           'weighted_subtree': {'ms_per_probe': 1e3 * t_ws_conc / group, 'ms_per_probe_one_call_at_a_time': 1e3 * t_ws / group, 'probes_per_call': group,
+                                'calls_in_flight': workers, 'gemm_launches_per_call': n_launch,
                                 'executed_gemm_gflop_per_probe': fl / group / 1e9, 'sum_of_gemm_launch_ms_per_call': busy_ms,
-                                'frac_of_peak_over_wall': fl / t_ws / PEAK_F32_MFMA, 'frac_of_peak_while_a_gemm_runs': fl / (busy_ms * 1e-3) / PEAK_F32_MFMA},
+                                'frac_of_peak_over_wall': fl / t_ws_conc / PEAK_F32_MFMA, 'frac_of_peak_over_wall_one_call_at_a_time': fl / t_ws / PEAK_F32_MFMA,
+                                'frac_of_peak_while_a_gemm_runs': fl / (busy_ms * 1e-3) / PEAK_F32_MFMA},
            'reference': '~36 h for 541 ResNet-101 jobs on one Titan X (README.md:166) = ~240 s per job'}
-    wbn._engine.close()
+    for w_ in wbs:
+        w_.net._engine.close()
     torch.cuda.empty_cache()
     return out
 
@@ -744,6 +794,7 @@ def main():
     ap.add_argument('--sustained-seconds', type=float, default=10.0)
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
     ap.add_argument('--inpainting-game', action='store_true', help='only the BASELINE.json configs[4] job mix (one GPU): print its object and exit')
+    ap.add_argument('--job-workers', type=int, default=2, help='job mix: job groups in flight (one engine, host thread and stream each)')
     ap.add_argument('--no-split-leg', action='store_true', help='skip the two other xfr_engine_set_split_gemm modes that ride on the line (split_gemm_modes)')
     ap.add_argument('--split-gemm', type=int, default=None, help='xfr_engine_set_split_gemm(MODE): 0 fp32 MFMA kernels everywhere, 1 bf16x6 forward convolutions of the deep-K layers, 3 the backward-data GEMMs too (the default); + 4: whatever the grid')
     ap.add_argument('--no-lean', action='store_true', help='xfr_engine_set_lean(0): the literal hook operands in every sweep (A/B against the default lean schedule)')
@@ -816,7 +867,7 @@ def run(args, comm):
         raise RuntimeError('XFR_TEST_RAISE_RANK: simulated failure of rank %d' % rank)
     if args.inpainting_game:
         if rank == 0:
-            print(json.dumps(run_inpainting_game(dev)))
+            print(json.dumps(run_inpainting_game(dev, workers=args.job_workers)))
         comm.close()
         return
     binding = shard.bind_rank_cpus(local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))) if args.bind else None
@@ -972,7 +1023,7 @@ def run(args, comm):
             except Exception as ex:      # the headline must still be printed
                 secondary.append({'model': m, 'error': repr(ex), 'outputs_ok': False})
         try:
-            secondary.append(run_inpainting_game(dev))
+            secondary.append(run_inpainting_game(dev, workers=args.job_workers))
         except Exception as ex:
             secondary.append({'model': 'resnet101 inpainting-game job mix', 'error': repr(ex), 'outputs_ok': False})
         del chain_main

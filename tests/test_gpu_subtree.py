@@ -174,6 +174,48 @@ def test_weighted_subtree_resnet101_golden(gpu_device):
     assert_map_close_robust(smap, g[key + '/map'], key, rtol=5e-3)
 
 
+LAZY_ZERO_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import golden_cases as GC
+from parity_utils import make_backbone, make_images
+from xfr_amd import synth
+bb, sd = make_backbone('stresnet_mini', seed=3, num_classes=5)
+wb = GC.engine_subject('stresnet_mini', bb, 'norelu').wb
+n = 3
+x = make_images('stresnet_mini', n, seed=11)
+xm, xn = synth.unit_rows(n, 512, seed=31) / 2500, synth.unit_rows(n, 512, seed=32) / 2500
+h = hashlib.sha256()
+for sweep_batch in (None, 5):
+    for sm, P, w, k in wb.weighted_subtree_ebp_batch(x, xm, xn, topk=8, subtree_mode='norelu', sweep_batch=sweep_batch):
+        assert np.isfinite(np.asarray(sm)).all()
+        h.update(np.ascontiguousarray(np.asarray(sm, dtype=np.float32)).tobytes())
+        h.update(np.asarray(sorted(k), dtype=np.int64).tobytes())
+lw = wb.layerwise_ebp(x[:1], k_poschannel=0, k_layer=7, mode='argmax', mwp=False)
+h.update(np.ascontiguousarray(np.asarray(lw, dtype=np.float32)).tobytes())
+print('DIGEST', h.hexdigest())
+"""
+
+
+def test_lazy_gradient_zeroing_against_the_eager_fill(gpu_device):
+    """The layerwise / prefix sweeps zero exactly the gradient rows a launch is about to read and nobody has written (engine.hip, run_backward) instead of
+    the whole region.  XFR_POISON_G=1 NaN-fills the region first, so a row the bookkeeping misses would surface in the maps; XFR_EAGER_ZERO=1 is the old
+    whole-region fill.  Both are latched at first use, hence one process each: the three runs (default, poisoned, eager) must agree bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(GC.GOLDEN_DIR.rstrip('/').rsplit('/', 1)[0])
+    digests = {}
+    for name, extra in (('default', {}), ('poisoned', {'XFR_POISON_G': '1'}), ('eager', {'XFR_EAGER_ZERO': '1'})):
+        env = {k: v for k, v in os.environ.items() if k not in ('XFR_POISON_G', 'XFR_EAGER_ZERO')}
+        env.update(extra)
+        out = subprocess.run([sys.executable, '-c', LAZY_ZERO_SCRIPT % (root, os.path.join(root, 'tests'))], capture_output=True, text=True, timeout=600, env=env,
+                             cwd=root)
+        assert out.returncode == 0, (name, out.stderr[-3000:])
+        digests[name] = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1]
+    assert digests['default'] == digests['poisoned'] == digests['eager'], digests
+
+
 def test_inpainting_game_workload_tool(gpu_device):
     """tools/inpainting_game_workload.py (BASELINE.json configs[4] shape) runs end to end on one GPU."""
     import json

@@ -312,7 +312,7 @@ int conv_gemm_last_cfg();       // the configuration the calling thread's last l
 // builds them when the weights arrive (conv_gemm_presplit; a pack that has none at a launch gets them there, on that launch's stream, which is then
 // drained once).  conv_gemm_forget_split: the packs inside [lo, lo + bytes) changed or go away -- drop their planes.
 void conv_gemm_forget_split(const void* lo, size_t bytes);
-bool conv_gemm_presplit(const float* w, int K, int cout, int ldw, hipStream_t s);     // false: no memory for the planes (the pack stays on the fp32 kernels)
+bool conv_gemm_presplit(const ConvParams& layer, const float* w, hipStream_t s);     // the planes of pack w of that layer (geometry, K, CoutTot, ldw); false: no memory (the pack stays on the fp32 kernels)
 int conv_gemm_split_covers(const ConvParams& p);       // a layer xfr_engine_set_split_gemm covers (whatever the launch's grid)
 long conv_gemm_split_launches();
 

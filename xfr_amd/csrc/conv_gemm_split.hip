@@ -243,22 +243,248 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
     stamp(p, wave, lane, 4);
 }
 
-// W[k][ldw] fp32 (k rows, output channel = column) -> bf16 planes [cout / 128][K / 16][piece][k half][128][8]
-__global__ void split_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ planes, int K, int cout, int ldw)
+// ---- K17b (round 6): the same GEMM for "same" KxK convolutions, X staged ONCE per 16-channel block for all its filter taps --------------------------------
+// What limits K17 is not the matrix pipe: a 128 x 128 x 16 step moves 20 KB from L2 (12 KB of W planes, 8 KB of fp32 X) and splits 2048 X values for 768
+// MFMA cycles; measured with the MFMAs removed the same launch is no faster than ~150 TFLOP/s-equivalent (profiles/r6/experiments/v2_phase_variants.txt).
+// In a stride-1 KxK convolution whose output map equals its input map (3x3 pad 1: every ResNet bottleneck's middle layer, forward and backward-data) the
+// X slab of tap (dh, dw) is the slab of tap (0, 0) shifted by (dh - pad) * W + (dw - pad) positions -- the same fp32 values, loaded and split kh * kw times.
+// Here the K order is (channel block, tap, channel): per block of 16 channels the workgroup stages ONE patch of the input row -- its 128 positions plus a
+// halo of pad * W + pad on both sides -- as bf16 pieces in LDS, and every tap's B fragments are ds_reads of that patch at the tap's offset; positions a
+// tap reaches outside the image read a zero slot.  Per 9 K-steps of a 3x3 layer: 108 + 10 KB from L2 instead of 180, one split instead of nine.
+// W planes in (channel block, tap) step order (split_pack_kernel, layout 1); tile, accumulators, folds, sign phases and epilogues as in K17.
+constexpr int SPP_MAX_HALO = 64, SPP_MAX_TAPS = 25;
+
+__host__ __device__ inline int spp_halo(const ConvParams& p) { return p.pad * p.W + p.pad; }
+__host__ __device__ inline int spp_patch_len(const ConvParams& p) { return SP_T + 2 * spp_halo(p); }
+inline size_t spp_lds_bytes(const ConvParams& p) { return (size_t)3 * SP_A_BYTES + (size_t)2 * 6 * (spp_patch_len(p) + 1) * 16; }
+
+template <bool RELU, int CHAIN>
+__global__ __launch_bounds__(NT, 2) void conv_gemm_split_patch_kernel(const ConvParams p, const uint16_t* __restrict__ ws0, const uint16_t* __restrict__ ws1,
+                                                                  const int n_co_tiles, const int n_m_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+    constexpr int XBASE = 3 * SP_A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    stamp(p, wave, lane, 0, 3);
+
+    const int lid = xcd_remap(blockIdx.x, n_co_tiles * n_m_tiles);
+    const int tile_m = lid / n_co_tiles;
+    const int tile_co_all = lid - tile_m * n_co_tiles;
+    const int n_co_half = n_co_tiles / p.nhalves;
+    const int half = tile_co_all / n_co_half;
+    const int tile_co = tile_co_all - half * n_co_half;
+    const int co0 = tile_co * SP_T, m0 = tile_m * SP_T;
+    const uint16_t* __restrict__ wsel = half ? ws1 : ws0;
+    const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
+    float* __restrict__ osel = half ? p.out1 : p.out0;
+    const int T = p.kh * p.kw, ncb = p.Cin / SP_BK, nk = T * ncb;
+    const int halo = spp_halo(p), PL = spp_patch_len(p);
+    const int PS = (PL + 1) * 16;                 // bytes of one (piece, k half) plane of a patch: PL positions + the zero slot
+    const int XB = 6 * PS;                        // one patch buffer
+    const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, n_co_half * nk * SP_A_BYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds);
+
+    // ---- staging tasks: task t = k half * PL + patch position q; a lane owns tasks tid and tid + 256 (2 PL <= 512)
+    unsigned t_voff[2], t_lds[2];
+    bool t_ok[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int t = tid + r * NT;
+        const int kh_ = t >= PL ? 1 : 0, q = t - kh_ * PL;
+        const long g = (long)m0 - halo + q;       // flattened (n, h, w) index of the input row
+        t_ok[r] = t < 2 * PL;
+        const bool in_row = t_ok[r] && g >= 0 && g < (long)p.in_nb * p.H * p.W;
+        t_voff[r] = in_row ? (unsigned)g * 4u + (unsigned)(kh_ * 8) * chan_bytes : OOB;      // out of the tensor: the hardware returns 0
+        t_lds[r] = lds_base + XBASE + kh_ * PS + q * 16;
+    }
+    // ---- fragment columns: sub-tile j, column j * 64 + wc * 32 + l31; which taps stay inside the image there
+    int c_pos[2];
+    unsigned c_mask[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = j * 64 + wc * 32 + l31, m = m0 + c;
+        c_pos[j] = c + halo;
+        unsigned mk = 0u;
+        if (m < p.M) {
+            const int ohw = p.OH * p.OW;
+            const int r = m % ohw;
+            const int oh = r / p.OW, ow = r - oh * p.OW;
+            for (int dh = 0; dh < p.kh; ++dh)
+                for (int dw = 0; dw < p.kw; ++dw)
+                    if ((unsigned)(oh + dh - p.pad) < (unsigned)p.H && (unsigned)(ow + dw - p.pad) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+        }
+        c_mask[j] = mk;
+    }
+    const unsigned char* a_lane = lds + (lhi * SP_T + wr * 32 + l31) * 16;
+    const unsigned char* b_plane = lds + XBASE + lhi * PS;
+
+    v16f acc[2][2], pipe[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; pipe[i][j][r] = 0.f; }
+
+    auto load_w = [&](int kt, int stage) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(lds + stage * SP_A_BYTES + (b * 4 + wave) * 1024), 16,
+                                                     ((b * 4 + wave) * 1024 + lane * 16) | (kt < nk ? 0u : OOB), (tile_co * nk + kt) * SP_A_BYTES, 0, 0);
+    };
+    float xp[8];
+    auto load_patch = [&](int cb, int r) {        // task r of every lane, channel block cb: eight dword loads (unconditional: the counted waits below count them)
+        const unsigned so = (unsigned)(cb * SP_BK) * chan_bytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xp[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rIn, t_voff[r], so + (unsigned)i * chan_bytes, 0));
+    };
+    auto store_patch = [&](int buf, int r, unsigned flip) {
+        v4u q0, q1, q2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = RELU ? fmaxf(xp[2 * i], 0.f) : xp[2 * i], b = RELU ? fmaxf(xp[2 * i + 1], 0.f) : xp[2 * i + 1];
+            unsigned h0, h1, h2;
+            split_pair(a, b, h0, h1, h2);
+            q0[i] = h0 ^ flip; q1[i] = h1 ^ flip; q2[i] = h2 ^ flip;
+        }
+        if (t_ok[r]) {
+            const unsigned at = t_lds[r] + buf * XB;
+            asm volatile("ds_write_b128 %0, %1" :: "v"(at), "v"(q0));
+            asm volatile("ds_write_b128 %0, %1" :: "v"(at + 2 * PS), "v"(q1));
+            asm volatile("ds_write_b128 %0, %1" :: "v"(at + 4 * PS), "v"(q2));
+        }
+    };
+    auto fold = [&](bool negated) {
+        if (negated) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] -= pipe[i][j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] += pipe[i][j];
+        }
+    };
+    // Sign phases (K17): here a whole channel block -- one patch -- carries one sign, and a pass of the loop (three K-steps) is folded with the sign of
+    // the block its steps belong to.
+    // K position of the step being computed
+    int tap = 0, cb = 0, buf = 0, shift = -halo;                // shift of tap (0, 0): (0 - pad) * W + (0 - pad)
+    int tdw = 0;
+    bool xl_prev = false;
+    auto step = [&](int kt, auto ST, auto FIRST) {
+        constexpr int st = decltype(ST)::value, st2 = (st + 2) % 3;
+        // the next block's patch, spread over this block's first steps: tap 0 loads task 0, tap 2 splits it and loads task 1, tap 4 splits that.  The
+        // split comes BEFORE this step's W DMA: the wait for its X registers then leaves at most the previous step's DMA in flight
+        const bool more = cb + 1 < ncb;
+        bool xl_now = false;
+        const unsigned flip_next = ((cb + 1) & 1) ? 0x80008000u : 0u;
+        if (more && tap == 2) store_patch(buf ^ 1, 0, flip_next);
+        if (more && tap == 4) store_patch(buf ^ 1, 1, flip_next);
+        load_w(kt + 2, st2);
+        if (more && tap == 0) { load_patch(cb + 1, 0); xl_now = true; }
+        if (more && tap == 2) { load_patch(cb + 1, 1); xl_now = true; }
+        const unsigned char* As = a_lane + st * SP_A_BYTES;
+        v8bf af[3][2], bf[3][2];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[pc][i] = *(const v8bf*)(As + (pc * 2 * SP_T + i * 64) * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pos = ((c_mask[j] >> tap) & 1u) ? c_pos[j] + shift : PL;       // a tap outside the image: the zero slot
+            const unsigned char* Bs = b_plane + buf * XB + pos * 16;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bf[pc][j] = *(const v8bf*)(Bs + pc * 2 * PS);
+        }
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+        v16f zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    pipe[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], (t == 0 && decltype(FIRST)::value) ? zero : pipe[i][j], 0, 0, 0);
+        // W(kt + 1) (issued during step kt - 1) has landed when at most W(kt + 2) and the patch loads issued since are outstanding: 3, + 8 per patch load
+        // of this step or the last one (both sit behind W(kt + 1) in the queue)
+        if (xl_now || xl_prev) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        xl_prev = xl_now;
+        // next K position
+        tap += 1; tdw += 1; shift += 1;
+        if (tdw == p.kw) { tdw = 0; shift += p.W - p.kw; }
+        if (tap == T) { tap = 0; shift = -halo; cb += 1; buf ^= 1; }
+    };
+
+    // ---- fill: zero slots, the patch of block 0, W(0), W(1)
+    if (tid < 12) {
+        const v4u z = {0u, 0u, 0u, 0u};
+        asm volatile("ds_write_b128 %0, %1" :: "v"(lds_base + XBASE + (tid / 6) * XB + (tid % 6) * PS + PL * 16), "v"(z));
+    }
+    load_w(0, 0);
+    load_patch(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_patch(0, 0, 0u);
+    load_patch(0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_patch(0, 1, 0u);
+    load_w(1, 1);
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // W(0) and the patch of block 0 are in LDS
+    stamp(p, wave, lane, 1);
+    std::integral_constant<int, 0> S0; std::integral_constant<int, 1> S1; std::integral_constant<int, 2> S2;
+    std::integral_constant<bool, true> first;
+    for (int kt = 0; kt < nk; kt += 3) {          // up to two steps past the end multiply zeros (their W stages are zero-filled)
+        // a pass's three steps start from C = 0; T % 3 == 0 (split_patch_ok) keeps a pass inside one channel block, whose sign it is folded with
+        const bool negated = (cb & 1) != 0;
+        std::integral_constant<bool, false> later;
+        step(kt, S0, first);
+        step(kt + 1, S1, later);
+        step(kt + 2, S2, later);
+        fold(negated);
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(p, wave, lane, 2);
+    stamp(p, wave, lane, 3);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        v16f t[1][1];
+        t[0][0] = acc[0][0];
+        block_epilogue<CHAIN, true>(p, t, smem, tid, lane, wave, co0 + (q >> 1) * 64, m0 + (q & 1) * 64, half, -1, 0, 1, osel, bsel, nullptr);
+        acc[0][0] = acc[0][1];
+        acc[0][1] = acc[1][0];
+        acc[1][0] = acc[1][1];
+    }
+    stamp(p, wave, lane, 4);
+}
+
+// W[k][ldw] fp32 (k rows, output channel = column) -> bf16 planes [cout / 128][K step][piece][k half][128][8].  taps == 1: the K steps in the pack's row
+// order (K17).  taps > 1 (K17b): the pack's rows are tap-major (k = tap * Cin + ci); step = (ci / 16) * taps + tap -- a channel block's taps side by side.
+__global__ void split_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ planes, int K, int cout, int ldw, int taps)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)K * cout) return;
     const int k = (int)(idx / cout), co = (int)(idx - (long)k * cout);
     unsigned h[3];
     split_pair(w[(long)k * ldw + co], 0.f, h[0], h[1], h[2]);          // the value's pieces in the low halves
-    const int rt = co / SP_T, r = co - rt * SP_T, kt = k / SP_BK, kk = k - kt * SP_BK, nk = K / SP_BK;
+    const int cin = K / taps, tap = k / cin, ci = k - tap * cin;
+    const int rt = co / SP_T, r = co - rt * SP_T, kt = (ci / SP_BK) * taps + tap, kk = ci % SP_BK, nk = K / SP_BK;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
         planes[((((long)(rt * nk + kt) * 3 + q) * 2 + kk / 8) * SP_T + r) * 8 + kk % 8] = (uint16_t)(h[q] & 0xffffu);
 }
 
 // ---- the bf16x6 kernel's host side: a registry of split packs (fp32 pack pointer -> bf16 planes), filled by the engine for the layers it covers
-struct SplitPack { uint16_t* planes; int K, cout, ldw; };
+struct SplitPack { uint16_t* planes; int K, cout, ldw, taps; };      // taps: 1 = K steps in pack order (K17), kh * kw = channel-block-major (K17b)
 static std::mutex g_split_mu;
 static std::unordered_map<const float*, SplitPack> g_split;
 
@@ -303,14 +529,25 @@ bool split_grid_ok(const ConvParams& p)
 
 static std::atomic<long> g_split_launches{0};
 
+// the layers K17b takes from K17: "same" KxK convolutions (output map = input map) with 5 .. 25 taps whose halo fits the patch
+bool split_patch_ok(const ConvParams& p)
+{
+    const int T = p.kh * p.kw;
+    if (T < 5 || T > SPP_MAX_TAPS || (T % 3) != 0 || p.stride != 1 || p.tap_major != 1) return false;        // (T % 3: a pass of three K-steps stays inside one channel block)
+    if (p.OH != p.H || p.OW != p.W || 2 * p.pad != p.kh - 1 || 2 * p.pad != p.kw - 1) return false;
+    static const bool off = getenv("XFR_SPLIT_NO_PATCH") != nullptr;          // A/B runs: K17 for every covered layer
+    return spp_halo(p) <= SPP_MAX_HALO && !off;
+}
+
 // the planes of pack w, split now if this is its first launch: the split runs on the launch's stream, which is drained before the entry becomes visible
 // (another stream's launch of the same layer may follow at once)
-const uint16_t* split_planes(const float* w, int K, int cout, int ldw, hipStream_t s)
+const uint16_t* split_planes(const float* w, int K, int cout, int ldw, int taps, hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_split_mu);
     auto it = g_split.find(w);
-    if (it != g_split.end()) return (it->second.K == K && it->second.cout == cout && it->second.ldw == ldw) ? it->second.planes : nullptr;
-    SplitPack sp{nullptr, K, cout, ldw};
+    if (it != g_split.end())
+        return (it->second.K == K && it->second.cout == cout && it->second.ldw == ldw && it->second.taps == taps) ? it->second.planes : nullptr;
+    SplitPack sp{nullptr, K, cout, ldw, taps};
     if (hipMalloc(&sp.planes, (size_t)K * cout * 3 * sizeof(uint16_t)) != hipSuccess) {
         (void)hipGetLastError();
         sp.planes = nullptr;
@@ -318,25 +555,28 @@ const uint16_t* split_planes(const float* w, int K, int cout, int ldw, hipStream
         return nullptr;
     }
     const long n = (long)K * cout;
-    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, sp.planes, K, cout, ldw);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, sp.planes, K, cout, ldw, taps);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(sp.planes); return nullptr; }
     g_split[w] = sp;
     return sp.planes;
 }
 
 template <bool RELU, int CHAIN>
-void launch_split_inst(const ConvParams& q, const uint16_t* w0, const uint16_t* w1, int n_co, int n_m, hipStream_t s)
+void launch_split_inst(const ConvParams& q, const uint16_t* w0, const uint16_t* w1, int n_co, int n_m, hipStream_t s, bool patch)
 {
-    // once per instantiation AND device: the kernel's 72 KB of dynamic LDS exceed the default limit
+    // once per instantiation AND device: the kernels' dynamic LDS (72 KB; K17b: 36 KB + two patches) exceeds the default limit
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_relaxed) & bit)) {
         (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<RELU, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_split_patch_kernel<RELU, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * SP_A_BYTES + 2 * 6 * (SP_T + 2 * SPP_MAX_HALO + 1) * 16);
         done.fetch_or(bit);
     }
-    hipLaunchKernelGGL((conv_gemm_split_kernel<RELU, CHAIN>), dim3(n_co * n_m), dim3(NT), SP_LDS, s, q, w0, w1, n_co, n_m);
+    if (patch) hipLaunchKernelGGL((conv_gemm_split_patch_kernel<RELU, CHAIN>), dim3(n_co * n_m), dim3(NT), spp_lds_bytes(q), s, q, w0, w1, n_co, n_m);
+    else hipLaunchKernelGGL((conv_gemm_split_kernel<RELU, CHAIN>), dim3(n_co * n_m), dim3(NT), SP_LDS, s, q, w0, w1, n_co, n_m);
 }
 
 // false: the launch is not one the split kernel covers (or its pack is not registered) -- the caller takes the fp32 kernel the rules give
@@ -353,8 +593,10 @@ bool launch_split(const ConvParams& p, hipStream_t s)
         if (q.chain_sig >= 0 && chain_sig_is_dual(q.chain_sig)) return false;      // (only ever with dualacc, which the layer test excludes)
         family = q.chain_sig < 0 ? 2 : (chain_sig_is_mfm(q.chain_sig) ? 3 : 1);
     }
-    const uint16_t* w0 = split_planes(p.w, p.K, p.CoutTot, p.ldw, s);
-    const uint16_t* w1 = p.nhalves == 2 ? split_planes(p.w_pos, p.K, p.CoutTot, p.ldw, s) : nullptr;
+    const bool patch = split_patch_ok(p);
+    const int taps = patch ? p.kh * p.kw : 1;
+    const uint16_t* w0 = split_planes(p.w, p.K, p.CoutTot, p.ldw, taps, s);
+    const uint16_t* w1 = p.nhalves == 2 ? split_planes(p.w_pos, p.K, p.CoutTot, p.ldw, taps, s) : nullptr;
     if (!w0 || (p.nhalves == 2 && !w1)) return false;
     // counted only now: every refusal above sends the launch to an fp32 kernel
     g_split_launches++;
@@ -365,11 +607,11 @@ bool launch_split(const ConvParams& p, hipStream_t s)
     const int n_co = (p.CoutTot / SP_T) * p.nhalves;
     const int n_m = (p.M + SP_T - 1) / SP_T;
     switch (family) {
-        case -1: launch_split_inst<true, 0>(q, w0, w1, n_co, n_m, s); break;
-        case 0: launch_split_inst<false, 0>(q, w0, w1, n_co, n_m, s); break;
-        case 1: launch_split_inst<false, 1>(q, w0, w1, n_co, n_m, s); break;
-        case 2: launch_split_inst<false, 2>(q, w0, w1, n_co, n_m, s); break;
-        default: launch_split_inst<false, 3>(q, w0, w1, n_co, n_m, s); break;
+        case -1: launch_split_inst<true, 0>(q, w0, w1, n_co, n_m, s, patch); break;
+        case 0: launch_split_inst<false, 0>(q, w0, w1, n_co, n_m, s, patch); break;
+        case 1: launch_split_inst<false, 1>(q, w0, w1, n_co, n_m, s, patch); break;
+        case 2: launch_split_inst<false, 2>(q, w0, w1, n_co, n_m, s, patch); break;
+        default: launch_split_inst<false, 3>(q, w0, w1, n_co, n_m, s, patch); break;
     }
     return true;
 }
@@ -390,7 +632,7 @@ void conv_gemm_forget_split(const void* lo, size_t bytes)
     }
 }
 int conv_gemm_split_covers(const ConvParams& p) { return split_layer_ok(p) ? 1 : 0; }
-bool conv_gemm_presplit(const float* w, int K, int cout, int ldw, hipStream_t s) { return split_planes(w, K, cout, ldw, s) != nullptr; }
+bool conv_gemm_presplit(const ConvParams& p, const float* w, hipStream_t s) { return split_planes(w, p.K, p.CoutTot, p.ldw, split_patch_ok(p) ? p.kh * p.kw : 1, s) != nullptr; }
 bool conv_gemm_split_wanted(const ConvParams& p) { return split_layer_ok(p) && (p.split_ok == 2 || split_grid_ok(p)); }
 bool conv_gemm_launch_split(const ConvParams& p, hipStream_t s) { return launch_split(p, s); }
 long conv_gemm_split_launches() { return g_split_launches.load(); }

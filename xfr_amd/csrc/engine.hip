@@ -2576,8 +2576,8 @@ static void presplit_weights(xfr_engine* e)
         conv_geometry(e, (int)k, 1, p);
         p.CoutTot = d.cout; p.nhalves = 1;
         if ((e->split_mask & 1) && conv_gemm_split_covers(p)) {
-            (void)conv_gemm_presplit(e->arena + o.w_true, p.K, p.CoutTot, p.ldw, 0);
-            (void)conv_gemm_presplit(e->arena + o.w_pos, p.K, p.CoutTot, p.ldw, 0);
+            (void)conv_gemm_presplit(p, e->arena + o.w_true, 0);
+            (void)conv_gemm_presplit(p, e->arena + o.w_pos, 0);
         }
         if ((e->split_mask & 2) && k != 0 && d.stride == 1) {
             // the backward-data GEMM of a stride-1 convolution (bwd_conv_params): a convolution with the flipped, transposed pack
@@ -2591,8 +2591,8 @@ static void presplit_weights(xfr_engine* e)
             q.tap_major = o.tap_bwd ? 1 : 0;
             q.CoutTot = a.C; q.nhalves = 1; q.ldw = o.ldb; q.K = o.Kb;
             if (conv_gemm_split_covers(q)) {
-                (void)conv_gemm_presplit(e->arena + o.w_bwd, q.K, q.CoutTot, q.ldw, 0);
-                (void)conv_gemm_presplit(e->arena + o.w_bwd_true, q.K, q.CoutTot, q.ldw, 0);
+                (void)conv_gemm_presplit(q, e->arena + o.w_bwd, 0);
+                (void)conv_gemm_presplit(q, e->arena + o.w_bwd_true, 0);
             }
         }
     }
