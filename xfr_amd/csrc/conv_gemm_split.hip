@@ -15,19 +15,40 @@ namespace {
 // ---- K17: conv_gemm_split_kernel -- fp32-accurate GEMM on the bf16 MFMA pipe ("bf16x6") ---------------------------------------------------------------
 // An fp32 value is EXACTLY the sum of three bf16 pieces (8 + 8 + 8 significant bits, each piece the round-to-nearest bf16 of what is left); a bf16 x
 // bf16 product is exact in fp32; the six products (i, j) with i + j <= 2, accumulated in fp32 smallest first, reproduce the fp32 product to ~2^-23 -- the
-// maps cannot tell it from a re-ordered fp32 sum (tests/precision/split_probe.py, profiles/r5/experiments/bf16_split.txt).  Six
-// v_mfma_f32_32x32x16_bf16 take 6 x 32 cycles where the sixteen fp32 MFMAs of the same K = 16 take 8 x 64.
-//   * W: split once per pack (conv_gemm_register_split) into three bf16 planes, tiled [128-row tile][K step][piece][k half][128][8]: a K-step of a row
+// maps cannot tell it from a re-ordered fp32 sum (tests/precision/split_probe.py, tests/test_split_arith.py).  Six v_mfma_f32_32x32x16_bf16 take
+// 6 x 32 cycles where the sixteen fp32 MFMAs of the same K = 16 take 8 x 64.
+//   * W: split when the weights arrive (conv_gemm_presplit) into three bf16 planes, tiled [128-row tile][K step][piece][k half][128][8]: a K-step of a row
 //     tile is one contiguous 12 KB block that goes global -> LDS without registers (three LDS stages, two steps ahead);
-//   * X: fp32 as the producing epilogues left it; the workgroup's 256 lanes gather a 16 x 128 slab three steps ahead into registers (the tap-major
-//     gather of K2: per-lane shifted offset per filter tap, channels as the scalar offset, padding / m tails / steps past the end out of the buffer's
-//     range = 0), split every value once and write the three planes to LDS in fragment order (ds_write as inline asm: a compiler-visible ds_write after a
-//     buffer_load...lds is ordered with s_waitcnt vmcnt(0), which would drain exactly that prefetch);
-//   * 128 x 128 block tile, wave (wr, wc) holds the quadrants (wr, wc) of the four 64 x 64 sub-tiles -- so each sub-tile is laid out exactly like the
-//     block tile of K1 / K2 and runs their epilogues (block_epilogue) unchanged;
-//   * the loop is unrolled by three (stage and register-set indices are static; up to two steps past the end multiply zeros), one counted wait and one
-//     raw barrier per step.
+//   * X: fp32 as the producing epilogues left it, split in registers on its way into LDS (ds_write as inline asm: a compiler-visible ds_write after a
+//     buffer_load...lds is ordered with s_waitcnt vmcnt(0), which would drain exactly that prefetch), in one of two ways -- below;
+//   * 128 x 128 block tile on EIGHT waves, two per SIMD: wave (wr4, wc) owns rows wr4 * 32 .. + 31 and columns wc * 64 .. + 63 -- two 32 x 32
+//     accumulator tiles, 12 MFMAs per K-step -- each a quadrant of one of the tile's four 64 x 64 sub-tiles, which are laid out exactly like the block
+//     tile of K1 / K2 and leave through their epilogues (block_epilogue) unchanged;
+//   * no sum stays in the matrix pipe for more than a pass of three K-steps: the MFMAs of a pass start from C = 0 and the pass is added to the fp32
+//     result registers with v_pk_add_f32, every other pass (patch mode: channel block) negated -- see `fold`;
+//   * the loop is unrolled by three (static X stage / register-set indices; up to two steps past the end multiply zeros), one counted wait and one raw
+//     barrier per step.
 // Layers: stride-1 convolutions (1x1 and tap-major KxK) with Cin % 16 == 0, 128 | Cout, no dual-accumulator launch, dense output.
+//
+// Why eight waves (round 6; profiles/r6/experiments/).  Round 5's kernel ran the tile on four waves, one per SIMD, and that wave issued its DMA (~150
+// cycles per instruction in a busy step), waited for its fragment reads and then fed 24 MFMAs, one thing after the other: ~1900 cycles per K-step for 768
+// cycles of matrix pipe.  Two ways out were built and measured: (a) K-steps alternating between two four-wave groups in a compute / load ping-pong with
+// stream-K grids -- the loading group becomes the bottleneck (2300 cycles per step: DMA and load issue, the split's VALU work under the partner's MFMAs),
+// the workgroup owns a whole CU (256 registers x 8 waves) and the timed three-stream step LOST 13 %; (b) this kernel -- the same tile cut among eight
+// waves of ~125 registers, i.e. the register space the four waves took, so other streams' launches still share the CU: the deep-K 1x1 layers +21 % in
+// isolation, the step +1 %.
+//
+// X, mode 1 -- the slab (1x1 and general tap-major layers): per K-step the 512 lanes gather a 16 x 128 slab three steps ahead into registers (the
+// tap-major gather of K2: per-lane shifted offset per filter tap, channels as the scalar offset, padding / m tails / steps past the end out of the
+// buffer's range = 0), four values per lane.
+// X, mode 2 -- the patch ("same" KxK convolutions: 3x3 pad 1, every ResNet bottleneck's middle layer, forward and backward-data).  What limits the slab
+// kernel is not the matrix pipe: a 128 x 128 x 16 step moves 20 KB from L2 (12 KB of W planes, 8 KB of fp32 X) and splits 2048 X values; with the MFMAs
+// removed the launch is no faster than ~150 TFLOP/s-equivalent (v2_phase_variants.txt).  In such a convolution the X slab of tap (dh, dw) is the slab of
+// tap (0, 0) shifted by (dh - pad) * W + (dw - pad) positions -- the same fp32 values, loaded and split kh * kw times.  Here the K order is (channel
+// block, tap, channel): per block of 16 channels the workgroup stages ONE patch of the input row -- its 128 positions plus a halo of pad * W + pad on
+// both sides -- as bf16 pieces in LDS (one task per lane, spread over the block's first steps), and every tap's B fragments are ds_reads of that patch at
+// the tap's offset; positions a tap reaches outside the image read a zero slot.  Per 9 K-steps of a 3x3 layer: 108 + 10 KB from L2 instead of 180, one
+// split instead of nine (+14 % in isolation, the ResNet-101 step +3.5 %).  W planes in (channel block, tap) step order (split_pack_kernel, taps > 1).
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int SP_T = 128, SP_BK = 16;
@@ -54,17 +75,35 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
     p2 = cvt_pk_bf16(sa, sb);
 }
 
-template <bool RELU, int CHAIN>
-__global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams p, const uint16_t* __restrict__ ws0, const uint16_t* __restrict__ ws1,
-                                                            const int n_co_tiles, const int n_m_tiles)
+// the patch of X mode 2
+constexpr int SPP_MAX_HALO = 64, SPP_MAX_TAPS = 25;
+
+__host__ __device__ inline int spp_halo(const ConvParams& p) { return p.pad * p.W + p.pad; }
+__host__ __device__ inline int spp_patch_len(const ConvParams& p) { return SP_T + 2 * spp_halo(p); }
+inline size_t spp_lds_bytes(const ConvParams& p) { return (size_t)3 * SP_A_BYTES + (size_t)2 * 6 * (spp_patch_len(p) + 1) * 16; }
+
+constexpr int NT8 = 512;
+
+template <int N>
+__device__ __forceinline__ void sp8_wait_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <bool RELU, int CHAIN, bool PATCH>
+__global__ __launch_bounds__(NT8, 2) void conv_gemm_split_kernel(const ConvParams p, const uint16_t* __restrict__ ws0, const uint16_t* __restrict__ ws1,
+                                                                  const int n_co_tiles, const int n_m_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
-    constexpr int XBASE = 3 * SP_A_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    // W ring: NST stages, DMA issued D = NST - 1 steps ahead (round 6, NST 3 / 4 / 5 on the same box: 1592 / 1550 / 1480 maps/s -- the DMA's latency is not
+    // what a step waits for, and a deeper ring costs LDS that co-running workgroups need); X behind it
+    constexpr int NST = 3, D = NST - 1, XBASE = NST * SP_A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr4 = wave8 >> 1, wc = wave8 & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
-    stamp(p, wave, lane, 0, 2);       // tuning stamps / the launch log's span record, like K1
+    const bool two_dma = wave8 < 4;               // 12 DMA chunks of 1 KB per K-step on eight waves: waves 0-3 issue two, waves 4-7 one
+    if (wave8 < 4) stamp(p, wave8, lane, 0, 4);
 
     const int lid = xcd_remap(blockIdx.x, n_co_tiles * n_m_tiles);
     const int tile_m = lid / n_co_tiles;
@@ -76,16 +115,31 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
     const uint16_t* __restrict__ wsel = half ? ws1 : ws0;
     const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
     float* __restrict__ osel = half ? p.out1 : p.out0;
-    const int nk = p.K / SP_BK;
+    const int T = p.kh * p.kw, ncb = p.Cin / SP_BK, nk = p.K / SP_BK;
+    const int halo = spp_halo(p), PL = spp_patch_len(p);
+    const int PS = PATCH ? (PL + 1) * 16 : SP_T * 16;       // bytes of one (piece, k half) plane of X: a patch (+ zero slot), or a step's 128 columns
+    const int XB = 6 * PS;
     const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, n_co_half * nk * SP_A_BYTES, 0x00020000);
     const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds);
 
-    // staging role: column m0 + (tid & 127), k-half wave >> 1 (wave-uniform)
-    const int sm = tid & 127, skh = wave >> 1;
+    // ---- X staging role of the lane
+    //   PATCH: task t = tid = k half * PL + patch position q (2 PL <= 512)
+    //   else : column m0 + (tid & 127), k quarter tid >> 7 (wave-uniform): four of a step's sixteen k
+    unsigned t_voff = OOB, t_lds = 0;
+    bool t_ok = false;
     int base_m = 0;
     unsigned long long tapmask = 0ull;
-    {
+    const int sm = tid & 127, skq = wave8 >> 1;
+    if constexpr (PATCH) {
+        const int kh_ = tid >= PL ? 1 : 0, q = tid - kh_ * PL;
+        const long g = (long)m0 - halo + q;
+        t_ok = tid < 2 * PL;
+        const bool in_row = t_ok && g >= 0 && g < (long)p.in_nb * p.H * p.W;
+        t_voff = in_row ? (unsigned)g * 4u + (unsigned)(kh_ * 8) * chan_bytes : OOB;
+        t_lds = lds_base + XBASE + kh_ * PS + q * 16;
+    } else {
         const int m = m0 + sm;
         const bool m_ok = m < p.M;
         const int mm = m_ok ? m : 0;
@@ -103,78 +157,57 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
             for (int dh = 0; dh < p.kh; ++dh)
                 if ((unsigned)(ih0 + dh) < (unsigned)p.H) tapmask |= vw << (dh * p.kw);
         }
+        t_lds = lds_base + XBASE + ((skq >> 1) * SP_T + sm) * 16 + (skq & 1) * 8;
     }
-    const unsigned xs_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds) + XBASE + (skh * SP_T + sm) * 16;   // this lane's LDS slot
+    // ---- fragment columns (PATCH): sub-block j2, column wc * 64 + j2 * 32 + l31; which taps stay inside the image there
+    int c_pos[2] = {0, 0};
+    unsigned c_mask[2] = {0u, 0u};
+    if constexpr (PATCH) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = wc * 64 + j * 32 + l31, m = m0 + c;
+            c_pos[j] = c + halo;
+            unsigned mk = 0u;
+            if (m < p.M) {
+                const int ohw = p.OH * p.OW;
+                const int r = m % ohw;
+                const int oh = r / p.OW, ow = r - oh * p.OW;
+                for (int dh = 0; dh < p.kh; ++dh)
+                    for (int dw = 0; dw < p.kw; ++dw)
+                        if ((unsigned)(oh + dh - p.pad) < (unsigned)p.H && (unsigned)(ow + dw - p.pad) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+            }
+            c_mask[j] = mk;
+        }
+    }
+    const unsigned char* a_lane = lds + (lhi * SP_T + wr4 * 32 + l31) * 16;
+    const unsigned char* b_plane = lds + XBASE + lhi * PS;
 
-    v16f acc[2][2], pipe[2][2];      // the fp32 result, and the in-pipe sums of the current pass (three K-steps)
+    v16f acc[2], pipe[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; pipe[i][j][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; pipe[j][r] = 0.f; }
 
+    auto dma = [&](int kt, int stage, int ch) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(lds + stage * SP_A_BYTES + ch * 1024), 16, (ch * 1024 + lane * 16) | (kt < nk ? 0u : OOB),
+                                                 (tile_co * nk + kt) * SP_A_BYTES, 0, 0);
+    };
     auto load_w = [&](int kt, int stage) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b)      // steps past the end: out of range, the hardware writes zeros
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(lds + stage * SP_A_BYTES + (b * 4 + wave) * 1024), 16,
-                                                     ((b * 4 + wave) * 1024 + lane * 16) | (kt < nk ? 0u : OOB), (tile_co * nk + kt) * SP_A_BYTES, 0, 0);
-    };
-    // the X loads walk the K-steps in order: (tap, first channel) of the next step to be loaded, and that tap's per-lane offset
-    int ld_tap = 0, ld_ci0 = 0;
-    unsigned ld_voff = (tapmask & 1ull) ? (unsigned)base_m * 4u : OOB;
-    auto load_x = [&](int kt, float (&v)[8]) {
-        const unsigned voff = ld_voff | (kt < nk ? 0u : OOB);
-        const unsigned so = (unsigned)(ld_ci0 + skh * 8) * chan_bytes;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rIn, voff, so + (unsigned)i * chan_bytes, 0));
-        ld_ci0 += SP_BK;
-        if (ld_ci0 >= p.Cin) {          // wave-uniform: next filter tap => new per-lane shifted offset
-            ld_ci0 = 0;
-            ld_tap += 1;
-            const int dh = ld_tap / p.kw, dw = ld_tap - dh * p.kw;
-            ld_voff = (ld_tap < p.kh * p.kw && ((tapmask >> ld_tap) & 1ull)) ? (unsigned)(base_m + dh * p.W + dw) * 4u : OOB;
-        }
-    };
-    auto write_piece = [&](v4u q, int stage, int piece) {
-        asm volatile("ds_write_b128 %0, %1" :: "v"(xs_addr + stage * SP_B_BYTES + piece * 2 * SP_T * 16), "v"(q));
-    };
-    // `flip`: 0x80008000 for a K-step of a NEGATED phase (below), else 0 -- the sign bits of both bf16 of a word
-    auto store_x = [&](const float (&v)[8], int stage, unsigned flip) {
-        v4u p0, p1, p2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a = RELU ? fmaxf(v[2 * i], 0.f) : v[2 * i], b = RELU ? fmaxf(v[2 * i + 1], 0.f) : v[2 * i + 1];
-            unsigned q0, q1, q2;
-            split_pair(a, b, q0, q1, q2);
-            p0[i] = q0 ^ flip; p1[i] = q1 ^ flip; p2[i] = q2 ^ flip;
-        }
-        write_piece(p0, stage, 0); write_piece(p1, stage, 1); write_piece(p2, stage, 2);
+        dma(kt, stage, wave8);
+        if (two_dma) dma(kt, stage, 8 + wave8);
     };
     // Short in-pipe sums and sign phases (round 6).  The bf16 MFMA does not round its running sum to nearest like the fp32 MFMA (an fmaf chain) does:
     // against float64 a K-long in-pipe sum has 1.5-3x the rms error of the fp32 kernels and sits ~4e-9 of its sum of magnitudes BELOW the exact value, in
     // every element of every layer -- which a contrastive map (a difference of two nearly equal sweeps) amplifies.  So (a) the MFMAs of a pass (three
     // K-steps) start from C = 0 and their sums are added to the fp32 result registers with v_pk_add_f32 (round to nearest): the K-long sum is an ordinary
-    // fp32 sum of K / 48 partial sums; (b) every other pass is computed NEGATED -- its X slabs are stored with the sign bits flipped (one XOR per word)
-    // and its sums subtracted -- so that the pipe's downward offset changes sign with every pass and cancels.  `flip`: the sign-bit mask of the phase the
-    // step's X slab (step kt+1) belongs to.
-    // one K-step; ST = kt % 3 (static), xcur = X(kt+1) registers (split here), xnew = registers that receive X(kt+3)
-    auto step = [&](int kt, auto ST, float (&xcur)[8], float (&xnew)[8], unsigned flip, auto FIRST) {
-        constexpr int st = decltype(ST)::value, st1 = (st + 1) % 3, st2 = (st + 2) % 3;
-        load_w(kt + 2, st2);
-        load_x(kt + 3, xnew);
-        const unsigned char* As = lds + st * SP_A_BYTES;
-        const unsigned char* Bs = lds + XBASE + st * SP_B_BYTES;
-        v8bf af[3][2], bf[3][2];
-        // quadrant (wr, wc) of sub-tile (i, j): rows i * 64 + wr * 32, columns j * 64 + wc * 32
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[pc][i] = *(const v8bf*)(As + ((pc * 2 + lhi) * SP_T + i * 64 + wr * 32 + l31) * 16);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[pc][j] = *(const v8bf*)(Bs + ((pc * 2 + lhi) * SP_T + j * 64 + wc * 32 + l31) * 16);
-        }
-        // (piece of W, piece of X), smallest products first
+    // fp32 sum of K / 48 partial sums; (b) every other pass (patch mode: every other channel block) is computed NEGATED -- its X pieces are stored with
+    // the sign bits flipped (one XOR per word) and its sums subtracted -- so that the pipe's downward offset changes sign and cancels.  Measured: rms
+    // 5-9e-9 of the sum of magnitudes, mean ~1e-11 (fp32 split-K kernel: 1.1e-8; round 5's K-long in-pipe sums: 3.2e-8), profiles/r6/conv_error_probe.txt.
+    auto fold = [&](bool negated) {
+        if (negated) { acc[0] -= pipe[0]; acc[1] -= pipe[1]; }
+        else { acc[0] += pipe[0]; acc[1] += pipe[1]; }
+    };
+    auto mfmas = [&](const v8bf (&af)[3], const v8bf (&bf)[3][2], auto FIRST) {
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
         v16f zero;
 #pragma unroll
@@ -182,293 +215,179 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_split_kernel(const ConvParams
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    pipe[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], (t == 0 && decltype(FIRST)::value) ? zero : pipe[i][j], 0, 0, 0);
-        store_x(xcur, st1, flip);
-        // W(kt+1) (issued during step kt-1) has landed when at most X(kt+2), W(kt+2), X(kt+3) are outstanding: 8 + 3 + 8
-        asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int j = 0; j < 2; ++j)
+                pipe[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]], bf[TB[t]][j], (t == 0 && decltype(FIRST)::value) ? zero : pipe[j], 0, 0, 0);
     };
-    // A pass's sums leave the matrix pipe: acc += pipe (v_pk_add_f32, round to nearest) -- or -=, for a pass whose X slabs were stored negated
-    auto fold = [&](bool negated) {
-        if (negated) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] -= pipe[i][j];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] += pipe[i][j];
-        }
-    };
-    float x0[8], x1[8], x2[8];
-    load_w(0, 0);
-    load_x(0, x0);
-    store_x(x0, 0, 0u);
-    load_w(1, 1);
-    load_x(1, x0);
-    load_x(2, x1);
-    asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // W(0) and the split of X(0) are in LDS
-    stamp(p, wave, lane, 1);
     std::integral_constant<int, 0> S0; std::integral_constant<int, 1> S1; std::integral_constant<int, 2> S2;
     std::integral_constant<bool, true> first; std::integral_constant<bool, false> later;
-    unsigned flip = 0u;                         // the current pass's phase
-    for (int kt = 0; kt < nk; kt += 3) {        // up to two steps past the end multiply zeros: no branch on kt inside the body
-        const bool negated = flip != 0u;
-        step(kt, S0, x0, x2, flip, first);      // the pass's sums start from C = 0: no in-pipe chain is longer than 18 MFMAs (288 terms)
-        step(kt + 1, S1, x1, x0, flip, later);
-        flip ^= 0x80008000u;
-        step(kt + 2, S2, x2, x1, flip, later);  // its X slab is the next pass's first
-        fold(negated);
+
+    if constexpr (PATCH) {
+        float xp[8];
+        auto load_patch = [&](int cb) {
+            const unsigned so = (unsigned)(cb * SP_BK) * chan_bytes;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xp[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rIn, t_voff, so + (unsigned)i * chan_bytes, 0));
+        };
+        auto store_patch = [&](int buf, unsigned flip) {
+            v4u q0, q1, q2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = RELU ? fmaxf(xp[2 * i], 0.f) : xp[2 * i], b = RELU ? fmaxf(xp[2 * i + 1], 0.f) : xp[2 * i + 1];
+                unsigned h0, h1, h2;
+                split_pair(a, b, h0, h1, h2);
+                q0[i] = h0 ^ flip; q1[i] = h1 ^ flip; q2[i] = h2 ^ flip;
+            }
+            if (t_ok) {
+                const unsigned at = t_lds + buf * XB;
+                asm volatile("ds_write_b128 %0, %1" :: "v"(at), "v"(q0));
+                asm volatile("ds_write_b128 %0, %1" :: "v"(at + 2 * PS), "v"(q1));
+                asm volatile("ds_write_b128 %0, %1" :: "v"(at + 4 * PS), "v"(q2));
+            }
+        };
+        int tap = 0, cb = 0, buf = 0, shift = -halo, tdw = 0;
+        bool xl_prev = false;
+        int wst = 0;                                  // W stage of the step being computed: kt % NST
+        auto step = [&](int kt, auto FIRST) {
+            const int st = wst, stD = wst + D >= NST ? wst + D - NST : wst + D;
+            const bool more = cb + 1 < ncb;
+            bool xl_now = false;
+            // the next block's patch: loaded at tap 0, split and stored at tap 2 -- BEFORE this step's DMA, so that the wait for its X registers leaves at most
+            // the previous step's DMA in flight
+            if (more && tap == 2) store_patch(buf ^ 1, ((cb + 1) & 1) ? 0x80008000u : 0u);
+            load_w(kt + D, stD);
+            if (more && tap == 0) { load_patch(cb + 1); xl_now = true; }
+            const unsigned char* As = a_lane + st * SP_A_BYTES;
+            v8bf af[3], bf[3][2];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) af[pc] = *(const v8bf*)(As + pc * 2 * SP_T * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pos = ((c_mask[j] >> tap) & 1u) ? c_pos[j] + shift : PL;
+                const unsigned char* Bs = b_plane + buf * XB + pos * 16;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) bf[pc][j] = *(const v8bf*)(Bs + pc * 2 * PS);
+            }
+            mfmas(af, bf, FIRST);
+            // W(kt + 1) has landed when at most the DMA of steps kt + 2 .. kt + D -- and the patch loads of this step or the last one -- are outstanding
+            if (xl_now || xl_prev) { if (two_dma) sp8_wait_barrier<2 * (D - 1) + 8>(); else sp8_wait_barrier<(D - 1) + 8>(); }
+            else { if (two_dma) sp8_wait_barrier<2 * (D - 1)>(); else sp8_wait_barrier<(D - 1)>(); }
+            xl_prev = xl_now;
+            wst = wst + 1 == NST ? 0 : wst + 1;
+            tap += 1; tdw += 1; shift += 1;
+            if (tdw == p.kw) { tdw = 0; shift += p.W - p.kw; }
+            if (tap == T) { tap = 0; shift = -halo; cb += 1; buf ^= 1; }
+        };
+        if (tid < 12) {
+            const v4u z = {0u, 0u, 0u, 0u};
+            asm volatile("ds_write_b128 %0, %1" :: "v"(lds_base + XBASE + (tid / 6) * XB + (tid % 6) * PS + PL * 16), "v"(z));
+        }
+        load_w(0, 0);
+        load_patch(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_patch(0, 0u);
+#pragma unroll
+        for (int d = 1; d < D; ++d) load_w(d, d);
+        if (two_dma) sp8_wait_barrier<2 * (D - 1)>(); else sp8_wait_barrier<(D - 1)>();
+        if (wave8 < 4) stamp(p, wave8, lane, 1);
+        for (int kt = 0; kt < nk; kt += 3) {
+            const bool negated = (cb & 1) != 0;
+            step(kt, first);
+            step(kt + 1, later);
+            step(kt + 2, later);
+            fold(negated);
+        }
+    } else {
+        int ld_tap = 0, ld_ci0 = 0;
+        unsigned ld_voff = (tapmask & 1ull) ? (unsigned)base_m * 4u : OOB;
+        auto load_x = [&](int kt, float (&v)[4]) {
+            const unsigned voff = ld_voff | (kt < nk ? 0u : OOB);
+            const unsigned so = (unsigned)(ld_ci0 + skq * 4) * chan_bytes;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rIn, voff, so + (unsigned)i * chan_bytes, 0));
+            ld_ci0 += SP_BK;
+            if (ld_ci0 >= p.Cin) {
+                ld_ci0 = 0;
+                ld_tap += 1;
+                const int dh = ld_tap / p.kw, dw = ld_tap - dh * p.kw;
+                ld_voff = (ld_tap < p.kh * p.kw && ((tapmask >> ld_tap) & 1ull)) ? (unsigned)(base_m + dh * p.W + dw) * 4u : OOB;
+            }
+        };
+        auto store_x = [&](const float (&v)[4], int stage, unsigned flip) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            v2u q0, q1, q2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float a = RELU ? fmaxf(v[2 * i], 0.f) : v[2 * i], b = RELU ? fmaxf(v[2 * i + 1], 0.f) : v[2 * i + 1];
+                unsigned h0, h1, h2;
+                split_pair(a, b, h0, h1, h2);
+                q0[i] = h0 ^ flip; q1[i] = h1 ^ flip; q2[i] = h2 ^ flip;
+            }
+            const unsigned at = t_lds + stage * XB;
+            asm volatile("ds_write_b64 %0, %1" :: "v"(at), "v"(q0));
+            asm volatile("ds_write_b64 %0, %1" :: "v"(at + 2 * PS), "v"(q1));
+            asm volatile("ds_write_b64 %0, %1" :: "v"(at + 4 * PS), "v"(q2));
+        };
+        int wst = 0;
+        auto step = [&](int kt, auto ST, float (&xcur)[4], float (&xnew)[4], unsigned flip, auto FIRST) {
+            constexpr int st = decltype(ST)::value, st1 = (st + 1) % 3;       // X ring: three stages, static (the loop is unrolled by three)
+            const int stD = wst + D >= NST ? wst + D - NST : wst + D;
+            load_w(kt + D, stD);
+            load_x(kt + 3, xnew);            // (AFTER the DMA: the counted wait below relies on this order)
+            const unsigned char* As = a_lane + wst * SP_A_BYTES;
+            const unsigned char* Bs = b_plane + st * XB + (wc * 64 + l31) * 16;
+            v8bf af[3], bf[3][2];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                af[pc] = *(const v8bf*)(As + pc * 2 * SP_T * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[pc][j] = *(const v8bf*)(Bs + pc * 2 * PS + j * 32 * 16);
+            }
+            mfmas(af, bf, FIRST);
+            store_x(xcur, st1, flip);
+            // W(kt + 1) has landed when at most X(kt + 2), the DMA of steps kt + 2 .. kt + D, X(kt + 3) are outstanding
+            if (two_dma) sp8_wait_barrier<8 + 2 * (D - 1)>(); else sp8_wait_barrier<8 + (D - 1)>();
+            wst = wst + 1 == NST ? 0 : wst + 1;
+        };
+        float x0[4], x1[4], x2[4];
+        load_w(0, 0);
+        load_x(0, x0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_x(x0, 0, 0u);
+#pragma unroll
+        for (int d = 1; d < D; ++d) load_w(d, d);
+        load_x(1, x0);
+        load_x(2, x1);
+        if (two_dma) sp8_wait_barrier<8 + 2 * (D - 1)>(); else sp8_wait_barrier<8 + (D - 1)>();
+        if (wave8 < 4) stamp(p, wave8, lane, 1);
+        unsigned flip = 0u;
+        for (int kt = 0; kt < nk; kt += 3) {
+            const bool negated = flip != 0u;
+            step(kt, S0, x0, x2, flip, first);
+            step(kt + 1, S1, x1, x0, flip, later);
+            flip ^= 0x80008000u;
+            step(kt + 2, S2, x2, x1, flip, later);
+            fold(negated);
+        }
     }
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stamp(p, wave, lane, 2);
-    stamp(p, wave, lane, 3);
+    if (wave8 < 4) { stamp(p, wave8, lane, 2); stamp(p, wave8, lane, 3); }
 
-    // the four 64 x 64 sub-tiles leave through the epilogues of K1 (each starts with a workgroup barrier before it reuses the LDS).  A REAL loop -- one
-    // epilogue instance in the code, not four (the compiled-chain family is 86 signatures) -- over a fixed register tile: the other three shift down.
+    // ---- epilogues of K1: the wave's two 32 x 32 tiles are quadrants (wr4 & 1, 0) and (wr4 & 1, 1) of the 64 x 64 sub-tile (wr4 >> 1, wc).  block_epilogue
+    // indexes its transposition scratch by the quadrant's wave number; the base is shifted so that every one of the eight waves lands on its own 32 x 36 tile.
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
+    for (int c = 0; c < 2; ++c) {
         v16f t[1][1];
-        t[0][0] = acc[0][0];
-        block_epilogue<CHAIN, true>(p, t, smem, tid, lane, wave, co0 + (q >> 1) * 64, m0 + (q & 1) * 64, half, -1, 0, 1, osel, bsel, nullptr);
-        acc[0][0] = acc[0][1];
-        acc[0][1] = acc[1][0];
-        acc[1][0] = acc[1][1];
+        t[0][0] = acc[0];
+        const int wq = (wr4 & 1) * 2 + c;
+        block_epilogue<CHAIN, true>(p, t, smem + (wave8 - wq) * (32 * 36), tid & 255, lane, wq, co0 + (wr4 >> 1) * 64, m0 + wc * 64, half, -1, 0, 1, osel, bsel, nullptr);
+        acc[0] = acc[1];
     }
-    stamp(p, wave, lane, 4);
-}
-
-// ---- K17b (round 6): the same GEMM for "same" KxK convolutions, X staged ONCE per 16-channel block for all its filter taps --------------------------------
-// What limits K17 is not the matrix pipe: a 128 x 128 x 16 step moves 20 KB from L2 (12 KB of W planes, 8 KB of fp32 X) and splits 2048 X values for 768
-// MFMA cycles; measured with the MFMAs removed the same launch is no faster than ~150 TFLOP/s-equivalent (profiles/r6/experiments/v2_phase_variants.txt).
-// In a stride-1 KxK convolution whose output map equals its input map (3x3 pad 1: every ResNet bottleneck's middle layer, forward and backward-data) the
-// X slab of tap (dh, dw) is the slab of tap (0, 0) shifted by (dh - pad) * W + (dw - pad) positions -- the same fp32 values, loaded and split kh * kw times.
-// Here the K order is (channel block, tap, channel): per block of 16 channels the workgroup stages ONE patch of the input row -- its 128 positions plus a
-// halo of pad * W + pad on both sides -- as bf16 pieces in LDS, and every tap's B fragments are ds_reads of that patch at the tap's offset; positions a
-// tap reaches outside the image read a zero slot.  Per 9 K-steps of a 3x3 layer: 108 + 10 KB from L2 instead of 180, one split instead of nine.
-// W planes in (channel block, tap) step order (split_pack_kernel, layout 1); tile, accumulators, folds, sign phases and epilogues as in K17.
-constexpr int SPP_MAX_HALO = 64, SPP_MAX_TAPS = 25;
-
-__host__ __device__ inline int spp_halo(const ConvParams& p) { return p.pad * p.W + p.pad; }
-__host__ __device__ inline int spp_patch_len(const ConvParams& p) { return SP_T + 2 * spp_halo(p); }
-inline size_t spp_lds_bytes(const ConvParams& p) { return (size_t)3 * SP_A_BYTES + (size_t)2 * 6 * (spp_patch_len(p) + 1) * 16; }
-
-template <bool RELU, int CHAIN>
-__global__ __launch_bounds__(NT, 2) void conv_gemm_split_patch_kernel(const ConvParams p, const uint16_t* __restrict__ ws0, const uint16_t* __restrict__ ws1,
-                                                                  const int n_co_tiles, const int n_m_tiles)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
-    constexpr int XBASE = 3 * SP_A_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    stamp(p, wave, lane, 0, 3);
-
-    const int lid = xcd_remap(blockIdx.x, n_co_tiles * n_m_tiles);
-    const int tile_m = lid / n_co_tiles;
-    const int tile_co_all = lid - tile_m * n_co_tiles;
-    const int n_co_half = n_co_tiles / p.nhalves;
-    const int half = tile_co_all / n_co_half;
-    const int tile_co = tile_co_all - half * n_co_half;
-    const int co0 = tile_co * SP_T, m0 = tile_m * SP_T;
-    const uint16_t* __restrict__ wsel = half ? ws1 : ws0;
-    const float* __restrict__ bsel = half ? p.bias_pos : p.bias;
-    float* __restrict__ osel = half ? p.out1 : p.out0;
-    const int T = p.kh * p.kw, ncb = p.Cin / SP_BK, nk = T * ncb;
-    const int halo = spp_halo(p), PL = spp_patch_len(p);
-    const int PS = (PL + 1) * 16;                 // bytes of one (piece, k half) plane of a patch: PL positions + the zero slot
-    const int XB = 6 * PS;                        // one patch buffer
-    const unsigned chan_bytes = (unsigned)p.in_nb * p.H * p.W * 4u;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, 0, n_co_half * nk * SP_A_BYTES, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds);
-
-    // ---- staging tasks: task t = k half * PL + patch position q; a lane owns tasks tid and tid + 256 (2 PL <= 512)
-    unsigned t_voff[2], t_lds[2];
-    bool t_ok[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int t = tid + r * NT;
-        const int kh_ = t >= PL ? 1 : 0, q = t - kh_ * PL;
-        const long g = (long)m0 - halo + q;       // flattened (n, h, w) index of the input row
-        t_ok[r] = t < 2 * PL;
-        const bool in_row = t_ok[r] && g >= 0 && g < (long)p.in_nb * p.H * p.W;
-        t_voff[r] = in_row ? (unsigned)g * 4u + (unsigned)(kh_ * 8) * chan_bytes : OOB;      // out of the tensor: the hardware returns 0
-        t_lds[r] = lds_base + XBASE + kh_ * PS + q * 16;
-    }
-    // ---- fragment columns: sub-tile j, column j * 64 + wc * 32 + l31; which taps stay inside the image there
-    int c_pos[2];
-    unsigned c_mask[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = j * 64 + wc * 32 + l31, m = m0 + c;
-        c_pos[j] = c + halo;
-        unsigned mk = 0u;
-        if (m < p.M) {
-            const int ohw = p.OH * p.OW;
-            const int r = m % ohw;
-            const int oh = r / p.OW, ow = r - oh * p.OW;
-            for (int dh = 0; dh < p.kh; ++dh)
-                for (int dw = 0; dw < p.kw; ++dw)
-                    if ((unsigned)(oh + dh - p.pad) < (unsigned)p.H && (unsigned)(ow + dw - p.pad) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
-        }
-        c_mask[j] = mk;
-    }
-    const unsigned char* a_lane = lds + (lhi * SP_T + wr * 32 + l31) * 16;
-    const unsigned char* b_plane = lds + XBASE + lhi * PS;
-
-    v16f acc[2][2], pipe[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; pipe[i][j][r] = 0.f; }
-
-    auto load_w = [&](int kt, int stage) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(lds + stage * SP_A_BYTES + (b * 4 + wave) * 1024), 16,
-                                                     ((b * 4 + wave) * 1024 + lane * 16) | (kt < nk ? 0u : OOB), (tile_co * nk + kt) * SP_A_BYTES, 0, 0);
-    };
-    float xp[8];
-    auto load_patch = [&](int cb, int r) {        // task r of every lane, channel block cb: eight dword loads (unconditional: the counted waits below count them)
-        const unsigned so = (unsigned)(cb * SP_BK) * chan_bytes;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xp[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rIn, t_voff[r], so + (unsigned)i * chan_bytes, 0));
-    };
-    auto store_patch = [&](int buf, int r, unsigned flip) {
-        v4u q0, q1, q2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a = RELU ? fmaxf(xp[2 * i], 0.f) : xp[2 * i], b = RELU ? fmaxf(xp[2 * i + 1], 0.f) : xp[2 * i + 1];
-            unsigned h0, h1, h2;
-            split_pair(a, b, h0, h1, h2);
-            q0[i] = h0 ^ flip; q1[i] = h1 ^ flip; q2[i] = h2 ^ flip;
-        }
-        if (t_ok[r]) {
-            const unsigned at = t_lds[r] + buf * XB;
-            asm volatile("ds_write_b128 %0, %1" :: "v"(at), "v"(q0));
-            asm volatile("ds_write_b128 %0, %1" :: "v"(at + 2 * PS), "v"(q1));
-            asm volatile("ds_write_b128 %0, %1" :: "v"(at + 4 * PS), "v"(q2));
-        }
-    };
-    auto fold = [&](bool negated) {
-        if (negated) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] -= pipe[i][j];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] += pipe[i][j];
-        }
-    };
-    // Sign phases (K17): here a whole channel block -- one patch -- carries one sign, and a pass of the loop (three K-steps) is folded with the sign of
-    // the block its steps belong to.
-    // K position of the step being computed
-    int tap = 0, cb = 0, buf = 0, shift = -halo;                // shift of tap (0, 0): (0 - pad) * W + (0 - pad)
-    int tdw = 0;
-    bool xl_prev = false;
-    auto step = [&](int kt, auto ST, auto FIRST) {
-        constexpr int st = decltype(ST)::value, st2 = (st + 2) % 3;
-        // the next block's patch, spread over this block's first steps: tap 0 loads task 0, tap 2 splits it and loads task 1, tap 4 splits that.  The
-        // split comes BEFORE this step's W DMA: the wait for its X registers then leaves at most the previous step's DMA in flight
-        const bool more = cb + 1 < ncb;
-        bool xl_now = false;
-        const unsigned flip_next = ((cb + 1) & 1) ? 0x80008000u : 0u;
-        if (more && tap == 2) store_patch(buf ^ 1, 0, flip_next);
-        if (more && tap == 4) store_patch(buf ^ 1, 1, flip_next);
-        load_w(kt + 2, st2);
-        if (more && tap == 0) { load_patch(cb + 1, 0); xl_now = true; }
-        if (more && tap == 2) { load_patch(cb + 1, 1); xl_now = true; }
-        const unsigned char* As = a_lane + st * SP_A_BYTES;
-        v8bf af[3][2], bf[3][2];
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[pc][i] = *(const v8bf*)(As + (pc * 2 * SP_T + i * 64) * 16);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pos = ((c_mask[j] >> tap) & 1u) ? c_pos[j] + shift : PL;       // a tap outside the image: the zero slot
-            const unsigned char* Bs = b_plane + buf * XB + pos * 16;
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bf[pc][j] = *(const v8bf*)(Bs + pc * 2 * PS);
-        }
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
-        v16f zero;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    pipe[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], (t == 0 && decltype(FIRST)::value) ? zero : pipe[i][j], 0, 0, 0);
-        // W(kt + 1) (issued during step kt - 1) has landed when at most W(kt + 2) and the patch loads issued since are outstanding: 3, + 8 per patch load
-        // of this step or the last one (both sit behind W(kt + 1) in the queue)
-        if (xl_now || xl_prev) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        xl_prev = xl_now;
-        // next K position
-        tap += 1; tdw += 1; shift += 1;
-        if (tdw == p.kw) { tdw = 0; shift += p.W - p.kw; }
-        if (tap == T) { tap = 0; shift = -halo; cb += 1; buf ^= 1; }
-    };
-
-    // ---- fill: zero slots, the patch of block 0, W(0), W(1)
-    if (tid < 12) {
-        const v4u z = {0u, 0u, 0u, 0u};
-        asm volatile("ds_write_b128 %0, %1" :: "v"(lds_base + XBASE + (tid / 6) * XB + (tid % 6) * PS + PL * 16), "v"(z));
-    }
-    load_w(0, 0);
-    load_patch(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_patch(0, 0, 0u);
-    load_patch(0, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_patch(0, 1, 0u);
-    load_w(1, 1);
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // W(0) and the patch of block 0 are in LDS
-    stamp(p, wave, lane, 1);
-    std::integral_constant<int, 0> S0; std::integral_constant<int, 1> S1; std::integral_constant<int, 2> S2;
-    std::integral_constant<bool, true> first;
-    for (int kt = 0; kt < nk; kt += 3) {          // up to two steps past the end multiply zeros (their W stages are zero-filled)
-        // a pass's three steps start from C = 0; T % 3 == 0 (split_patch_ok) keeps a pass inside one channel block, whose sign it is folded with
-        const bool negated = (cb & 1) != 0;
-        std::integral_constant<bool, false> later;
-        step(kt, S0, first);
-        step(kt + 1, S1, later);
-        step(kt + 2, S2, later);
-        fold(negated);
-    }
-    wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stamp(p, wave, lane, 2);
-    stamp(p, wave, lane, 3);
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        v16f t[1][1];
-        t[0][0] = acc[0][0];
-        block_epilogue<CHAIN, true>(p, t, smem, tid, lane, wave, co0 + (q >> 1) * 64, m0 + (q & 1) * 64, half, -1, 0, 1, osel, bsel, nullptr);
-        acc[0][0] = acc[0][1];
-        acc[0][1] = acc[1][0];
-        acc[1][0] = acc[1][1];
-    }
-    stamp(p, wave, lane, 4);
+    if (wave8 < 4) stamp(p, wave8, lane, 4);
 }
 
 // W[k][ldw] fp32 (k rows, output channel = column) -> bf16 planes [cout / 128][K step][piece][k half][128][8].  taps == 1: the K steps in the pack's row
-// order (K17).  taps > 1 (K17b): the pack's rows are tap-major (k = tap * Cin + ci); step = (ci / 16) * taps + tap -- a channel block's taps side by side.
+// order (X mode 1).  taps > 1 (X mode 2, the patch): the pack's rows are tap-major (k = tap * Cin + ci); step = (ci / 16) * taps + tap -- a channel block's taps side by side.
 __global__ void split_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ planes, int K, int cout, int ldw, int taps)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,7 +403,7 @@ __global__ void split_pack_kernel(const float* __restrict__ w, uint16_t* __restr
 }
 
 // ---- the bf16x6 kernel's host side: a registry of split packs (fp32 pack pointer -> bf16 planes), filled by the engine for the layers it covers
-struct SplitPack { uint16_t* planes; int K, cout, ldw, taps; };      // taps: 1 = K steps in pack order (K17), kh * kw = channel-block-major (K17b)
+struct SplitPack { uint16_t* planes; int K, cout, ldw, taps; };      // taps: 1 = K steps in pack order (slab), kh * kw = channel-block-major (patch)
 static std::mutex g_split_mu;
 static std::unordered_map<const float*, SplitPack> g_split;
 
@@ -529,13 +448,13 @@ bool split_grid_ok(const ConvParams& p)
 
 static std::atomic<long> g_split_launches{0};
 
-// the layers K17b takes from K17: "same" KxK convolutions (output map = input map) with 5 .. 25 taps whose halo fits the patch
+// the layers that stage X as a patch: "same" KxK convolutions (output map = input map) with 5 .. 25 taps whose halo fits the patch
 bool split_patch_ok(const ConvParams& p)
 {
     const int T = p.kh * p.kw;
     if (T < 5 || T > SPP_MAX_TAPS || (T % 3) != 0 || p.stride != 1 || p.tap_major != 1) return false;        // (T % 3: a pass of three K-steps stays inside one channel block)
     if (p.OH != p.H || p.OW != p.W || 2 * p.pad != p.kh - 1 || 2 * p.pad != p.kw - 1) return false;
-    static const bool off = getenv("XFR_SPLIT_NO_PATCH") != nullptr;          // A/B runs: K17 for every covered layer
+    static const bool off = getenv("XFR_SPLIT_NO_PATCH") != nullptr;          // A/B runs: the slab for every covered layer
     return spp_halo(p) <= SPP_MAX_HALO && !off;
 }
 
@@ -564,19 +483,20 @@ const uint16_t* split_planes(const float* w, int K, int cout, int ldw, int taps,
 template <bool RELU, int CHAIN>
 void launch_split_inst(const ConvParams& q, const uint16_t* w0, const uint16_t* w1, int n_co, int n_m, hipStream_t s, bool patch)
 {
-    // once per instantiation AND device: the kernels' dynamic LDS (72 KB; K17b: 36 KB + two patches) exceeds the default limit
+    // once per instantiation AND device: the kernels' dynamic LDS (72 KB; patch: 36 KB + two patches) exceeds the default limit
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
+    constexpr int PATCH_LDS_MAX = 3 * SP_A_BYTES + 2 * 6 * (SP_T + 2 * SPP_MAX_HALO + 1) * 16;
     if (!(done.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<RELU, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_gemm_split_patch_kernel<RELU, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  3 * SP_A_BYTES + 2 * 6 * (SP_T + 2 * SPP_MAX_HALO + 1) * 16);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<RELU, CHAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<RELU, CHAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PATCH_LDS_MAX);
         done.fetch_or(bit);
     }
-    if (patch) hipLaunchKernelGGL((conv_gemm_split_patch_kernel<RELU, CHAIN>), dim3(n_co * n_m), dim3(NT), spp_lds_bytes(q), s, q, w0, w1, n_co, n_m);
-    else hipLaunchKernelGGL((conv_gemm_split_kernel<RELU, CHAIN>), dim3(n_co * n_m), dim3(NT), SP_LDS, s, q, w0, w1, n_co, n_m);
+    const dim3 grid(n_co * n_m);
+    if (patch) hipLaunchKernelGGL((conv_gemm_split_kernel<RELU, CHAIN, true>), grid, dim3(NT8), spp_lds_bytes(q), s, q, w0, w1, n_co, n_m);
+    else hipLaunchKernelGGL((conv_gemm_split_kernel<RELU, CHAIN, false>), grid, dim3(NT8), SP_LDS, s, q, w0, w1, n_co, n_m);
 }
 
 // false: the launch is not one the split kernel covers (or its pack is not registered) -- the caller takes the fp32 kernel the rules give
