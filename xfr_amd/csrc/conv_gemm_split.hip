@@ -32,11 +32,14 @@ namespace {
 //
 // Why eight waves (round 6; profiles/r6/experiments/).  Round 5's kernel ran the tile on four waves, one per SIMD, and that wave issued its DMA (~150
 // cycles per instruction in a busy step), waited for its fragment reads and then fed 24 MFMAs, one thing after the other: ~1900 cycles per K-step for 768
-// cycles of matrix pipe.  Two ways out were built and measured: (a) K-steps alternating between two four-wave groups in a compute / load ping-pong with
+// cycles of matrix pipe.  Three ways out were built and measured: (a) K-steps alternating between two four-wave groups in a compute / load ping-pong with
 // stream-K grids -- the loading group becomes the bottleneck (2300 cycles per step: DMA and load issue, the split's VALU work under the partner's MFMAs),
-// the workgroup owns a whole CU (256 registers x 8 waves) and the timed three-stream step LOST 13 %; (b) this kernel -- the same tile cut among eight
-// waves of ~125 registers, i.e. the register space the four waves took, so other streams' launches still share the CU: the deep-K 1x1 layers +21 % in
-// isolation, the step +1 %.
+// the workgroup owns a whole CU (256 registers x 8 waves) and the timed three-stream step LOST 13 %; (b) the same tile cut among eight waves of ~125
+// registers, all in the same instruction order: the deep-K 1x1 layers +21 % in isolation, the 3x3 layers level (the two waves of a SIMD run in
+// lock-step between the barriers and wait for LDS together), the step +1 % -- this is the slab mode below; (c) patch mode: the eight waves hold the
+// fragments of step kt in registers while they read those of step kt + 1, and the two waves of a SIMD take the two halves of a step in opposite order
+// (waves 0-3: MFMAs first; waves 4-7: DMA and fragment reads first): the stage-3 3x3 layer 119 -> 142 TFLOP/s-equivalent in isolation at ~200 registers
+// per wave, the timed step level (what one launch gains it takes from the launches that shared its CUs).
 //
 // X, mode 1 -- the slab (1x1 and general tap-major layers): per K-step the 512 lanes gather a 16 x 128 slab three steps ahead into registers (the
 // tap-major gather of K2: per-lane shifted offset per filter tap, channels as the scalar offset, padding / m tails / steps past the end out of the
@@ -244,57 +247,82 @@ __global__ __launch_bounds__(NT8, 2) void conv_gemm_split_kernel(const ConvParam
                 asm volatile("ds_write_b128 %0, %1" :: "v"(at + 4 * PS), "v"(q2));
             }
         };
+        // Software pipeline, two roles.  A wave holds the fragments of step kt in registers while it reads those of step kt + 1; the two waves that share
+        // a SIMD (wave8 and wave8 + 4) run the two halves of a step in opposite order -- waves 0-3: MFMAs, then the load part; waves 4-7: the load part,
+        // then MFMAs -- so that on every SIMD one wave's DMA issue and LDS latency sit under the other wave's MFMAs.  (All eight in the same order -- the
+        // first cut of this kernel -- run in lock-step between the barriers and wait for LDS together: no faster than four waves.)
+        // Position of the step whose fragments are read NEXT (kt + 1): filter tap, channel block, patch buffer, the tap's shift
         int tap = 0, cb = 0, buf = 0, shift = -halo, tdw = 0;
-        bool xl_prev = false;
-        int wst = 0;                                  // W stage of the step being computed: kt % NST
-        auto step = [&](int kt, auto FIRST) {
-            const int st = wst, stD = wst + D >= NST ? wst + D - NST : wst + D;
+        bool xl_prev = false, xl_now = false;
+        const bool mfma_first = wave8 < 4;
+        // the load part of step kt: DMA of W(kt + 3), the next block's patch (loaded at tap 0 of the position above, split and stored at tap 2 -- BEFORE
+        // the DMA, so that the wait for its X registers leaves at most the previous step's DMA in flight), fragments of step kt + 1
+        auto load_part = [&](int kt, v8bf (&af)[3], v8bf (&bf)[3][2]) {
+            const int st1 = (kt + 1) % 3, st3 = kt % 3;          // (kt >= -1: the prologue calls this with kt = -1, st3 = 2)
             const bool more = cb + 1 < ncb;
-            bool xl_now = false;
-            // the next block's patch: loaded at tap 0, split and stored at tap 2 -- BEFORE this step's DMA, so that the wait for its X registers leaves at most
-            // the previous step's DMA in flight
+            xl_now = false;
             if (more && tap == 2) store_patch(buf ^ 1, ((cb + 1) & 1) ? 0x80008000u : 0u);
-            load_w(kt + D, stD);
+            load_w(kt + 3, kt < 0 ? 2 : st3);
             if (more && tap == 0) { load_patch(cb + 1); xl_now = true; }
-            const unsigned char* As = a_lane + st * SP_A_BYTES;
-            v8bf af[3], bf[3][2];
+            const unsigned char* As = a_lane + (kt < 0 ? 0 : st1) * SP_A_BYTES;
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) af[pc] = *(const v8bf*)(As + pc * 2 * SP_T * 16);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int pos = ((c_mask[j] >> tap) & 1u) ? c_pos[j] + shift : PL;
+                const int pos = ((c_mask[j] >> tap) & 1u) ? c_pos[j] + shift : PL;       // a tap outside the image: the zero slot
                 const unsigned char* Bs = b_plane + buf * XB + pos * 16;
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) bf[pc][j] = *(const v8bf*)(Bs + pc * 2 * PS);
             }
-            mfmas(af, bf, FIRST);
-            // W(kt + 1) has landed when at most the DMA of steps kt + 2 .. kt + D -- and the patch loads of this step or the last one -- are outstanding
-            if (xl_now || xl_prev) { if (two_dma) sp8_wait_barrier<2 * (D - 1) + 8>(); else sp8_wait_barrier<(D - 1) + 8>(); }
-            else { if (two_dma) sp8_wait_barrier<2 * (D - 1)>(); else sp8_wait_barrier<(D - 1)>(); }
-            xl_prev = xl_now;
-            wst = wst + 1 == NST ? 0 : wst + 1;
             tap += 1; tdw += 1; shift += 1;
             if (tdw == p.kw) { tdw = 0; shift += p.W - p.kw; }
             if (tap == T) { tap = 0; shift = -halo; cb += 1; buf ^= 1; }
+        };
+        // W(kt + 2) -- read during the next step -- has landed when at most this step's DMA and the patch loads of this step or the last one are outstanding
+        auto end_step = [&]() {
+            if (xl_now || xl_prev) { if (two_dma) sp8_wait_barrier<10>(); else sp8_wait_barrier<9>(); }
+            else { if (two_dma) sp8_wait_barrier<2>(); else sp8_wait_barrier<1>(); }
+            xl_prev = xl_now;
+        };
+        auto step = [&](int kt, v8bf (&caf)[3], v8bf (&cbf)[3][2], v8bf (&naf)[3], v8bf (&nbf)[3][2], auto FIRST) {
+            // (one copy of the load part, the MFMA block on either side of it: two whole-step branches made the compiler keep three accumulator sets)
+            if (mfma_first) mfmas(caf, cbf, FIRST);
+            __builtin_amdgcn_sched_barrier(0);
+            load_part(kt, naf, nbf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!mfma_first) mfmas(caf, cbf, FIRST);
+            end_step();
         };
         if (tid < 12) {
             const v4u z = {0u, 0u, 0u, 0u};
             asm volatile("ds_write_b128 %0, %1" :: "v"(lds_base + XBASE + (tid / 6) * XB + (tid % 6) * PS + PL * 16), "v"(z));
         }
         load_w(0, 0);
+        load_w(1, 1);
         load_patch(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         store_patch(0, 0u);
-#pragma unroll
-        for (int d = 1; d < D; ++d) load_w(d, d);
-        if (two_dma) sp8_wait_barrier<2 * (D - 1)>(); else sp8_wait_barrier<(D - 1)>();
+        sp8_wait_barrier<0>();                       // W(0), W(1), the patch of block 0 and the zero slots are in LDS
+        v8bf f0a[3], f0b[3][2], f1a[3], f1b[3][2];
+        load_part(-1, f0a, f0b);                     // W(2); fragments of step 0
+        end_step();
         if (wave8 < 4) stamp(p, wave8, lane, 1);
-        for (int kt = 0; kt < nk; kt += 3) {
-            const bool negated = (cb & 1) != 0;
-            step(kt, first);
-            step(kt + 1, later);
-            step(kt + 2, later);
-            fold(negated);
+        int pass_in_blk = 0;
+        bool neg = false;                            // sign of the channel block the pass being COMPUTED belongs to
+        const int passes_per_blk = T / 3;
+        auto pass_done = [&]() {
+            fold(neg);
+            if (++pass_in_blk == passes_per_blk) { pass_in_blk = 0; neg = !neg; }
+        };
+        for (int kt = 0; kt < nk; kt += 6) {         // up to five steps past the end multiply zeros (their W stages are zero-filled)
+            step(kt, f0a, f0b, f1a, f1b, first);
+            step(kt + 1, f1a, f1b, f0a, f0b, later);
+            step(kt + 2, f0a, f0b, f1a, f1b, later);
+            pass_done();
+            step(kt + 3, f1a, f1b, f0a, f0b, first);
+            step(kt + 4, f0a, f0b, f1a, f1b, later);
+            step(kt + 5, f1a, f1b, f0a, f0b, later);
+            pass_done();
         }
     } else {
         int ld_tap = 0, ld_ci0 = 0;
