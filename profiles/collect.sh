@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect one round's rocprofv3 evidence for bench.py on the GPU box (run from the repo root, e.g. through gpurun):
-#   bash profiles/collect.sh r5      -> gpurun_out/prof_r5/..., summaries copied to profiles/r5/
+#   bash profiles/collect.sh r6      -> gpurun_out/prof_r6/..., summaries copied to profiles/r6/
 # Counters are collected in their own passes (--pmc never together with a trace domain other than the kernel trace).
 # Every BASELINE.json single-GPU configuration gets the same set: resnet101 (no suffix), resnet50_128 (_r50), lightcnn (_lcnn).
 set -u
-R=${1:-r5}
+R=${1:-r6}
 D=gpurun_out/prof_$R
 P=profiles/$R
 export TMPDIR=/tmp
@@ -73,12 +73,16 @@ python profiles/frac_from_launch_log.py $P/launch_log_r50.csv --alg-gflop 2961.4
 for rep in 1 2; do for m in resnet101 resnet50_128; do for f in "" "--no-lean"; do
   python bench.py --model $m $f --no-cpu-baseline --no-secondary --no-sustained --no-profile --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m [$f]', round(d['value'],1), 'maps/s', round(d['ms_per_step'],3), 'ms')"
 done; done; done > $P/lean_ab.txt
-# bf16x6 modes (xfr_engine_set_split_gemm; 1 = the default: forward convolutions) on this box, alternating; GEMM error of the kernels against float64
-for rep in 1 2; do for m in resnet101 resnet50_128; do for f in "--split-gemm 0" "" "--split-gemm 3"; do
+# bf16x6 modes (xfr_engine_set_split_gemm; 3 = the default since round 6: forward convolutions and backward-data GEMMs) on this box, alternating; GEMM
+# error of the kernels against float64
+for rep in 1 2; do for m in resnet101 resnet50_128; do for f in "--split-gemm 0" "--split-gemm 1" ""; do
   python bench.py --model $m $f --no-split-leg --no-cpu-baseline --no-secondary --no-sustained --no-profile --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m [$f]', round(d['value'],1), 'maps/s', round(d['ms_per_step'],3), 'ms', 'outputs_ok', d['outputs_ok'], '1-cos(row 0)', 1-d['row0_cosine_vs_reference'])"
 done; done; done > $P/split_gemm_ab.txt
-python tools/conv_error_probe.py 2> /dev/null | grep -v amdgpu > $P/conv_error_probe.txt
-python tools/conv_sweep.py --cfgs 7,4,9 --reps 200 --only 0,1,3,10 2> /dev/null | grep -v amdgpu > $P/conv_sweep_bf16x6.txt
+python tools/conv_error_probe.py --extra 2> /dev/null | grep -v amdgpu > $P/conv_error_probe.txt
+python tools/conv_sweep.py --cfgs 7,4,9 --reps 200 --only 0,1,3,4,10 2> /dev/null | grep -v amdgpu > $P/conv_sweep_bf16x6.txt
+python tools/conv_sweep.py --cfgs 7,4,9 --reps 200 --only 0,1,3,4 --nb 32 2> /dev/null | grep -v amdgpu >> $P/conv_sweep_bf16x6.txt
+python tools/conv_sweep.py --cfgs 7,4,9 --reps 200 --only 0,1,3,4 --nb 8 2> /dev/null | grep -v amdgpu >> $P/conv_sweep_bf16x6.txt
+python tools/mean_ebp_probe.py 2> /dev/null | grep -v amdgpu > $P/mean_ebp_probe.txt
 python bench.py --inpainting-game > $P/bench_inpainting_game.json 2> /dev/null
 python tools/subtree_probe.py --log 2> /dev/null | grep -v amdgpu > $P/weighted_subtree_probe.txt
 rocprofv3 $ST -d $D/subtree -o $R -- python tools/subtree_probe.py --reps 5 > /dev/null 2> $D/subtree.err
