@@ -39,7 +39,9 @@ namespace {
 // lock-step between the barriers and wait for LDS together), the step +1 % -- this is the slab mode below; (c) patch mode: the eight waves hold the
 // fragments of step kt in registers while they read those of step kt + 1, and the two waves of a SIMD take the two halves of a step in opposite order
 // (waves 0-3: MFMAs first; waves 4-7: DMA and fragment reads first): the stage-3 3x3 layer 119 -> 142 TFLOP/s-equivalent in isolation at ~200 registers
-// per wave, the timed step level (what one launch gains it takes from the launches that shared its CUs).
+// per wave, the timed step level (what one launch gains it takes from the launches that shared its CUs).  The same pipeline in slab mode needs ~250
+// registers (two X register sets beside the two fragment sets): 1024 -> 256 at 110 TFLOP/s-equivalent where the lock-step waves hold 119-121, the step
+// -3 % (slab_pipelined_step.txt) -- the slab stays in lock-step.
 //
 // X, mode 1 -- the slab (1x1 and general tap-major layers): per K-step the 512 lanes gather a 16 x 128 slab three steps ahead into registers (the
 // tap-major gather of K2: per-lane shifted offset per filter tap, channels as the scalar offset, padding / m tails / steps past the end out of the
