@@ -37,6 +37,9 @@ def main():
                          'through the reference-shaped callers')
     ap.add_argument('--max-batch', type=int, default=0, help='engine batch capacity (default 32, or 16 * group in group mode: 32 layerwise sweeps per probe and round)')
     ap.add_argument('--phases', action='store_true', help='group mode: time every method separately (adds device synchronisations)')
+    ap.add_argument('--workers', type=int, default=1,
+                    help='group mode: job groups in flight per GPU -- that many engines, each on its own host thread and stream; a second one fills the launch '
+                         'gaps and host synchronisation points of the first (bench.py: 82 -> 121 jobs/s; an engine for 128 images is ~95 GB of workspace)')
     ap.add_argument('--numpy-inputs', action='store_true', help='uint8 H x W x 3 images through convert_from_numpy (PIL) per call, like the reference')
     args = ap.parse_args()
     import numpy as np
@@ -65,6 +68,18 @@ def main():
         return synth.synth_state_dict(bb, seed=0)
     shard.load_and_broadcast(wbn._engine, make_sd, src=0)     # one load, one broadcast
     wbn._engine.loaded_version = bb.version
+    # further workers of this rank (group mode): their own engine and stream, the arena copied on the device from the first one's
+    wbs, streams = [wb], [torch.cuda.Stream(device=dev)]
+    for _ in range(1, max(1, args.workers) if args.group > 1 else 1):
+        wn = WB.WhiteboxSTResnet(bb)
+        wbs.append(WB.Whitebox(wn, ebp_subtree_mode='norelu'))
+        wn._program = wbn._program
+        wn._engine = Engine(wn._program, wbn._engine.max_batch, dev)
+        wn._engine_key = wbn._engine_key
+        wn._engine.weight_arena().copy_(wbn._engine.weight_arena())
+        wn._engine.mark_weights_loaded()
+        wn._engine.loaded_version = bb.version
+        streams.append(torch.cuda.Stream(device=dev))
 
     lo, hi = shard.shard_range(args.jobs, rank, world)
     k = args.mates
@@ -91,7 +106,11 @@ def main():
     phase = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for g0 in range(lo, hi if args.group > 1 else lo, args.group):
+    import threading
+    lock = threading.Lock()
+    counts = {'written': 0, 'done': 0, 't': 0.0}
+
+    def run_group(w, g0):
         # group mode: the jobs [g0, g1) whose outputs are not all on disk yet run as ONE batch through every method
         g1 = min(hi, g0 + args.group)
         todo = []
@@ -101,22 +120,52 @@ def main():
                                                                 for nm in names.values())
             if missing:
                 todo.append((job, odir))
+        wr, dt_g = 0, 0.0
         if todo:
             jobs = []
             for job, _ in todo:
                 imgs = pool[job % len(pool)]
                 jobs.append((list(imgs[1:1 + k]), list(imgs[1 + k:]), imgs[0]))
             t1 = time.perf_counter()
-            res = IG.run_jobs_batched(wb, jobs, 'resnetv4_pytorch', 'norelu', 6, dev, topk=args.topk, timings=phase if args.phases else None)
-            torch.cuda.synchronize()
-            t_methods[3] += time.perf_counter() - t1            # group mode reports the per-job total in the last slot
+            res = IG.run_jobs_batched(wbs[w], jobs, 'resnetv4_pytorch', 'norelu', 6, dev, topk=args.topk,
+                                      timings=phase if (args.phases and len(wbs) == 1) else None)
+            torch.cuda.current_stream(dev).synchronize()
+            dt_g = time.perf_counter() - t1
             for i, (job, odir) in enumerate(todo):
                 for key, nm in names.items():
                     m = np.asarray(res[key][i])
                     assert m.shape == (112, 112) and np.isfinite(m).all() and abs(float(m.sum()) - 1.0) < 1e-3
                     if odir:
-                        written += int(SIO.create_save_smap(nm, odir, True, lambda m=m: m, '%05d' % job, displayable(jobs[i][2])))
-        done += g1 - g0
+                        wr += int(SIO.create_save_smap(nm, odir, True, lambda m=m: m, '%05d' % job, displayable(jobs[i][2])))
+        with lock:
+            counts['written'] += wr
+            counts['done'] += g1 - g0
+            counts['t'] += dt_g
+
+    groups = list(range(lo, hi if args.group > 1 else lo, args.group))
+    if len(wbs) == 1:
+        for g0 in groups:
+            run_group(0, g0)
+    else:
+        errs = []
+
+        def body(w):
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(streams[w]):
+                    for g0 in groups[w::len(wbs)]:
+                        run_group(w, g0)
+            except BaseException as ex:      # noqa: BLE001
+                errs.append(ex)
+        ts = [threading.Thread(target=body, args=(w,)) for w in range(len(wbs))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+    done += counts['done']
+    written += counts['written']
+    t_methods[3] += counts['t']            # group mode reports the per-job total in the last slot (summed over the workers)
     for job in range(lo, hi if args.group <= 1 else lo):
         imgs = pool[job % len(pool)]
         probe, mates, nonmates = imgs[0], list(imgs[1:1 + k]), list(imgs[1 + k:])
@@ -171,7 +220,7 @@ def main():
     if rank == 0:
         per = (t_methods / max(done, 1) * 1e3).round(1).tolist()
         print(json.dumps({'workload': 'inpainting-game whitebox saliency generation shape, ResNet-101, synthetic', 'jobs': total,
-                          'n_gpus': world, 'seconds': dt, 'jobs_per_s': total / dt, 'group': args.group,
+                          'n_gpus': world, 'seconds': dt, 'jobs_per_s': total / dt, 'group': args.group, 'workers': len(wbs),
                           'ms_per_job_by_phase_rank0': {k_: round(1e3 * v / max(done, 1), 2) for k_, v in phase.items()} or None,
                           'ms_per_job_rank0': {'meanEBP': per[0], 'contrastive(+%d encodes)' % (2 * k): per[1], 'truncated': per[2],
                                                'weighted_subtree_top%d' % args.topk: per[3]},
