@@ -316,7 +316,7 @@ xfr_status xfr_debug_u8_preprocess(xfr_engine* e, const uint8_t* x_u8_dev, int32
  * always run literal, so a sample's map can differ in its last digits between a batch of 32 and a batch of 1: callers that need batch-invariant
  * arithmetic switch this off together with xfr_engine_set_tail_balance. */
 xfr_status xfr_engine_set_lean(xfr_engine* e, int32_t enable);
-/* bf16x6 GEMMs (ABI version 5).  The deep-K stride-1 convolutions of 14 x 14 and larger maps (K >= 512 for 1x1, K >= 1152 for KxK, 128 | Cout) can run
+/* bf16x6 GEMMs (ABI version 5).  The deep-K stride-1 convolutions of 14 x 14 and larger maps (K >= 256 for 1x1, K >= 1152 for KxK, 128 | Cout) can run
  * on the bf16 matrix pipe: every fp32 operand is the exact sum of three bf16 pieces, the six piece products of order <= 2 are exact and are accumulated in
  * fp32 (conv_gemm_split.hip K17).  Since round 6 no sum stays in the matrix pipe for more than three K-steps (48 of the K terms): the partial sums are
  * added to fp32 registers with round-to-nearest adds and alternate in sign, and a launch's error against float64 is BELOW the fp32 MFMA kernels'

@@ -451,8 +451,10 @@ const SplitPolicy& split_policy()
 {
     // A/B runs only (tools/ab_env.sh): XFR_SPLIT_MIN_K1 / _K3 = the shallowest 1x1 / KxK layer, XFR_SPLIT_MIN_TILES = the smallest grid
     static const SplitPolicy pol = [] {
-        SplitPolicy q{512, 1152, 128};     // round 6, same box, alternating: 1x1 from K = 512 +0.5 % (ResNet-101) / +1 % (ResNet-50-128d) over K >= 1024;
-                                           // from K = 256 the same, from K = 128 a loss; KxK from K = 576 and grids from 64 / 196 tiles: level
+        SplitPolicy q{256, 1152, 128};     // round 6, same box, alternating: 1x1 from K = 512 +0.5 % (ResNet-101) / +1 % (ResNet-50-128d) over K >= 1024; from
+                                           // K = 256 level with that in time (final kernel: 1535 / 2490 against 1532 / 2499 maps/s) and closer to the reference
+                                           // (the kernel's sums are more accurate than the fp32 MFMA kernels': row-0 1 - cosine 1.1e-6 against 4.9e-6); from
+                                           // K = 128 a loss; KxK from K = 576 and grids from 64 / 196 tiles: level
         if (const char* e = getenv("XFR_SPLIT_MIN_K1")) q.min_k1 = atoi(e);
         if (const char* e = getenv("XFR_SPLIT_MIN_K3")) q.min_k3 = atoi(e);
         if (const char* e = getenv("XFR_SPLIT_MIN_TILES")) q.min_tiles = atoi(e);
