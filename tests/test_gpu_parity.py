@@ -256,9 +256,10 @@ def test_golden_contrastive_cases_on_the_lean_schedule(gpu_device, arch, mode):
 
 @pytest.mark.parametrize('arch,mode', [('stresnet101', 'affineonly_with_prior'), ('stresnet101', 'norelu'), ('resnet50_128', 'norelu')])
 def test_golden_cases_on_the_split_gemm(gpu_device, arch, mode):
-    """xfr_engine_set_split_gemm(3): forward convolutions AND the sweep's backward-data GEMMs of the deep-K layers on the bf16 matrix pipe (bf16x6,
-    conv_gemm.hip K17; the default, mode 1, covers the forward convolutions only and is what every other golden test runs).  The golden cases of the
-    ResNets once more in that experimental mode -- same vectors from the real reference, same tolerances; the kernel's launches are counted."""
+    """xfr_engine_set_split_gemm(3 + 4): forward convolutions AND the sweep's backward-data GEMMs of the covered layers on the bf16 matrix pipe (bf16x6,
+    conv_gemm_split.hip K17) -- the default mode since round 6, here for EVERY grid (+ 4): these replays run batches of one and four, whose launches the
+    default grid rule leaves on the fp32 kernels.  The golden cases of the ResNets -- same vectors from the real reference, same tolerances; the kernel's
+    launches are counted."""
     if arch == 'stresnet101':
         gold, cases = GC.golden('golden_r101'), GC.r101_cases(mode)
         bb, sd = make_backbone(arch, seed=0, num_classes=65359)
@@ -285,11 +286,11 @@ def test_golden_cases_on_the_split_gemm(gpu_device, arch, mode):
 
 @pytest.mark.parametrize('arch,mode', [('stresnet101', 'affineonly_with_prior'), ('resnet50_128', 'norelu')])
 def test_split_gemm_equals_fp32_kernels(gpu_device, arch, mode):
-    """The bf16x6 kernel (mode 1: forward convolutions, the default; mode 3: backward-data GEMMs too) against the fp32 MFMA kernels (mode 0) on the same
-    engine, same inputs: every fp32 operand is the exact sum of three bf16 pieces and
-    the six piece products of order <= 2 are exact in fp32; what differs is the bf16 MFMA's own summation (rms error against float64 1.5-3x the fp32
-    kernels', tools/conv_error_probe.py; its one-sided part is cancelled by the kernel's sign phases).  Encodings 1e-5, plain-EBP maps 5e-5 of the
-    maximum (measured 5e-7 .. 2e-5), contrastive maps (a difference of nearly equal tensors: parity_utils) LEAN_RTOL_CONTRAST (measured 5e-6 .. 1.5e-3)."""
+    """The bf16x6 kernel (mode 1: forward convolutions; mode 3, the default: backward-data GEMMs too; both + 4 = every grid) against the fp32 MFMA kernels
+    (mode 0) on the same engine, same inputs: every fp32 operand is the exact sum of three bf16 pieces, the six piece products of order <= 2 are exact in
+    fp32 and partial sums of 48 K-terms are folded into fp32 registers; what differs is the summation order (rms error against float64 BELOW the fp32
+    kernels', tools/conv_error_probe.py).  Encodings 1e-5, plain-EBP maps 5e-5 of the maximum, contrastive maps (a difference of nearly equal tensors:
+    parity_utils) LEAN_RTOL_CONTRAST."""
     n = 4
     bb, sd = make_backbone(arch, seed=6, num_classes=None if arch == 'resnet50_128' else 7)
     subj = GC.engine_subject(arch, bb, mode)

@@ -1,4 +1,4 @@
-"""The arithmetic the bf16x6 kernel (conv_gemm.hip K17) rests on, restated with torch on the CPU: the nearest-rounding three-way split of an fp32 value is
+"""The arithmetic the bf16x6 kernel (conv_gemm_split.hip K17) rests on, restated with torch on the CPU: the nearest-rounding three-way split of an fp32 value is
 EXACT, every piece is at most half a bf16 ulp of the one before, piece products are exact in fp32, and the six products of order <= 2 reproduce the fp32
 product to ~2^-24 (the three dropped ones are ~2^-25).  tests/precision/split_probe.py runs whole networks through the same emulation."""
 import numpy as np

@@ -2,7 +2,7 @@
 //
 // The product's GEMMs run v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak, 1/16 of the bf16 rate) at 0.72-0.8 of that peak: the only lever left past it is
 // to feed the bf16 pipe with SPLIT operands.  An fp32 value is exactly the sum of three bf16 pieces (8 + 8 + 8 significant bits; the "deep" variant and the
-// host-side weight split round every piece to nearest like the product kernel, conv_gemm.hip K17; the first-cut and direct-B variants still truncate, which
+// host-side weight split round every piece to nearest like the product kernel, conv_gemm_split.hip K17; the first-cut and direct-B variants still truncate, which
 // leaves one-signed remainders), a bf16 x bf16 product is exact in fp32, and the six products with i + j <= 2 reproduce the fp32 product to ~2^-23
 // ("bf16x6": tests/precision/split_probe.py shows the maps cannot tell it from a re-ordered fp32 sum, while the three-product "bf16x3" moves the
 // contrastive maps by 2e-2).  Six v_mfma_f32_32x32x16_bf16 do the work of sixteen fp32 MFMAs in 6 x 32 instead of 8 x 64 cycles: a 2.67x ceiling.

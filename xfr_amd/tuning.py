@@ -46,7 +46,7 @@ def analyse_launch_log(csv_path, steps, flop_per_step):
     rows = [l.strip().split(',') for l in open(csv_path)][1:]
     # seq, stream, Cout, nhalves, K, M, kh, chain, cfg, start, end  (10 ns ticks)
     recs = [(int(r[0]), r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]), int(r[9]), int(r[10])) for r in rows if int(r[9]) > 0 and int(r[10]) > 0]
-    # share of the GEMM FLOPs (2 Cout nhalves K M per launch) that ran on the bf16x6 kernel (configuration 9, conv_gemm.hip K17)
+    # share of the GEMM FLOPs (2 Cout nhalves K M per launch) that ran on the bf16x6 kernel (configuration 9, conv_gemm_split.hip K17)
     fl = [(2.0 * int(r[2]) * int(r[3]) * int(r[4]) * int(r[5]), int(r[8])) for r in rows]
     split_share = sum(f for f, c in fl if c == 9) / max(sum(f for f, _ in fl), 1.0)
     split_launches = sum(1 for _, c in fl if c == 9) / float(steps + 2)
