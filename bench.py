@@ -608,7 +608,7 @@ def run_secondary(model, dev, steps, warmup, chain_before):
     return out
 
 
-def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=65359, workers=2):
+def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=65359, workers=2, engine_batch=None):
     """BASELINE.json configs[4] on ONE GPU: the job mix of the reference's inpainting-game generator on ResNet-101 (eval/
     generate_inpaintinggame_wb_saliency_maps_multigpu.py:121-231; python/xfr/inpainting_game/generate_whitebox_saliency.py:79-214) -- per job meanEBP
     over the 65359-way hooked classifier, contrastive and truncated-contrastive triplet EBP from `mates` averaged mate / non-mate encodings, and
@@ -633,7 +633,7 @@ def run_inpainting_game(dev, jobs=64, group=8, mates=4, topk=32, num_classes=653
         wbn = WB.WhiteboxSTResnet(bb)
         wbs.append(WB.Whitebox(wbn, ebp_subtree_mode='norelu'))  # eval/create_wbnet.py:51-52 default for resnetv4/v6
         wbn._program = bb.build_program()
-        wbn._engine = Engine(wbn._program, max(32, 16 * group), dev)
+        wbn._engine = Engine(wbn._program, engine_batch or max(32, 16 * group), dev)
         wbn._engine_key = (str(bb.device), id(bb))
         wbn._engine.load_weights(sd)
         wbn._engine.loaded_version = bb.version
@@ -795,6 +795,7 @@ def main():
     ap.add_argument('--fusion', type=int, default=None, help='xfr_engine_set_epilogue_fusion level (default: the library default, 3; 1 leaves BatchNorm / ReLU of the probe forward in their own kernels, 0 un-fuses everything)')
     ap.add_argument('--inpainting-game', action='store_true', help='only the BASELINE.json configs[4] job mix (one GPU): print its object and exit')
     ap.add_argument('--job-workers', type=int, default=2, help='job mix: job groups in flight (one engine, host thread and stream each)')
+    ap.add_argument('--job-engine-batch', type=int, default=None, help='job mix: batch capacity of each engine (default 16 x the group of 8 = 128: 32 layerwise sweeps per probe and round; an engine for 128 images is ~95 GB)')
     ap.add_argument('--no-split-leg', action='store_true', help='skip the two other xfr_engine_set_split_gemm modes that ride on the line (split_gemm_modes)')
     ap.add_argument('--split-gemm', type=int, default=None, help='xfr_engine_set_split_gemm(MODE): 0 fp32 MFMA kernels everywhere, 1 bf16x6 forward convolutions of the deep-K layers, 3 the backward-data GEMMs too (the default); + 4: whatever the grid')
     ap.add_argument('--no-lean', action='store_true', help='xfr_engine_set_lean(0): the literal hook operands in every sweep (A/B against the default lean schedule)')
@@ -867,7 +868,7 @@ def run(args, comm):
         raise RuntimeError('XFR_TEST_RAISE_RANK: simulated failure of rank %d' % rank)
     if args.inpainting_game:
         if rank == 0:
-            print(json.dumps(run_inpainting_game(dev, workers=args.job_workers)))
+            print(json.dumps(run_inpainting_game(dev, workers=args.job_workers, engine_batch=args.job_engine_batch)))
         comm.close()
         return
     binding = shard.bind_rank_cpus(local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))) if args.bind else None
@@ -1023,7 +1024,7 @@ def run(args, comm):
             except Exception as ex:      # the headline must still be printed
                 secondary.append({'model': m, 'error': repr(ex), 'outputs_ok': False})
         try:
-            secondary.append(run_inpainting_game(dev, workers=args.job_workers))
+            secondary.append(run_inpainting_game(dev, workers=args.job_workers, engine_batch=args.job_engine_batch))
         except Exception as ex:
             secondary.append({'model': 'resnet101 inpainting-game job mix', 'error': repr(ex), 'outputs_ok': False})
         del chain_main
