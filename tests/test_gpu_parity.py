@@ -86,6 +86,48 @@ def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
 
 
 @pytest.mark.parametrize('shape', [
+    # cin, h, w, nb, cout, k, stride, pad
+    (128, 28, 28, 3, 128, 3, 1, 1),    # patch staging, rows of 28 (halo 29), ragged M (2352 = 18 x 128 + 48), a single co tile
+    (64, 56, 56, 1, 128, 3, 1, 1),     # halo 57 of the 64 a patch may take
+    (512, 7, 7, 6, 256, 3, 1, 1),      # 7 x 7 images: a 128-column tile spans 2.6 images, most taps of a border pixel leave the image
+    (32, 12, 12, 2, 128, 5, 1, 2),     # 5 x 5: 25 taps, not a multiple of three -> a KxK layer on the slab path
+    (64, 10, 10, 3, 256, 3, 1, 0),     # a 'valid' 3 x 3 (pad 0): not a same-size layer -> slab path
+    (256, 14, 14, 64, 256, 1, 1, 0),   # 1 x 1, K = 256 (the shallowest layer the engine sends), 2 x 98 tiles
+    (16, 9, 9, 1, 128, 1, 1, 0),       # a single K step, M = 81: less than one tile
+    (48, 8, 8, 2, 384, 3, 1, 1),       # three co tiles, three channel blocks
+])
+def test_bf16x6_kernel_shapes(gpu_device, shape):
+    """conv_gemm_split_kernel (K17; cfg 9 of xfr_debug_conv runs it on every shape it CAN run, whatever the engine's depth / grid rules) at the edges of
+    its two staging modes, against float64 conv2d: the fp32 operands are split exactly, so the bar is the fp32 kernels' (2e-5 of the maximum) and the
+    kernel in fact stays far below it (asserted at 4e-6).  The launch counter proves the bf16x6 kernel ran, twice the same bits."""
+    from xfr_amd import _lib
+    from xfr_amd.engine import Engine
+    lib = _lib.load()
+    cin, h, w, nb, cout, k, stride, pad = shape
+    bb, sd = make_backbone('stresnet_mini', seed=0, num_classes=3)
+    eng = Engine(bb.build_program(), 2, gpu_device)        # (only for the process-wide launch counter's entry point)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((nb, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn((cout,), generator=g)
+    want = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad)
+    xg = x.to(gpu_device).permute(1, 0, 2, 3).contiguous()
+    outs = []
+    for reps in (1, 3):
+        out = torch.full((cout, nb) + tuple(want.shape[2:]), float('nan'), device=gpu_device)
+        ms = ctypes.c_float()
+        before = eng.split_gemm_launches()
+        _lib.check(lib.xfr_debug_conv(xg.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), cin, h, w, nb, cout, k, k,
+                                      stride, pad, 0, 9, reps, ctypes.byref(ms)))
+        assert eng.split_gemm_launches() - before == 2 * reps, 'the bf16x6 kernel did not run this shape'       # warm-up + timed launches
+        outs.append(out.permute(1, 0, 2, 3).cpu())
+    eng.close()
+    assert torch.isfinite(outs[0]).all()
+    assert float((outs[0].double() - want).abs().max()) <= 4e-6 * float(want.abs().max())
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('shape', [
     (256, 14, 14, 64, 256, 3, 1, 1),   # ResNet-101 layer 3 at 64 images: 784 tiles = 3 x 256 + 16 tail tiles
     (1024, 14, 14, 32, 256, 1, 1, 0),  # 392 tiles: 136 tail tiles, float4 operand path
     (512, 7, 7, 32, 512, 3, 1, 1),     # 200 tiles: fewer tiles than CUs
