@@ -710,7 +710,11 @@ int pick_tail_split(const ConvParams& p, int tiles, int nk, size_t tile_bytes)
 void warn_interpreted(const ConvParams& q)
 {
     static std::atomic<int> said{0};
-    if (q.chain_interpret || getenv("XFR_QUIET") || said.exchange(1)) return;
+    // (a launch whose rows are not float4-aligned -- M, or images x pixels, not a multiple of 4: stage 4 of a batch of one -- runs the interpreter BY DESIGN:
+    // the compiled epilogues load and store float4; nothing to regenerate, nothing to say)
+    const int ohw = q.OH * q.OW;
+    const bool vec_ok = (q.M & 3) == 0 && ((q.chain_B * ohw) & 3) == 0 && ((q.out_nb * ohw) & 3) == 0;
+    if (q.chain_interpret || !vec_ok || getenv("XFR_QUIET") || said.exchange(1)) return;
     uint16_t codes[XFR_MAX_EW_STEPS];
     const int n = ew_chain_codes(q.chain, codes);
     fprintf(stderr, "xfr_amd: a GEMM launch (Cout %d, K %d, M %d) runs its %d-step fused chain through the INTERPRETED epilogue: no compiled signature [", q.CoutTot, q.K, q.M, q.chain.n);
