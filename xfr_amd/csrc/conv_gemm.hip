@@ -688,7 +688,10 @@ int pick_tail_split(const ConvParams& p, int tiles, int nk, size_t tile_bytes)
     if (q >= qmax || p.K < 1024) return 1;   // many rounds: blocks are dispatched as slots free up, the last round matters little
     // Final-round cost in units of one whole tile: a CU runs ceil(r*S/C) parts of 1/S tile, each with a fixed ramp
     // (ring fill, partial store, arrival) worth ~192 K-rows.  Measured on MI355X: parts shorter
-    // than 256 K-rows cost more than they balance, and nothing is gained below K = 1024.
+    // than 256 K-rows cost more than they balance, and nothing is gained below K = 1024.  (Round 6, after the last arriver's reduction stopped
+    // serialising its loads -- conv_gemm_dev.h block_epilogue: in isolation K = 512 layers under one round now gain 28 % from four parts, but in
+    // the timed step and in a batch-1 call every variant of this rule -- K from 256 / 512, parts from 128 rows, half / twice the per-part
+    // penalty -- measured level with it: profiles/r6/experiments/tail_exchange.txt.)
     const double ramp = 192.0 / (double)p.K;
     const double whole = 1.0 + ramp;
     double best = whole;
