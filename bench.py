@@ -333,6 +333,11 @@ def make_workload(args, dev, rank, cpu_only=False, comm=None):
             W.u8_step = make_u8_step(eng, imgs, resnet.MEAN_RGB, B, enc_t, None, dev)
             g1, p1 = torch.stack((gallery[0], gallery[B])).contiguous(), probes[:1].contiguous()
             W.one = lambda: eng.triplet_contrastive(p1, g1, enc_t, 1.0 / 2500.0, None)   # noqa: E731
+
+            def step_inputs(n):        # n triplets per call, fresh (not resident-declared) inputs: tools/one_triplet_probe.py --triplets
+                gn, pn = torch.cat((gallery[:n], gallery[B:B + n])).contiguous(), probes[:n].contiguous()
+                return lambda: eng.triplet_contrastive(pn, gn, enc_t, 1.0 / 2500.0, None)
+            W.step_inputs = step_inputs
         W.flop_per_unit = 6 * F_FWD['resnet101']           # 2 encodes + true fwd + relu(W) fwd + 2 backward-data sweeps = 86.51 GFLOP
         W.metric = 'triplet-contrastive-EBP saliency maps/sec, ResNet-101 224x224'
         W.work = ('ResNet-101 triplet contrastive EBP, batch=%d synthetic 224x224 triplets per GPU (2 encodes + contrastive_ebp per '
