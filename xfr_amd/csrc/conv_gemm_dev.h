@@ -237,6 +237,10 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
         // p.chain_ld, <= 4 distinct tensors) are in flight together before the steps are interpreted: every workgroup of
         // a launch reaches its epilogue at the same time, so a chain of dependent loads here is paid in full.
         const EwLoads& ld = p.chain_ld;
+        // The interpreter indexes the chain's steps with a run-time index: on the by-value kernel argument that index sends the whole ConvParams to
+        // scratch (2 KB per lane, every step read back from there: a stage-4 launch of a one-image call took 75 us where the compiled chain takes 23).
+        // Read the steps from the kernel-argument segment itself -- ConvParams is the first argument of every GEMM kernel -- through the constant cache.
+        const EwChain& kchain = ((const ConvParams*)__builtin_amdgcn_kernarg_segment_ptr())->chain;
         // float4 pieces need rows whose length is a multiple of 4 on both sides (gradient rows of out_nb images, forward
         // rows of chain_B images); a piece may then straddle two samples (7x7 maps) but never a row
         const bool vec_ok = MI == 1 && NJ == 1 && LDS_OK && (p.M & 3) == 0 &&
@@ -285,7 +289,7 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
 #pragma unroll
                 for (int u = 0; u < 1; ++u)
                     ew_interpret<false>(ok[u], idx4[u], aidx4[u], sb, 0, g[u], od[u], v0[u], v1[u], v2[u], v3[u], out4, p.accumulate,
-                                        p.chain, cos[u], p.chain_eps);
+                                        kchain, cos[u], p.chain_eps);
             }
         } else
 #pragma unroll
@@ -335,8 +339,8 @@ __device__ __forceinline__ void block_epilogue(const ConvParams& p, v16f (&acc)[
                         g[e8] = v;
                     }
 #pragma unroll 1
-                    for (int sidx = 0; sidx < p.chain.n; ++sidx) {
-                        const EwStep& st = p.chain.s[sidx];
+                    for (int sidx = 0; sidx < kchain.n; ++sidx) {
+                        const EwStep& st = kchain.s[sidx];
                         const int type = st.type, s0 = st.ls0, s1 = st.ls1;
                         if (type == EW_HOOK) {
                             if (s0 == -2) {                      // p is not observed: relu(g) or the identity
