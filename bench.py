@@ -267,8 +267,8 @@ def one_triplet_latency(W, reps=30):
         return {'ms_median': ts[len(ts) // 2], 'ms_p90': ts[int(0.9 * (len(ts) - 1))], 'host_ms_median': th[len(th) // 2]}, s
     out, s = timed(W.one)
     out.update({'calls': reps, 'outputs_ok': bool(torch.isfinite(s).all().item()) and abs(float(s.sum().item()) - 1.0) < 1e-3,
-                'what': 'one triplet per call (2 encodes + contrastive EBP), device synchronised after each call, library defaults; host_ms = the calling '
-                        "thread's time inside the call"})
+                'what': ('one image per call (EBP over the 80013-way classifier)' if W.model == 'lightcnn' else 'one triplet per call (2 encodes + contrastive EBP)') +
+                   ", device synchronised after each call, library defaults; host_ms = the calling thread's time inside the call"})
     return out
 
 
@@ -410,6 +410,12 @@ def make_workload(args, dev, rank, cpu_only=False, comm=None):
                 _, pooled = eng.ebp(x, cls_t, seed, want_mwp=False, want_pooled=True, inputs_ready=ready)
                 return eng.mwp_to_saliency(pooled[0])
             W.step = step
+            x1, seed1 = x[:1].contiguous(), seed[:, :1].contiguous()
+
+            def one():             # one image per call, like Whitebox.ebp(img, P) (whitebox.py:490-498)
+                _, pooled = eng.ebp(x1, cls_t, seed1, want_mwp=False, want_pooled=True)
+                return eng.mwp_to_saliency(pooled[0])
+            W.one = one
         # the engine only runs the relu(W) forward where a hook divides by X ('affineonly' needs none): 2 F_fwd executed, 3 F_fwd in
         # the modes that divide by a Split's X -- the roofline uses the executed GEMM FLOPs, capped by SURVEY's 3 F_fwd
         W.flop_per_unit = 3 * F_FWD['lightcnn']
