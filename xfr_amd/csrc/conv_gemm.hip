@@ -685,6 +685,14 @@ int pick_tail_split(const ConvParams& p, int tiles, int nk, size_t tile_bytes)
         const int S = std::min(p.tail_force, nk);
         return ((long)r * S <= max_blocks) ? S : 1;
     }
+    if (q == 0 && p.K >= 8192 && p.tail_force == 0) {
+        // A few tiles with a very deep K -- the backward GEMM through a hooked classifier (K = 80013 / 65359 classes, 4-8 tiles), a Linear on a flattened
+        // map: a handful of workgroups would walk the whole weight matrix.  As many parts as fill the chip once, at least 256 K-rows each (round 6:
+        // 534 -> 99 us at one image with 64 parts instead of 8, 204 -> 60 us at eight; the exchange costs 0.6 us per part since it stopped
+        // serialising its loads).
+        const long S = std::min<long>(std::min<long>(64, p.K / 256), std::min<long>(max_blocks / r, std::max<long>(8, C / r)));
+        return (int)std::min<long>(S, nk);
+    }
     if (q >= qmax || p.K < 1024) return 1;   // many rounds: blocks are dispatched as slots free up, the last round matters little
     // Final-round cost in units of one whole tile: a CU runs ceil(r*S/C) parts of 1/S tile, each with a fixed ramp
     // (ring fill, partial store, arrival) worth ~192 K-rows.  Measured on MI355X: parts shorter
@@ -939,7 +947,9 @@ static int pick_cfg_impl(const ConvParams& p_in, bool allow_split)
     {
         const int rem = p.CoutTot % 64;
 #ifndef XFR_NO_ROW_TILE      /* A/B builds only (profiles/r4/experiments/row_tile_ab.txt) */
-        if (rem > 0 && rem <= 32 && p.tap_major != 2 && p.out_stride == 1 && p.CoutTot > 32) return 12;
+        // (more than one 64-column tile of positions: a one-image call through an 80013-way classifier has ONE column, and 2501 tiles of 32 x 128 took
+        // 183 us where the 64 x 64 tile takes 57 -- same K order, same bits)
+        if (rem > 0 && rem <= 32 && p.tap_major != 2 && p.out_stride == 1 && p.CoutTot > 32 && p.M > 64) return 12;
 #endif
     }
     if (ks_ok<8>(p)) {
