@@ -63,6 +63,8 @@ def _check_factory():
     (128, 8, 8, 2, 40, 8, 1, 0),       # Linear on a flattened 8x8 map (64 taps)
     (256, 14, 14, 5, 256, 3, 1, 1),    # layer-3 3x3: the bf16x6 kernel's gather (cfg 9), ragged M (980 = 7 x 128 + 84)
     (1024, 14, 14, 3, 128, 1, 1, 0),   # deep-K 1x1 on the bf16x6 kernel, one 128-row tile
+    (8192, 1, 1, 2, 256, 1, 1, 0),     # a few tiles over a very deep K (the backward GEMM through a hooked classifier): up to 64 K-parts (cfg 0)
+    (256, 1, 1, 1, 1037, 1, 1, 0),     # a classifier's forward for ONE image: ragged Cout (1037 = 16 x 64 + 13), one column
 ])
 @pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8, 9, 10, 12, 10004, 20004, 30005, 80004, 20006, 30008, 20012])
 def test_conv_gemm_matches_fp32_reference(gpu_device, shape, cfg):
