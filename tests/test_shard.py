@@ -126,7 +126,7 @@ class _FakeEngine(object):
 
 def _comm_worker(rank, world, port, q, scenario):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      XFR_DIST_BACKEND='gloo', XFR_DIST_TIMEOUT='30')
+                      XFR_DIST_BACKEND='gloo', XFR_DIST_TIMEOUT='60')      # (30 s were not enough once: a spawned rank's first `import torch` on a cold page cache)
     if scenario == 'fail_broadcast':
         os.environ['XFR_TEST_FAIL_BROADCAST'] = '1'
     if scenario == 'fail_init':
@@ -168,7 +168,7 @@ def test_comm_survives_a_failing_collective_backend(scenario):
     procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r['rank'])
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r['rank'])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
