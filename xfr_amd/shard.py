@@ -219,6 +219,24 @@ class Comm(object):
         return engine
 
     def close(self):
+        if self.world > 1 and self.store is not None:
+            # Check out through the store.  It lives in rank 0's process: a rank that is still leaving its last store barrier (it polls every 2 ms)
+            # finds the connection closed if rank 0 has already exited -- without a healthy collective backend nothing else orders the exits.  Rank 0
+            # waits for every rank that has not reported an exception, for at most 30 s.
+            try:
+                import time
+                self.store.add('checkout', 1)
+                if self.rank == 0:
+                    t0, tc, gone = time.time(), 0.0, 0
+                    while time.time() - t0 < min(self.timeout_s, 30.0):
+                        if time.time() - tc > 0.25:       # ranks that reported an exception never check out
+                            tc = time.time()
+                            gone = len([r for r in self.collect_errors() if r != 0])
+                        if int(self.store.add('checkout', 0)) >= self.world - gone:
+                            break
+                        time.sleep(0.002)
+            except Exception:          # noqa: BLE001 -- leaving anyway
+                pass
         if self.world > 1 and dist.is_initialized():
             try:
                 if self.collective_ok:
