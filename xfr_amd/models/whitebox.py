@@ -31,6 +31,14 @@ def _is_dataframe(obj):
     return pd is not None and isinstance(obj, pd.DataFrame)
 
 
+def _triplet_rows(x_mate, x_nonmate):
+    """The 2 x D weight of the triplet classifier, WHERE THE ENCODINGS ARE: encodings that encode() left on the device stay there -- a `.cpu()` here made
+    every demo sequence (demo/test_whitebox.py:124-133: two encodes, set_triplet_classifier, contrastive_ebp) wait twice for the device before the sweep
+    was even enqueued."""
+    a, b = torch.as_tensor(x_mate).detach().float().reshape(1, -1), torch.as_tensor(x_nonmate).detach().float().reshape(1, -1)
+    return torch.cat((a, b.to(a.device)), dim=0)
+
+
 class _TripletClassifier(object):
     """Stand-in for the nn.Linear(D, 2, bias=False) that set_triplet_classifier installs
     (whitebox.py:95-96,123-124,220).  It is created after hook registration, hence un-hooked."""
@@ -148,7 +156,7 @@ class WhiteboxSTResnet(WhiteboxNetwork):
     """whitebox.py:87-110"""
 
     def set_triplet_classifier(self, x_mate, x_nonmate):
-        w = torch.cat((x_mate.detach().cpu().float().reshape(1, -1), x_nonmate.detach().cpu().float().reshape(1, -1)), dim=0)
+        w = _triplet_rows(x_mate, x_nonmate)
         self._classifier = _TripletClassifier(w)
         self.net.fc2 = self._classifier
 
@@ -171,7 +179,7 @@ class WhiteboxLightCNN(WhiteboxNetwork):
         self.f_preprocess = lightcnn_preprocess()
 
     def set_triplet_classifier(self, x_mate, x_nonmate):
-        w = torch.cat((x_mate.detach().cpu().float().reshape(1, -1), x_nonmate.detach().cpu().float().reshape(1, -1)), dim=0)
+        w = _triplet_rows(x_mate, x_nonmate)
         self._classifier = _TripletClassifier(w)
         self.net.fc2 = self._classifier
 
@@ -195,7 +203,7 @@ class Whitebox_resnet50_128(WhiteboxNetwork):
         self.fc1 = self._classifier
 
     def set_triplet_classifier(self, x_mate, x_nonmate):
-        w = torch.cat((x_mate.detach().cpu().float().reshape(1, -1), x_nonmate.detach().cpu().float().reshape(1, -1)), dim=0)
+        w = _triplet_rows(x_mate, x_nonmate)
         self._classifier = _TripletClassifier(w)
         self.fc1 = self._classifier
 
